@@ -1,0 +1,998 @@
+// Host side of libbayesod_hip.so: handle, HBM plan, weight folding/packing, launch sequencing and
+// the C ABI of include/bayesod.h.  Mirrors, stage for stage, the call stack of
+// src/retina_net/experiments/run_inference.py:137-149 -> inference_utils.bayes_od_inference
+// -> RetinaNetModel.call.
+#include "../../include/bayesod.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;   // keras BatchNormalization default
+
+thread_local std::string g_create_error;
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+struct Plane {               // bf16 NHWC view with a 1-pixel zero border
+    uint16_t* d = nullptr;
+    int64_t base = 0;        // pixel offset of this view inside d
+    int64_t bstride = 0;     // pixels between consecutive batch items
+    int h = 0, w = 0, C = 0, pitch = 0;
+};
+
+struct PackedConv { uint16_t* w = nullptr; float* bias = nullptr; int cout = 0, cout_pad = 0, taps = 0, kw = 0, cin = 0; };
+
+struct Op {
+    enum Kind { STEM, POOL, CONV } kind;
+    ConvArgs conv;
+    bool is_head3x3 = false;
+    double flops = 0;
+};
+
+uint16_t f2bf(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf2f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+struct bod_context {
+    bod_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    int64_t device_bytes = 0;
+
+    // geometry
+    int sh = 0, sw = 0, ph = 0, pw = 0;                 // stem / pool output
+    int ch[6] = {0}, cw[6] = {0};                       // stage 2..5 sizes (index = stage)
+    int nlev = 0; int lh[8] = {0}, lw[8] = {0};         // pyramid levels p3..p7
+    int64_t lvl_off[8] = {0};                           // padded pixel offset of each level
+    int64_t lvl_p0[8] = {0};                            // dense pixel offset of each level
+    int64_t Ppad = 0; int P = 0, A = 0;
+
+    // weights
+    std::map<std::string, HostTensor> host_w;           // "name/kind"
+    std::map<std::string, PackedConv> packed;
+    float* stem_w = nullptr; float* stem_b = nullptr;
+    bool weights_ready = false, anchors_ready = false, forward_done = false, posterior_done = false,
+         nms_done = false, cluster_done = false;
+
+    // activations
+    float* d_images = nullptr;
+    uint16_t* stem_out = nullptr;
+    Plane pyramid;                                       // all levels, [B][Ppad][256]
+    uint16_t* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
+    float* raw[3] = {nullptr};                           // cls [B,N,P,9C] box [B,N,P,36] cov [B,N,P,90]
+    std::map<std::string, RowEnt*> tables;
+    std::vector<Op> ops;
+    const float* cur_images = nullptr;
+
+    // post
+    float* d_anchors = nullptr;
+    PostBuffers pb{};
+    float* nms_scores = nullptr; int32_t* nms_begin = nullptr; int32_t* nms_sel = nullptr; int32_t* nms_nsel = nullptr;
+    float* out_scores = nullptr; float* out_means = nullptr; float* out_covs = nullptr; float* out_counts = nullptr;
+    float* iou_scratch = nullptr; int64_t iou_cap = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_head, ev_post;
+    double prof_flops = 0;
+
+    bod_status fail(bod_status s, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return s;
+    }
+    template <typename T> bod_status dalloc(T** p, size_t n_elems, bool zero = true) {
+        void* q = nullptr;
+        const size_t bytes = std::max<size_t>(n_elems * sizeof(T), 256);
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return fail(BOD_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        if (zero) {
+            e = hipMemsetAsync(q, 0, bytes, stream);
+            if (e != hipSuccess) return fail(BOD_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+        }
+        allocs.push_back(q);
+        device_bytes += (int64_t)bytes;
+        *p = reinterpret_cast<T*>(q);
+        return BOD_OK;
+    }
+};
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return (h)->fail(BOD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                             __FILE__, __LINE__);                                               \
+    } while (0)
+#define BODCHK(expr) do { bod_status _s = (expr); if (_s != BOD_OK) return _s; } while (0)
+
+namespace {
+
+const char* kHeadPrefix[3] = {"pyramid_classification", "pyramid_regression", "pyramid_cov"};
+const int kHeadConvs[3] = {4, 3, 4};     // RegHeader.call uses 3 towers convs (multitask_headers.py:209-230)
+
+int same_pad_before(int in, int k, int s) {
+    const int out = (in + s - 1) / s;
+    const int total = std::max((out - 1) * s + k - in, 0);
+    return total / 2;
+}
+
+bod_status new_plane(bod_context* h, Plane* p, int B, int hh, int ww, int C) {
+    p->h = hh; p->w = ww; p->C = C; p->pitch = ww + 2; p->base = 0;
+    p->bstride = (int64_t)(hh + 2) * (ww + 2);
+    return h->dalloc(&p->d, (size_t)B * p->bstride * C);
+}
+
+// row table for plane -> plane convolutions. org_* = padded coordinate of the window origin of
+// output (0,0); res optional (nearest-upsampled when its size differs).
+bod_status make_table(bod_context* h, const std::string& key, int B, const Plane& in, const Plane& out,
+                      int stride, int org_y, int org_x, const Plane* res, const RowEnt** tbl) {
+    auto it = h->tables.find(key);
+    if (it != h->tables.end()) { *tbl = it->second; return BOD_OK; }
+    std::vector<RowEnt> rows((size_t)B * out.h * out.w);
+    size_t r = 0;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < out.h; ++y)
+            for (int x = 0; x < out.w; ++x) {
+                RowEnt e{};
+                e.in_off = (int32_t)(in.base + b * in.bstride + (int64_t)(y * stride + org_y) * in.pitch + (x * stride + org_x));
+                e.in_pitch = in.pitch;
+                e.out_off = (int32_t)(out.base + b * out.bstride + (int64_t)(y + 1) * out.pitch + (x + 1));
+                if (res) {
+                    int ry = y, rx = x;
+                    if (res->h != out.h || res->w != out.w) {
+                        ry = std::min((int)std::floor((y + 0.5) * ((double)res->h / out.h)), res->h - 1);
+                        rx = std::min((int)std::floor((x + 0.5) * ((double)res->w / out.w)), res->w - 1);
+                    }
+                    e.res_off = (int32_t)(res->base + b * res->bstride + (int64_t)(ry + 1) * res->pitch + (rx + 1));
+                }
+                rows[r++] = e;
+            }
+    RowEnt* d = nullptr;
+    BODCHK(h->dalloc(&d, rows.size(), false));
+    HIPCHK(h, hipMemcpyAsync(d, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->tables[key] = d;
+    *tbl = d;
+    return BOD_OK;
+}
+
+const HostTensor* find_w(bod_context* h, const std::string& name, int kind) {
+    auto it = h->host_w.find(name + "/" + std::to_string(kind));
+    return it == h->host_w.end() ? nullptr : &it->second;
+}
+
+// Fold BN (double), pack OHWI bf16 padded to cout_pad, upload.
+bod_status pack_conv(bod_context* h, const std::string& name, const std::string& bn, int cout_pad_to,
+                     PackedConv* out) {
+    auto it = h->packed.find(name);
+    if (it != h->packed.end()) { *out = it->second; return BOD_OK; }
+    const HostTensor* k = find_w(h, name, 0);
+    if (!k || k->shape.size() != 4) return h->fail(BOD_ERR_NOT_READY, "missing conv kernel '%s'", name.c_str());
+    const int kh = (int)k->shape[0], kw = (int)k->shape[1], cin = (int)k->shape[2], cout = (int)k->shape[3];
+    const HostTensor* b = find_w(h, name, 1);
+    std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
+    for (int o = 0; o < cout; ++o) shift[o] = b ? (double)b->data[o] : 0.0;
+    if (!bn.empty()) {
+        const HostTensor *g = find_w(h, bn, 2), *be = find_w(h, bn, 3), *mu = find_w(h, bn, 4), *var = find_w(h, bn, 5);
+        if (!g || !be || !mu || !var) return h->fail(BOD_ERR_NOT_READY, "missing batch-norm '%s'", bn.c_str());
+        for (int o = 0; o < cout; ++o) {
+            const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + (double)BN_EPS);
+            scale[o] = s;
+            shift[o] = (shift[o] - (double)mu->data[o]) * s + (double)be->data[o];
+        }
+    }
+    PackedConv pc;
+    pc.cout = cout; pc.taps = kh * kw; pc.kw = kw; pc.cin = cin;
+    pc.cout_pad = ((cout + cout_pad_to - 1) / cout_pad_to) * cout_pad_to;
+    std::vector<uint16_t> w((size_t)pc.cout_pad * pc.taps * cin, 0);
+    std::vector<float> bias(pc.cout_pad, 0.f);
+    for (int o = 0; o < cout; ++o) {
+        bias[o] = (float)shift[o];
+        for (int t = 0; t < pc.taps; ++t)
+            for (int c = 0; c < cin; ++c) {
+                const double v = (double)k->data[((size_t)t * cin + c) * cout + o] * scale[o];
+                w[((size_t)o * pc.taps + t) * cin + c] = f2bf((float)v);
+            }
+    }
+    BODCHK(h->dalloc(&pc.w, w.size(), false));
+    BODCHK(h->dalloc(&pc.bias, bias.size(), false));
+    HIPCHK(h, hipMemcpyAsync(pc.w, w.data(), w.size() * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->packed[name] = pc;
+    *out = pc;
+    return BOD_OK;
+}
+
+ConvArgs base_args(const PackedConv& pc, const RowEnt* rows, int M, int in_cstride, int out_cstride) {
+    ConvArgs a{};
+    a.rows = rows; a.M = M; a.taps = pc.taps; a.KW = pc.kw; a.cin = pc.cin;
+    a.in_cstride = in_cstride; a.cout_pad = pc.cout_pad; a.cout_valid = pc.cout;
+    a.out_cstride = out_cstride; a.res_cstride = out_cstride; a.groups = 1;
+    a.fan_count = 1; a.fan_stride = 0;
+    return a;
+}
+
+// conv + folded BN (+residual) (+ReLU) between two planes
+bod_status add_conv(bod_context* h, const std::string& name, const std::string& bn, const Plane& in,
+                    const Plane& out, int stride, bool same, bool relu, const Plane* res,
+                    uint16_t* out_relu = nullptr) {
+    PackedConv pc;
+    BODCHK(pack_conv(h, name, bn, 64, &pc));
+    if (pc.cin != in.C || pc.cout != out.C)
+        return h->fail(BOD_ERR_INVALID_ARG, "conv '%s': weight shape [%d->%d] does not match planes [%d->%d]",
+                       name.c_str(), pc.cin, pc.cout, in.C, out.C);
+    const int kh = pc.taps / pc.kw;
+    int oy = 1, ox = 1;
+    if (same) { oy = 1 - same_pad_before(in.h, kh, stride); ox = 1 - same_pad_before(in.w, pc.kw, stride); }
+    // the table depends on plane geometry only (offsets are relative to each buffer's base)
+    char key[256];
+    snprintf(key, sizeof key, "pp:%lld,%lld,%d:%lld,%lld,%d,%d,%d:%d:%d:%d:%lld,%lld,%d,%d,%d", (long long)in.base,
+             (long long)in.bstride, in.pitch, (long long)out.base, (long long)out.bstride, out.pitch, out.h, out.w,
+             stride, oy, ox, res ? (long long)res->base : -1LL, res ? (long long)res->bstride : 0LL,
+             res ? res->pitch : 0, res ? res->h : 0, res ? res->w : 0);
+    const RowEnt* tbl = nullptr;
+    const int B = h->cfg.batch;
+    BODCHK(make_table(h, key, B, in, out, stride, oy, ox, res, &tbl));
+    Op op; op.kind = Op::CONV;
+    op.conv = base_args(pc, tbl, B * out.h * out.w, in.C, out.C);
+    op.conv.g[0] = ConvGroup{in.d, pc.w, pc.bias, out.d, res ? res->d : nullptr, out_relu, 0, 0};
+    op.conv.flags = relu ? CONV_RELU : 0;
+    op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
+    h->ops.push_back(op);
+    return BOD_OK;
+}
+
+bod_status build_geometry(bod_context* h) {
+    const bod_config& c = h->cfg;
+    const int H = c.image_h, W = c.image_w;
+    if (H < 64 || W < 64) return h->fail(BOD_ERR_INVALID_ARG, "image size %dx%d too small", H, W);
+    h->sh = (H - 7) / 2 + 1; h->sw = (W - 7) / 2 + 1;
+    h->ph = (h->sh + 2 - 3) / 2 + 1; h->pw = (h->sw + 4 - 3) / 2 + 1;
+    h->ch[2] = h->ph; h->cw[2] = h->pw;
+    for (int s = 3; s <= 5; ++s) { h->ch[s] = (h->ch[s - 1] - 1) / 2 + 1; h->cw[s] = (h->cw[s - 1] - 1) / 2 + 1; }
+    if (c.min_level != 3 || c.max_level != 7)
+        return h->fail(BOD_ERR_INVALID_ARG, "only pyramid levels 3..7 are supported (got %d..%d)", c.min_level, c.max_level);
+    h->nlev = 5;
+    h->lh[0] = h->ch[3]; h->lw[0] = h->cw[3];
+    h->lh[1] = h->ch[4]; h->lw[1] = h->cw[4];
+    h->lh[2] = h->ch[5]; h->lw[2] = h->cw[5];
+    h->lh[3] = (h->lh[2] + 1) / 2; h->lw[3] = (h->lw[2] + 1) / 2;
+    h->lh[4] = (h->lh[3] + 1) / 2; h->lw[4] = (h->lw[3] + 1) / 2;
+    int64_t pp = 0; int p = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int stride = 1 << (l + 3);
+        const int ah = (H + stride - 1) / stride, aw = (W + stride - 1) / stride;   // anchor grid (fpn_anchor_generator.py:28-29)
+        if (ah != h->lh[l] || aw != h->lw[l])
+            return h->fail(BOD_ERR_INVALID_ARG,
+                           "pyramid level p%d is %dx%d but the anchor grid is %dx%d for a %dx%d image "
+                           "(the reference's tf.concat of head outputs with anchors would mismatch too)",
+                           l + 3, h->lh[l], h->lw[l], ah, aw, H, W);
+        h->lvl_off[l] = pp; h->lvl_p0[l] = p;
+        pp += (int64_t)(h->lh[l] + 2) * (h->lw[l] + 2);
+        p += h->lh[l] * h->lw[l];
+    }
+    h->Ppad = pp; h->P = p; h->A = p * c.anchors_per_location;
+    return BOD_OK;
+}
+
+Plane level_view(bod_context* h, int l) {
+    Plane v = h->pyramid;
+    v.base = h->lvl_off[l]; v.h = h->lh[l]; v.w = h->lw[l]; v.pitch = h->lw[l] + 2;
+    return v;
+}
+
+bod_status build_plan(bod_context* h) {
+    const bod_config& c = h->cfg;
+    const int B = c.batch, N = c.mc_samples;
+    h->ops.clear();
+    // ---------------- stem
+    {
+        const HostTensor* k = find_w(h, "conv1", 0);
+        if (!k || k->shape.size() != 4 || k->shape[0] != 7 || k->shape[2] != 3 || k->shape[3] != 64)
+            return h->fail(BOD_ERR_NOT_READY, "missing / malformed stem kernel 'conv1' [7,7,3,64]");
+        const HostTensor* b = find_w(h, "conv1", 1);
+        const HostTensor *g = find_w(h, "bn_conv1", 2), *be = find_w(h, "bn_conv1", 3), *mu = find_w(h, "bn_conv1", 4), *var = find_w(h, "bn_conv1", 5);
+        if (!g || !be || !mu || !var) return h->fail(BOD_ERR_NOT_READY, "missing batch-norm 'bn_conv1'");
+        std::vector<float> w(7 * 7 * 3 * 64), bias(64);
+        for (int o = 0; o < 64; ++o) {
+            const double s = (double)g->data[o] / std::sqrt((double)var->data[o] + (double)BN_EPS);
+            bias[o] = (float)((((b ? (double)b->data[o] : 0.0) - (double)mu->data[o]) * s) + (double)be->data[o]);
+            for (int t = 0; t < 147; ++t) w[(size_t)t * 64 + o] = (float)((double)k->data[(size_t)t * 64 + o] * s);
+        }
+        BODCHK(h->dalloc(&h->stem_w, w.size(), false));
+        BODCHK(h->dalloc(&h->stem_b, bias.size(), false));
+        HIPCHK(h, hipMemcpyAsync(h->stem_w, w.data(), w.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->stem_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        BODCHK(h->dalloc(&h->stem_out, (size_t)B * h->sh * h->sw * 64));
+        Op s; s.kind = Op::STEM; h->ops.push_back(s);
+        Op p; p.kind = Op::POOL; h->ops.push_back(p);
+    }
+    // ---------------- ResNet-50 stages (feature_extractor.py:104-139)
+    Plane x;
+    BODCHK(new_plane(h, &x, B, h->ph, h->pw, 64));
+    Plane pool_out = x;
+    h->ops[1].conv.g[0].out = pool_out.d;   // remember pool destination
+    const char* blocks[6] = {"", "", "abc", "abcd", "abcdef", "abc"};
+    const int f1s[6] = {0, 0, 64, 128, 256, 512};
+    Plane taps[6];
+    for (int st = 2; st <= 5; ++st) {
+        const int f1 = f1s[st], f3 = f1 * 4, hh = h->ch[st], ww = h->cw[st];
+        const int first_stride = st == 2 ? 1 : 2;
+        Plane t1, t2, sc, oa, ob;
+        BODCHK(new_plane(h, &t1, B, hh, ww, f1));
+        BODCHK(new_plane(h, &t2, B, hh, ww, f1));
+        BODCHK(new_plane(h, &sc, B, hh, ww, f3));
+        BODCHK(new_plane(h, &oa, B, hh, ww, f3));
+        BODCHK(new_plane(h, &ob, B, hh, ww, f3));
+        bool use_a = true;
+        for (const char* bl = blocks[st]; *bl; ++bl) {
+            char cb[64], bb[64];
+            snprintf(cb, sizeof cb, "res%d%c_branch", st, *bl);
+            snprintf(bb, sizeof bb, "bn%d%c_branch", st, *bl);
+            const std::string c_(cb), b_(bb);
+            Plane& out = use_a ? oa : ob;
+            if (*bl == 'a') {
+                BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, first_stride, false, true, nullptr));
+                BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
+                BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
+                BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &sc));
+                // the C3 / C4 taps are the block-'a' outputs (:119-120,:126-127): keep them alive
+                if (st == 3 || st == 4) {
+                    taps[st] = out;
+                    Plane fresh;
+                    BODCHK(new_plane(h, &fresh, B, hh, ww, f3));
+                    x = out;
+                    if (use_a) oa = fresh; else ob = fresh;
+                    use_a = !use_a;
+                    continue;
+                }
+            } else {
+                BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, 1, false, true, nullptr));
+                BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
+                BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &x));
+            }
+            x = out;
+            use_a = !use_a;
+        }
+    }
+    const Plane c5 = x, c4 = taps[4], c3 = taps[3];
+
+    // ---------------- FPN (feature_decoder.py:136-171)
+    h->pyramid.C = 256; h->pyramid.bstride = h->Ppad;
+    BODCHK(h->dalloc(&h->pyramid.d, (size_t)B * h->Ppad * 256));
+    Plane c5r, m4, m3, p6relu;
+    BODCHK(new_plane(h, &c5r, B, h->lh[2], h->lw[2], 256));
+    BODCHK(new_plane(h, &m4, B, h->lh[1], h->lw[1], 256));
+    BODCHK(new_plane(h, &m3, B, h->lh[0], h->lw[0], 256));
+    // relu(P6) shares the pyramid layout so one row table serves both outputs of the P6 conv
+    uint16_t* p6relu_buf = nullptr;
+    BODCHK(h->dalloc(&p6relu_buf, (size_t)B * h->Ppad * 256));
+    p6relu = h->pyramid; p6relu.d = p6relu_buf;
+    BODCHK(add_conv(h, "C5_reduced", "", c5, c5r, 1, false, false, nullptr));
+    BODCHK(add_conv(h, "P5", "", c5r, level_view(h, 2), 1, true, false, nullptr));
+    BODCHK(add_conv(h, "P6", "", c5, level_view(h, 3), 2, true, false, nullptr, p6relu_buf));
+    {
+        Plane v = p6relu; v.base = h->lvl_off[3]; v.h = h->lh[3]; v.w = h->lw[3]; v.pitch = h->lw[3] + 2;
+        BODCHK(add_conv(h, "P7", "", v, level_view(h, 4), 2, true, false, nullptr));
+    }
+    BODCHK(add_conv(h, "C4_reduced", "", c4, m4, 1, false, false, &c5r));     // + nearest-up(c5r)
+    BODCHK(add_conv(h, "P4", "", m4, level_view(h, 1), 1, true, false, nullptr));
+    BODCHK(add_conv(h, "C3_reduced", "", c3, m3, 1, false, false, &m4));      // + nearest-up(m4) (:162-167)
+    BODCHK(add_conv(h, "P3", "", m3, level_view(h, 0), 1, true, false, nullptr));
+
+    // ---------------- heads (multitask_headers.py; retinanet_model.py:78-109)
+    const size_t act_elems = (size_t)B * N * h->Ppad * 256;
+    for (int hd = 0; hd < 3; ++hd) {
+        if (hd == 2 && !c.has_covar_head) continue;
+        BODCHK(h->dalloc(&h->head_act[hd][0], act_elems));
+        BODCHK(h->dalloc(&h->head_act[hd][1], act_elems));
+    }
+    const int out_ch[3] = {c.anchors_per_location * c.num_classes, c.anchors_per_location * 4, c.anchors_per_location * 10};
+    for (int hd = 0; hd < 3; ++hd) {
+        if (hd == 2 && !c.has_covar_head) continue;
+        BODCHK(h->dalloc(&h->raw[hd], (size_t)B * N * h->P * out_ch[hd]));
+    }
+    // row tables: layer 1 (pyramid -> N dropout variants), layers 2.. (per sample), output 1x1
+    std::vector<RowEnt> t1((size_t)B * h->P), t2((size_t)B * N * h->P), t3((size_t)B * N * h->P);
+    {
+        size_t r1 = 0, r2 = 0;
+        for (int b = 0; b < B; ++b) {
+            for (int l = 0; l < 5; ++l)
+                for (int y = 0; y < h->lh[l]; ++y)
+                    for (int xq = 0; xq < h->lw[l]; ++xq) {
+                        const int pitch = h->lw[l] + 2;
+                        RowEnt e{};
+                        e.in_off = (int32_t)((int64_t)b * h->Ppad + h->lvl_off[l] + (int64_t)y * pitch + xq);
+                        e.in_pitch = pitch;
+                        e.out_off = (int32_t)((int64_t)b * N * h->Ppad + h->lvl_off[l] + (int64_t)(y + 1) * pitch + (xq + 1));
+                        e.rng_p = (int32_t)(h->lvl_p0[l] + y * h->lw[l] + xq);
+                        e.rng_zs = (b << 16);
+                        t1[r1++] = e;
+                    }
+            for (int n = 0; n < N; ++n)
+                for (int l = 0; l < 5; ++l)
+                    for (int y = 0; y < h->lh[l]; ++y)
+                        for (int xq = 0; xq < h->lw[l]; ++xq) {
+                            const int pitch = h->lw[l] + 2;
+                            const int64_t plane0 = ((int64_t)b * N + n) * h->Ppad + h->lvl_off[l];
+                            const int32_t dense = (int32_t)(h->lvl_p0[l] + y * h->lw[l] + xq);
+                            RowEnt e{};
+                            e.in_off = (int32_t)(plane0 + (int64_t)y * pitch + xq);
+                            e.in_pitch = pitch;
+                            e.out_off = (int32_t)(plane0 + (int64_t)(y + 1) * pitch + (xq + 1));
+                            e.rng_p = dense;
+                            e.rng_zs = n | (b << 16);
+                            t2[r2] = e;
+                            RowEnt f = e;
+                            f.in_off = e.out_off;                 // 1x1 reads the centre pixel
+                            f.out_off = (int32_t)(((int64_t)b * N + n) * h->P + dense);
+                            t3[r2] = f;
+                            ++r2;
+                        }
+        }
+    }
+    RowEnt *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+    BODCHK(h->dalloc(&d1, t1.size(), false));
+    BODCHK(h->dalloc(&d2, t2.size(), false));
+    BODCHK(h->dalloc(&d3, t3.size(), false));
+    HIPCHK(h, hipMemcpyAsync(d1, t1.data(), t1.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d2, t2.data(), t2.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d3, t3.data(), t3.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+
+    const bool mc = N > 1;                                  // mc_dropout_enabled (retinanet_model.py:74-77)
+    const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 4294967296.0);
+    const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
+    const int nheads = c.has_covar_head ? 3 : 2;
+    // which heads are still running a tower conv at `layer`
+    for (int layer = 0; layer < 4; ++layer) {
+        Op op; op.kind = Op::CONV; op.is_head3x3 = true;
+        int g = 0; PackedConv pc0{};
+        for (int hd = 0; hd < nheads; ++hd) {
+            if (layer >= kHeadConvs[hd]) continue;
+            PackedConv pc;
+            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc));
+            if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
+                return h->fail(BOD_ERR_INVALID_ARG, "head conv %s_%d must be 3x3 256->256", kHeadPrefix[hd], layer);
+            ConvGroup cg{};
+            cg.in = layer == 0 ? h->pyramid.d : h->head_act[hd][(layer + 1) & 1];
+            cg.w = pc.w; cg.bias = pc.bias;
+            cg.out = h->head_act[hd][layer & 1];
+            cg.layer_id = hd * 4 + layer;
+            op.conv.g[g] = cg;
+            if (g == 0) pc0 = pc;
+            ++g;
+        }
+        const int M = layer == 0 ? B * h->P : B * N * h->P;
+        ConvArgs a = base_args(pc0, layer == 0 ? d1 : d2, M, 256, 256);
+        for (int q = 0; q < g; ++q) a.g[q] = op.conv.g[q];
+        a.groups = g;
+        a.flags = CONV_RELU | (mc ? CONV_DROPOUT : 0);
+        a.fan_count = layer == 0 ? N : 1;
+        a.fan_stride = (int32_t)h->Ppad;
+        a.drop_threshold = thr; a.drop_scale = dscale;
+        op.conv = a;
+        op.flops = 2.0 * M * 256.0 * 2304.0 * g;
+        h->ops.push_back(op);
+    }
+    for (int hd = 0; hd < nheads; ++hd) {
+        PackedConv pc;
+        BODCHK(pack_conv(h, kHeadPrefix[hd], "", 64, &pc));
+        if (pc.cin != 256 || pc.cout != out_ch[hd] || pc.taps != 1)
+            return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], pc.cin, pc.cout);
+        Op op; op.kind = Op::CONV;
+        ConvArgs a = base_args(pc, d3, B * N * h->P, 256, out_ch[hd]);
+        a.g[0] = ConvGroup{h->head_act[hd][(kHeadConvs[hd] - 1) & 1], pc.w, pc.bias, h->raw[hd], nullptr, nullptr, 0, 0};
+        a.flags = CONV_OUT_F32;
+        op.conv = a;
+        op.flops = 2.0 * a.M * pc.cout * 256.0;
+        h->ops.push_back(op);
+    }
+    return BOD_OK;
+}
+
+bod_status alloc_post(bod_context* h) {
+    const bod_config& c = h->cfg;
+    const size_t BA = (size_t)c.batch * h->A;
+    const int nblocks = (h->A + 255) / 256;
+    PostBuffers& p = h->pb;
+    BODCHK(h->dalloc(&p.keep, BA));
+    BODCHK(h->dalloc(&p.d_counts, BA * c.num_classes));
+    BODCHK(h->dalloc(&p.block_counts, (size_t)c.batch * nblocks));
+    BODCHK(h->dalloc(&p.num_kept, (size_t)c.batch));
+    BODCHK(h->dalloc(&p.counts, BA * c.num_classes));
+    BODCHK(h->dalloc(&p.score, BA * c.num_classes));
+    BODCHK(h->dalloc(&p.means, BA * 4));
+    BODCHK(h->dalloc(&p.covs, BA * 16));
+    BODCHK(h->dalloc(&p.ranking, BA));
+    BODCHK(h->dalloc(&p.corners, BA * 4));
+    BODCHK(h->dalloc(&p.anchor_index, BA));
+    BODCHK(h->dalloc(&h->d_anchors, (size_t)h->A * 4));
+    BODCHK(h->dalloc(&h->nms_scores, BA));
+    BODCHK(h->dalloc(&h->nms_begin, BA));
+    const size_t BK = (size_t)c.batch * c.nms_max_output_size;
+    BODCHK(h->dalloc(&h->nms_sel, BK));
+    BODCHK(h->dalloc(&h->nms_nsel, (size_t)c.batch));
+    BODCHK(h->dalloc(&h->out_scores, BK * c.num_classes));
+    BODCHK(h->dalloc(&h->out_means, BK * 4));
+    BODCHK(h->dalloc(&h->out_covs, BK * 16));
+    BODCHK(h->dalloc(&h->out_counts, BK * c.num_classes));
+    BODCHK(h->dalloc(&h->d_images, (size_t)c.batch * c.image_h * c.image_w * 3));
+    return BOD_OK;
+}
+
+PostCfg post_cfg(bod_context* h, uint64_t seed, uint32_t first_image) {
+    const bod_config& c = h->cfg;
+    PostCfg p{};
+    p.B = c.batch; p.N = c.mc_samples; p.A = h->A; p.C = c.num_classes; p.draws = c.num_categorical_draws;
+    p.use_full_covar = c.use_full_covar; p.has_covar = c.has_covar_head; p.dirichlet = c.dirichlet_non_informative;
+    p.gaussian_iso = c.gaussian_isotropic; p.ranking_method = c.ranking_method; p.iso_var = c.isotropic_variance;
+    p.kitti_sh = c.kitti_scale_h; p.kitti_sw = c.kitti_scale_w;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.image_base = first_image;
+    return p;
+}
+
+bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image) {
+    const bod_config& c = h->cfg;
+    for (Op& op : h->ops) {
+        switch (op.kind) {
+            case Op::STEM:
+                HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, c.batch, c.image_h,
+                                           c.image_w, h->sh, h->sw, h->stream));
+                break;
+            case Op::POOL:
+                HIPCHK(h, launch_stem_pool(h->stem_out, reinterpret_cast<uint16_t*>(op.conv.g[0].out), c.batch,
+                                           h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
+                break;
+            case Op::CONV: {
+                op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
+                op.conv.image_base = first_image;
+                const bool timed = h->profiling && op.is_head3x3;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timed) {
+                    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+                    HIPCHK(h, hipEventRecord(e0, h->stream));
+                }
+                HIPCHK(h, launch_conv_igemm(op.conv, h->stream));
+                if (timed) {
+                    HIPCHK(h, hipEventRecord(e1, h->stream));
+                    h->ev_head.emplace_back(e0, e1);
+                    h->prof_flops += op.flops;
+                }
+                break;
+            }
+        }
+    }
+    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    return BOD_OK;
+}
+
+bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
+    if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
+    PostCfg pc = post_cfg(h, seed, first_image);
+    PostBuffers pb = h->pb;
+    pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+        HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    HIPCHK(h, launch_posterior(pc, pb, h->stream));
+    if (h->cfg.ranking_method == BOD_RANK_JOINT_ENTROPY && h->cfg.gaussian_isotropic && h->cfg.dirichlet_non_informative)
+        HIPCHK(h, launch_joint_entropy_rank(pc, pb, h->stream));
+    if (h->profiling) { HIPCHK(h, hipEventRecord(e1, h->stream)); h->ev_post.emplace_back(e0, e1); }
+    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    return BOD_OK;
+}
+
+bod_status run_nms(bod_context* h) {
+    const bod_config& c = h->cfg;
+    NmsArgs a{};
+    a.B = c.batch; a.A = h->A; a.num_kept = h->pb.num_kept; a.corners = h->pb.corners; a.ranking = h->pb.ranking;
+    a.work_scores = h->nms_scores; a.work_begin = h->nms_begin; a.selected = h->nms_sel; a.num_selected = h->nms_nsel;
+    a.max_out = c.nms_max_output_size; a.iou_thr = c.nms_iou_threshold; a.sigma = c.nms_soft_sigma; a.variant = c.nms_variant;
+    HIPCHK(h, launch_nms(a, h->stream));
+    h->nms_done = true; h->cluster_done = false;
+    return BOD_OK;
+}
+
+bod_status run_cluster(bod_context* h) {
+    const bod_config& c = h->cfg;
+    ClusterArgs a{};
+    a.B = c.batch; a.A = h->A; a.C = c.num_classes; a.max_out = c.nms_max_output_size;
+    a.num_kept = h->pb.num_kept; a.selected = h->nms_sel; a.num_selected = h->nms_nsel;
+    a.corners = h->pb.corners; a.counts = h->pb.counts; a.means = h->pb.means; a.covs = h->pb.covs;
+    a.thr = c.nms_iou_threshold;
+    a.out_scores = h->out_scores; a.out_means = h->out_means; a.out_covs = h->out_covs; a.out_counts = h->out_counts;
+    HIPCHK(h, launch_cluster_fuse(a, h->stream));
+    h->cluster_done = true;
+    return BOD_OK;
+}
+
+bod_status stage_images(bod_context* h, const float* images, int on_device, const float** dev) {
+    if (!images) return h->fail(BOD_ERR_INVALID_ARG, "images is NULL");
+    if (on_device) { *dev = images; return BOD_OK; }
+    const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(h->d_images, images, bytes, hipMemcpyHostToDevice, h->stream));
+    *dev = h->d_images;
+    return BOD_OK;
+}
+
+template <typename T>
+bod_status d2h(bod_context* h, T* dst, const T* src, size_t n) {
+    if (!dst || n == 0) return BOD_OK;
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    return BOD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* bod_version(void) { return "bayesod-hip 0.1.0 (gfx950)"; }
+
+const char* bod_last_error(bod_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+bod_status bod_create(const bod_config* cfg, bod_handle* out) {
+    if (!cfg || !out) { g_create_error = "bod_create: NULL argument"; return BOD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "no HIP device visible: libbayesod_hip has no CPU fallback";
+        return BOD_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<bod_context> h(new bod_context());
+    h->cfg = *cfg;
+    auto bail = [&](bod_status s) { g_create_error = h->err; return s; };
+    const bod_config& c = h->cfg;
+    if (c.device < 0 || c.device >= ndev) return bail(h->fail(BOD_ERR_INVALID_ARG, "device %d out of range [0,%d)", c.device, ndev));
+    if (c.batch < 1 || c.batch > 4096 || c.mc_samples < 1 || c.mc_samples > 4096)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "batch=%d / mc_samples=%d out of range", c.batch, c.mc_samples));
+    if (c.num_classes != 4 && c.num_classes != 8)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "num_classes (incl. background) must be 4 or 8, got %d", c.num_classes));
+    if (c.anchors_per_location < 1 || (c.anchors_per_location * c.num_classes) % 4 != 0)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "anchors_per_location=%d unsupported", c.anchors_per_location));
+    if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) return bail(h->fail(BOD_ERR_INVALID_ARG, "dropout_rate must be in [0,1)"));
+    if (c.num_categorical_draws < 1 || c.num_categorical_draws > 1024) return bail(h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range"));
+    if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
+    if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+    bod_status s = build_geometry(h.get());
+    if (s != BOD_OK) return bail(s);
+    if ((int64_t)c.batch * c.mc_samples * h->Ppad >= (1LL << 31))
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "batch*mc_samples*pixels exceeds 2^31 rows"));
+    s = alloc_post(h.get());
+    if (s != BOD_OK) return bail(s);
+    *out = h.release();
+    return BOD_OK;
+}
+
+bod_status bod_destroy(bod_handle h) {
+    if (!h) return BOD_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->iou_scratch) hipFree(h->iou_scratch);
+    for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return BOD_OK;
+}
+
+bod_status bod_query_sizes(bod_handle h, bod_sizes* out) {
+    if (!h || !out) return BOD_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->num_pixels = h->P; out->num_anchors = h->A; out->num_levels = h->nlev;
+    for (int l = 0; l < h->nlev; ++l) { out->level_h[l] = h->lh[l]; out->level_w[l] = h->lw[l]; }
+    out->max_detections = h->cfg.nms_max_output_size;
+    out->device_bytes = h->device_bytes;
+    return BOD_OK;
+}
+
+bod_status bod_update_config(bod_handle h, const bod_config* cfg) {
+    if (!h || !cfg) return BOD_ERR_INVALID_ARG;
+    const bod_config& o = h->cfg;
+    if (cfg->device != o.device || cfg->image_h != o.image_h || cfg->image_w != o.image_w || cfg->batch != o.batch ||
+        cfg->mc_samples != o.mc_samples || cfg->num_classes != o.num_classes ||
+        cfg->anchors_per_location != o.anchors_per_location || cfg->min_level != o.min_level ||
+        cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate)
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: geometry / model fields cannot change on a live handle");
+    if (cfg->nms_max_output_size != o.nms_max_output_size)
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: nms_max_output_size sizes device buffers and cannot change");
+    if (cfg->num_categorical_draws < 1 || cfg->num_categorical_draws > 1024)
+        return h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range");
+    h->cfg = *cfg;
+    return BOD_OK;
+}
+
+bod_status bod_load_weight(bod_handle h, const char* name, int32_t kind, const int64_t* shape, int32_t ndim, const float* data) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!name || !shape || !data || ndim < 1 || ndim > 4 || kind < 0 || kind > 5)
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_load_weight: bad argument");
+    if ((kind == 0) != (ndim == 4)) return h->fail(BOD_ERR_INVALID_ARG, "bod_load_weight('%s'): kind %d needs ndim %d", name, kind, kind == 0 ? 4 : 1);
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return h->fail(BOD_ERR_INVALID_ARG, "non-positive dim"); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    h->host_w[std::string(name) + "/" + std::to_string(kind)] = std::move(t);
+    h->weights_ready = false;
+    return BOD_OK;
+}
+
+bod_status bod_finalize_weights(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->weights_ready) return BOD_OK;
+    if (!h->ops.empty()) return h->fail(BOD_ERR_INVALID_ARG, "weights were already finalized; create a new handle to reload");
+    BODCHK(build_plan(h));
+    h->host_w.clear();
+    h->weights_ready = true;
+    return BOD_OK;
+}
+
+bod_status bod_set_anchors(bod_handle h, const float* anchors, int32_t n) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!anchors || n != h->A) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_anchors: expected %d anchors, got %d", h->A, n);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_anchors, anchors, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->anchors_ready = true;
+    return BOD_OK;
+}
+
+bod_status bod_upload_images(bod_handle h, const float* host_images) {
+    if (!h || !host_images) return BOD_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(h->d_images, host_images, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+const float* bod_device_images(bod_handle h) { return h ? h->d_images : nullptr; }
+
+bod_status bod_synchronize(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const float* dev = nullptr;
+    BODCHK(stage_images(h, images, on_device, &dev));
+    return run_forward(h, dev, seed, first_image_id);
+}
+
+bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* cov) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
+    const bod_config& c = h->cfg;
+    const size_t n = (size_t)c.batch * c.mc_samples * h->A;
+    BODCHK(d2h(h, cls, h->raw[0], n * c.num_classes));
+    BODCHK(d2h(h, box, h->raw[1], n * 4));
+    if (cov) {
+        if (!c.has_covar_head) return h->fail(BOD_ERR_INVALID_ARG, "model has no covariance head");
+        BODCHK(d2h(h, cov, h->raw[2], n * 10));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const float* cov) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized (raw buffers are allocated with the plan)");
+    const bod_config& c = h->cfg;
+    const size_t n = (size_t)c.batch * c.mc_samples * h->A;
+    if (cls) HIPCHK(h, hipMemcpyAsync(h->raw[0], cls, n * c.num_classes * 4, hipMemcpyHostToDevice, h->stream));
+    if (box) HIPCHK(h, hipMemcpyAsync(h->raw[1], box, n * 16, hipMemcpyHostToDevice, h->stream));
+    if (cov && c.has_covar_head) HIPCHK(h, hipMemcpyAsync(h->raw[2], cov, n * 40, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    return BOD_OK;
+}
+
+bod_status bod_get_pyramid(bod_handle h, int32_t l, float* out) {
+    if (!h || !out) return BOD_ERR_INVALID_ARG;
+    if (!h->forward_done || !h->pyramid.d) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
+    if (l < 0 || l >= h->nlev) return h->fail(BOD_ERR_INVALID_ARG, "level index %d out of range", l);
+    const int B = h->cfg.batch;
+    std::vector<uint16_t> tmp((size_t)B * h->Ppad * 256);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pyramid.d, tmp.size() * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int hh = h->lh[l], ww = h->lw[l], pitch = ww + 2;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < hh; ++y)
+            for (int x = 0; x < ww; ++x) {
+                const uint16_t* s = &tmp[((size_t)b * h->Ppad + h->lvl_off[l] + (size_t)(y + 1) * pitch + (x + 1)) * 256];
+                float* d = out + (((size_t)b * hh + y) * ww + x) * 256;
+                for (int ch = 0; ch < 256; ++ch) d[ch] = bf2f(s[ch]);
+            }
+    return BOD_OK;
+}
+
+bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward / bod_set_raw has not run");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return run_posterior(h, seed, first_image_id);
+}
+
+bod_status bod_get_num_kept(bod_handle h, int32_t* out) {
+    if (!h || !out) return BOD_ERR_INVALID_ARG;
+    if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
+    BODCHK(d2h(h, out, h->pb.num_kept, (size_t)h->cfg.batch));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+static bod_status image_m(bod_handle h, int32_t img, int32_t* m) {
+    if (img < 0 || img >= h->cfg.batch) return h->fail(BOD_ERR_INVALID_ARG, "image index %d out of range", img);
+    HIPCHK(h, hipMemcpyAsync(m, h->pb.num_kept + img, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_get_posterior(bod_handle h, int32_t img, float* counts, float* score, float* means, float* covs, float* ranking, int32_t* anchor_index) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
+    int32_t m = 0;
+    BODCHK(image_m(h, img, &m));
+    const size_t o = (size_t)img * h->A, C = h->cfg.num_classes;
+    BODCHK(d2h(h, counts, h->pb.counts + o * C, m * C));
+    BODCHK(d2h(h, score, h->pb.score + o * C, m * C));
+    BODCHK(d2h(h, means, h->pb.means + o * 4, (size_t)m * 4));
+    BODCHK(d2h(h, covs, h->pb.covs + o * 16, (size_t)m * 16));
+    BODCHK(d2h(h, ranking, h->pb.ranking + o, (size_t)m));
+    BODCHK(d2h(h, anchor_index, h->pb.anchor_index + o, (size_t)m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_set_posterior(bod_handle h, int32_t img, int32_t m, const float* counts, const float* means, const float* covs, const float* ranking) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (img < 0 || img >= h->cfg.batch || m < 0 || m > h->A) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_posterior: bad image index / M");
+    if (m > 0 && (!counts || !means || !covs || !ranking)) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_posterior: NULL array");
+    const size_t o = (size_t)img * h->A, C = h->cfg.num_classes;
+    std::vector<float> corners((size_t)m * 4);
+    for (int i = 0; i < m; ++i) {
+        const float v = means[i * 4], u = means[i * 4 + 1], hh = means[i * 4 + 2], ww = means[i * 4 + 3];
+        corners[i * 4] = v - hh / 2.0f; corners[i * 4 + 1] = u - ww / 2.0f;
+        corners[i * 4 + 2] = v + hh / 2.0f; corners[i * 4 + 3] = u + ww / 2.0f;
+    }
+    if (m > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->pb.counts + o * C, counts, m * C * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pb.means + o * 4, means, (size_t)m * 16, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pb.covs + o * 16, covs, (size_t)m * 64, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pb.ranking + o, ranking, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pb.corners + o * 4, corners.data(), (size_t)m * 16, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pb.num_kept + img, &m, 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    return BOD_OK;
+}
+
+bod_status bod_nms(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return run_nms(h);
+}
+
+bod_status bod_get_nms(bod_handle h, int32_t img, int32_t* indices, int32_t* num) {
+    if (!h || !num) return BOD_ERR_INVALID_ARG;
+    if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms has not run");
+    if (img < 0 || img >= h->cfg.batch) return h->fail(BOD_ERR_INVALID_ARG, "image index out of range");
+    HIPCHK(h, hipMemcpyAsync(num, h->nms_nsel + img, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    BODCHK(d2h(h, indices, h->nms_sel + (size_t)img * h->cfg.nms_max_output_size, (size_t)*num));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_get_iou_matrix(bod_handle h, int32_t img, float* iou) {
+    if (!h || !iou) return BOD_ERR_INVALID_ARG;
+    if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
+    int32_t m = 0;
+    BODCHK(image_m(h, img, &m));
+    if (m == 0) return BOD_OK;
+    const int64_t need = (int64_t)m * m;
+    if (need > h->iou_cap) {
+        if (h->iou_scratch) hipFree(h->iou_scratch);
+        h->iou_scratch = nullptr; h->iou_cap = 0;
+        if (hipMalloc((void**)&h->iou_scratch, (size_t)need * 4) != hipSuccess)
+            return h->fail(BOD_ERR_OOM, "cannot allocate %lld-element IoU matrix", (long long)need);
+        h->iou_cap = need;
+    }
+    HIPCHK(h, launch_iou_matrix(h->pb.corners + (size_t)img * h->A * 4, m, h->iou_scratch, h->stream));
+    BODCHK(d2h(h, iou, h->iou_scratch, (size_t)need));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_cluster_fuse(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms has not run");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return run_cluster(h);
+}
+
+bod_status bod_get_detections(bod_handle h, int32_t img, int32_t* num, float* scores, float* means, float* covs, float* counts) {
+    if (!h || !num) return BOD_ERR_INVALID_ARG;
+    if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_cluster_fuse has not run");
+    if (img < 0 || img >= h->cfg.batch) return h->fail(BOD_ERR_INVALID_ARG, "image index out of range");
+    HIPCHK(h, hipMemcpyAsync(num, h->nms_nsel + img, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t k = (size_t)*num, o = (size_t)img * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
+    BODCHK(d2h(h, scores, h->out_scores + o * C, k * C));
+    BODCHK(d2h(h, means, h->out_means + o * 4, k * 4));
+    BODCHK(d2h(h, covs, h->out_covs + o * 16, k * 16));
+    BODCHK(d2h(h, counts, h->out_counts + o * C, k * C));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
+    if (h->cfg.mc_samples < 2) return h->fail(BOD_ERR_INVALID_ARG, "bayes_od needs mc_samples >= 2 (sample covariance divides by N-1)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const float* dev = nullptr;
+    BODCHK(stage_images(h, images, on_device, &dev));
+    BODCHK(run_forward(h, dev, seed, first_image_id));
+    BODCHK(run_posterior(h, seed, first_image_id));
+    BODCHK(run_nms(h));
+    return run_cluster(h);
+}
+
+bod_status bod_profile_begin(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    h->ev_head.clear(); h->ev_post.clear(); h->prof_flops = 0; h->profiling = true;
+    return BOD_OK;
+}
+
+bod_status bod_profile_end(bod_handle h, double* head_ms, int64_t* head_launches, double* head_flops, double* post_ms, int64_t* post_launches) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double hm = 0, pm = 0;
+    for (auto& e : h->ev_head) { float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e.first, e.second)); hm += ms; }
+    for (auto& e : h->ev_post) { float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e.first, e.second)); pm += ms; }
+    if (head_ms) *head_ms = hm;
+    if (head_launches) *head_launches = (int64_t)h->ev_head.size();
+    if (head_flops) *head_flops = h->prof_flops;
+    if (post_ms) *post_ms = pm;
+    if (post_launches) *post_launches = (int64_t)h->ev_post.size();
+    h->profiling = false;
+    return BOD_OK;
+}
+
+}  // extern "C"

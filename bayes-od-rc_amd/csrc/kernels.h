@@ -1,0 +1,134 @@
+// Internal launch interface between engine.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_igemm.hip)
+//
+// D[cout][pixel] = sum_k W[cout][k] * X[pixel][k],  k = (tap, cin).   NHWC bf16 activations live
+// in spatially zero-padded planes so the im2col gather never needs bounds checks; output "rows"
+// (pixels) are described by a row table, which lets one launch cover all pyramid levels, MC
+// samples and images at once.
+// ------------------------------------------------------------------------------------------------
+struct RowEnt {            // 32 B per output pixel
+    int32_t in_off;        // pixel index (in the group's input buffer) of the window origin
+    int32_t in_pitch;      // padded row width of that plane, in pixels
+    int32_t out_off;       // pixel index in the output buffer
+    int32_t res_off;       // pixel index in the residual buffer (unused if no residual)
+    int32_t rng_p;         // pixel index in the image's concatenated p3..p7 pyramid (dropout counter x)
+    int32_t rng_zs;        // sample | image_in_batch << 16
+    int32_t pad0, pad1;
+};
+
+struct ConvGroup {
+    const uint16_t* in;    // bf16 activations
+    const uint16_t* w;     // bf16 [Cout_pad][taps][Cin]
+    const float* bias;     // fp32 [Cout_pad]
+    void* out;             // bf16 or fp32
+    const uint16_t* res;   // bf16 residual or nullptr
+    uint16_t* out_relu;    // optional second output relu(out) (P6 -> P7 input) or nullptr
+    int32_t in_coff;       // channel offset inside an input pixel
+    int32_t layer_id;      // dropout stream id (head*4 + layer)
+};
+
+enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4 };
+
+struct ConvArgs {
+    ConvGroup g[3];
+    const RowEnt* rows;
+    int32_t M;             // number of output pixels (rows)
+    int32_t taps, KW;      // KH*KW, KW
+    int32_t cin;           // channels reduced per tap (multiple of 64)
+    int32_t in_cstride;    // channels per input pixel
+    int32_t cout_pad;      // multiple of the cout tile
+    int32_t cout_valid;    // real output channels
+    int32_t out_cstride;   // channels per output pixel
+    int32_t res_cstride;
+    int32_t flags;
+    int32_t fan_count;     // >1: write fan_count dropout variants (sample n at out_off + n*fan_stride)
+    int32_t fan_stride;
+    uint32_t seed_lo, seed_hi;
+    uint32_t drop_threshold;
+    float drop_scale;
+    uint32_t image_base;   // global id of image 0 of the batch
+    int32_t groups;
+};
+
+hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Stem + pooling + small elementwise (aux_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+// 7x7 s2 VALID conv (fp32 image, fp32 folded weights [7][7][3][64]) + bias + ReLU -> bf16 [B,oh,ow,64]
+hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, uint16_t* out,
+                            int B, int H, int W, int oh, int ow, hipStream_t s);
+// ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on bf16 [B,ih,iw,64] -> padded-plane bf16 output
+hipError_t launch_stem_pool(const uint16_t* in, uint16_t* out, int B, int ih, int iw, int oh, int ow,
+                            int out_pitch, int out_plane, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Bayesian post-processing (post_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+struct PostCfg {
+    int32_t B, N, A, C, draws;
+    int32_t use_full_covar, has_covar, dirichlet, gaussian_iso, ranking_method;
+    float iso_var;
+    float kitti_sh, kitti_sw;       // 0 => off
+    uint32_t seed_lo, seed_hi, image_base;
+};
+
+struct PostBuffers {
+    // inputs
+    const float* cls;       // [B,N,A,C]
+    const float* box;       // [B,N,A,4]
+    const float* cov;       // [B,N,A,10]
+    const float* anchors;   // [A,4]
+    // dense per-anchor scratch
+    uint8_t* keep;          // [B,A]
+    float* d_counts;        // [B,A,C]   sampled counts (likelihood)
+    // compacted outputs, capacity A per image
+    int32_t* block_counts;  // [B, nblocks]
+    int32_t* num_kept;      // [B]
+    float* counts;          // [B,A,C]   Dirichlet posterior counts
+    float* score;           // [B,A,C]
+    float* means;           // [B,A,4]
+    float* covs;            // [B,A,16]
+    float* ranking;         // [B,A]
+    float* corners;         // [B,A,4]
+    int32_t* anchor_index;  // [B,A]
+};
+
+hipError_t launch_posterior(const PostCfg& c, const PostBuffers& b, hipStream_t s);
+hipError_t launch_joint_entropy_rank(const PostCfg& c, const PostBuffers& b, hipStream_t s);
+
+struct NmsArgs {
+    int32_t B, A;                 // per-image capacity A
+    const int32_t* num_kept;      // [B]
+    const float* corners;         // [B,A,4]
+    const float* ranking;         // [B,A]
+    float* work_scores;           // [B,A] scratch
+    int32_t* work_begin;          // [B,A] scratch
+    int32_t* selected;            // [B,max_out]
+    int32_t* num_selected;        // [B]
+    int32_t max_out;
+    float iou_thr, sigma;
+    int32_t variant;
+};
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+
+struct ClusterArgs {
+    int32_t B, A, C, max_out;
+    const int32_t* num_kept;
+    const int32_t* selected;      // [B,max_out]
+    const int32_t* num_selected;  // [B]
+    const float* corners;         // [B,A,4]
+    const float* counts;          // [B,A,C]
+    const float* means;           // [B,A,4]
+    const float* covs;            // [B,A,16]
+    float thr;
+    // outputs [B,max_out,...]
+    float* out_scores; float* out_means; float* out_covs; float* out_counts;
+};
+hipError_t launch_cluster_fuse(const ClusterArgs& a, hipStream_t s);
+hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s);

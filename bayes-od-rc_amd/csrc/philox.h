@@ -1,0 +1,31 @@
+// Philox4x32-10 (Salmon et al. SC'11; same generator as rocRAND's philox4x32_10), inlined so the
+// counter layout is ours to define (DESIGN.md "RNG contract"; oracle twin: oracle/philox.py).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BOD_HD __host__ __device__ __forceinline__
+#else
+#define BOD_HD inline
+#endif
+
+struct Philox4 { uint32_t x, y, z, w; };
+
+BOD_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                             uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+#define BOD_CAT_TAG 0x00CA7E60u

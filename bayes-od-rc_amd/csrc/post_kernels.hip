@@ -1,0 +1,749 @@
+// Bayesian post-processing on the device: everything `bayes_od_inference` does after the model
+// call and all of `bayes_od_clustering` (src/retina_net/experiments/inference_utils.py:25-215,
+// :285-364).  fp32 throughout, like the reference.
+//
+//   K1 post_sample_kernel   softmax per MC sample -> mean -> Categorical.sample(30) via Philox
+//                           uniforms -> counts -> background filter flag            (:31-51)
+//   K2 post_scan_kernel     ordered compaction offsets (tf.boolean_mask keeps anchor order)
+//   K3 post_fuse_kernel     per kept anchor: decode, mean / 4x4 sample covariance over MC,
+//                           aleatoric L D L^T, mixing, Dirichlet + Gaussian prior fusion,
+//                           KITTI rescale, score ranking, corners                    (:25-29,:53-202)
+//   K4 nms_kernel           NonMaxSuppressionV5 (soft-NMS), one wavefront per image   (:204-212)
+//   K5 cluster_fuse_kernel  bayes_od_clustering, one workgroup per (image, centre)   (:285-364)
+//   K6 iou_matrix_kernel    box_utils.bbox_iou_vuvu (only for API compatibility)     (:214-215)
+#include "kernels.h"
+#include "philox.h"
+#include <math.h>
+
+#define POST_BLOCK 256
+#define MAXC 16
+
+// ------------------------------------------------------------------------------------------------
+// small dense helpers (all indices compile-time after unrolling)
+// ------------------------------------------------------------------------------------------------
+struct Mat4 { float m[4][4]; };
+
+// inverse of a symmetric positive definite 4x4 through Cholesky A = G G^T, inv = G^-T G^-1
+__device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) {
+    float g[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float d = a.m[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= g[j][k] * g[j][k];
+        const float dj = sqrtf(d);
+        g[j][j] = dj;
+        const float inv = 1.0f / dj;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            float s = a.m[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= g[i][k] * g[j][k];
+            g[i][j] = s * inv;
+        }
+    }
+    // h = G^-1 (lower)
+    float h[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[i][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j][j] = 1.0f / g[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) s += g[i][k] * h[k][j];
+            h[i][j] = -s / g[i][i];
+        }
+    }
+    Mat4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = i; k < 4; ++k) s += h[k][i] * h[k][j];
+            r.m[i][j] = s;
+            r.m[j][i] = s;
+        }
+    return r;
+}
+
+__device__ __forceinline__ void decode_box(const float4 anc, const float4 t, float o[4]) {
+    // box_utils.box_from_anchor_and_target_bnms (:171-192): anchors (v,u,h,w)
+    o[0] = anc.z * t.x / 10.0f + anc.x;
+    o[1] = anc.w * t.y / 10.0f + anc.y;
+    o[2] = anc.z * fminf(fmaxf(expf(t.z / 5.0f), 1e-4f), 1e4f);
+    o[3] = anc.w * fminf(fmaxf(expf(t.w / 5.0f), 1e-4f), 1e4f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: mean softmax + categorical sampling + filter flag
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(POST_BLOCK) void post_sample_kernel(PostCfg c, PostBuffers pb, int nblocks) {
+    const int a = blockIdx.x * POST_BLOCK + threadIdx.x;
+    const int b = blockIdx.y;
+    bool keep = false;
+    if (a < c.A) {
+        float mp[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) mp[j] = 0.f;
+        for (int n = 0; n < c.N; ++n) {
+            const float* l = pb.cls + (((size_t)b * c.N + n) * c.A + a) * C;
+            float v[C];
+            if (C % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) {
+                    const float4 t = reinterpret_cast<const float4*>(l)[q];
+                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C; ++j) v[j] = l[j];
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int j = 1; j < C; ++j) mx = fmaxf(mx, v[j]);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) { v[j] = expf(v[j] - mx); s += v[j]; }
+#pragma unroll
+            for (int j = 0; j < C; ++j) mp[j] += v[j] / s;
+        }
+        float cdf[C];
+        float accum = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) { mp[j] = mp[j] / (float)c.N; accum += mp[j]; cdf[j] = accum; }
+        const float total = cdf[C - 1];
+        int cnt[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) cnt[j] = 0;
+        const int groups = (c.draws + 3) / 4;
+        for (int g = 0; g < groups; ++g) {
+            const Philox4 r = philox4x32_10((uint32_t)a, (uint32_t)g, BOD_CAT_TAG, c.image_base + b,
+                                            c.seed_lo, c.seed_hi);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (4 * g + q < c.draws) {
+                    const float t = (float)(w[q] >> 8) * 5.9604644775390625e-8f * total;
+                    int k = 0;
+#pragma unroll
+                    for (int j = 0; j < C; ++j) k += (cdf[j] <= t) ? 1 : 0;
+                    k = k < C - 1 ? k : C - 1;
+#pragma unroll
+                    for (int j = 0; j < C; ++j) cnt[j] += (j == k) ? 1 : 0;
+                }
+            }
+        }
+        int best = 0, bestc = cnt[0];
+#pragma unroll
+        for (int j = 1; j < C; ++j)
+            if (cnt[j] > bestc) { bestc = cnt[j]; best = j; }
+        keep = best != C - 1;
+        pb.keep[(size_t)b * c.A + a] = keep ? 1 : 0;
+        float* dc = pb.d_counts + ((size_t)b * c.A + a) * C;
+#pragma unroll
+        for (int j = 0; j < C; ++j) dc[j] = (float)cnt[j];
+    }
+    const int n = __syncthreads_count(keep ? 1 : 0);
+    if (threadIdx.x == 0) pb.block_counts[(size_t)b * nblocks + blockIdx.x] = n;
+}
+
+// K2: exclusive scan of block counts (in place), one block per image
+__global__ __launch_bounds__(POST_BLOCK) void post_scan_kernel(PostBuffers pb, int nblocks) {
+    __shared__ int part[POST_BLOCK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int* bc = pb.block_counts + (size_t)b * nblocks;
+    const int per = (nblocks + POST_BLOCK - 1) / POST_BLOCK;
+    int local = 0;
+    for (int i = 0; i < per; ++i) {
+        const int idx = tid * per + i;
+        if (idx < nblocks) local += bc[idx];
+    }
+    part[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < POST_BLOCK; ++i) { const int t = part[i]; part[i] = run; run += t; }
+        pb.num_kept[b] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = 0; i < per; ++i) {
+        const int idx = tid * per + i;
+        if (idx < nblocks) { const int t = bc[idx]; bc[idx] = run; run += t; }
+    }
+}
+
+// K3: per kept anchor fusion, written straight to its compacted slot
+template <int C>
+__global__ __launch_bounds__(POST_BLOCK) void post_fuse_kernel(PostCfg c, PostBuffers pb, int nblocks) {
+    __shared__ int wave_off[POST_BLOCK / 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.x * POST_BLOCK + tid;
+    const int b = blockIdx.y;
+    const bool keep = (a < c.A) && pb.keep[(size_t)b * c.A + a];
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_off[wave + 1] = __popcll(bal);
+    if (tid == 0) wave_off[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int w = 1; w <= POST_BLOCK / 64; ++w) wave_off[w] += wave_off[w - 1];
+    __syncthreads();
+    if (!keep) return;
+    const int slot = pb.block_counts[(size_t)b * nblocks + blockIdx.x] + wave_off[wave] + before;
+    const size_t o = (size_t)b * c.A + slot;
+
+    const float4 anc = reinterpret_cast<const float4*>(pb.anchors)[a];
+    // ---- epistemic: two-pass mean / unbiased covariance over MC samples (:220-244)
+    float mu[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < c.N; ++n) {
+        const float4 t = reinterpret_cast<const float4*>(pb.box)[((size_t)b * c.N + n) * c.A + a];
+        float bx[4];
+        decode_box(anc, t, bx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mu[i] += bx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mu[i] = mu[i] / (float)c.N;
+    Mat4 epi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi.m[i][j] = 0.f;
+    for (int n = 0; n < c.N; ++n) {
+        const float4 t = reinterpret_cast<const float4*>(pb.box)[((size_t)b * c.N + n) * c.A + a];
+        float bx[4];
+        decode_box(anc, t, bx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bx[i] -= mu[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) epi.m[i][j] += bx[i] * bx[j];
+    }
+    const float nm1 = (float)c.N - 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { epi.m[i][j] = epi.m[i][j] / nm1; epi.m[j][i] = epi.m[i][j]; }
+
+    // ---- aleatoric (:62-84): mean of the raw lower-triangular params, D = exp(diag), L = inv(unit lower)
+    Mat4 al;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) al.m[i][j] = 0.f;
+    if (c.has_covar) {
+        float x[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) x[q] = 0.f;
+        for (int n = 0; n < c.N; ++n) {
+            const float* p = pb.cov + (((size_t)b * c.N + n) * c.A + a) * 10;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float2 t = reinterpret_cast<const float2*>(p)[q];
+                x[2 * q] += t.x; x[2 * q + 1] += t.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) x[q] = x[q] / (float)c.N;
+        // tfp.math.fill_triangular (retinanet_model.py:110)
+        const float d0 = expf(x[4]), d1 = expf(x[9]), d2 = expf(x[5]), d3 = expf(x[0]);
+        if (c.use_full_covar) {
+            const float l10 = x[8], l20 = x[7], l21 = x[6], l30 = x[3], l31 = x[2], l32 = x[1];
+            // inverse of the unit lower matrix by forward substitution
+            float li[4][4];
+            li[0][0] = 1.f; li[0][1] = 0.f; li[0][2] = 0.f; li[0][3] = 0.f;
+            li[1][0] = -l10; li[1][1] = 1.f; li[1][2] = 0.f; li[1][3] = 0.f;
+            li[2][0] = -(l20 * 1.f + l21 * li[1][0]); li[2][1] = -l21; li[2][2] = 1.f; li[2][3] = 0.f;
+            li[3][0] = -(l30 * 1.f + l31 * li[1][0] + l32 * li[2][0]);
+            li[3][1] = -(l31 * 1.f + l32 * li[2][1]);
+            li[3][2] = -l32; li[3][3] = 1.f;
+            const float d[4] = {d0, d1, d2, d3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k <= j; ++k) s += li[i][k] * d[k] * li[j][k];
+                    al.m[i][j] = s; al.m[j][i] = s;
+                }
+        } else {
+            al.m[0][0] = d0; al.m[1][1] = d1; al.m[2][2] = d2; al.m[3][3] = d3;
+        }
+    }
+    Mat4 lik;                                                     // (:86-87)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lik.m[i][j] = (10.0f * al.m[i][j] + 1.0f * epi.m[i][j]) / 11.0f;
+
+    // ---- Dirichlet posterior (:90-97)
+    const float* dc = pb.d_counts + ((size_t)b * c.A + a) * C;
+    float pc[C];
+    float csum = 0.f;
+    const float alpha = c.dirichlet ? 1.0f / (float)C : 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) { pc[j] = dc[j] + alpha; csum += pc[j]; }
+    float best = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const float s = pc[j] / csum;
+        pb.counts[o * C + j] = pc[j];
+        pb.score[o * C + j] = s;
+        best = j == 0 ? s : fmaxf(best, s);
+    }
+
+    // ---- Gaussian prior fusion (:100-145): prior mean = the anchor, prior cov = iso_var * I
+    Mat4 pcov;
+    float pm[4];
+    if (c.gaussian_iso) {
+        const Mat4 prec = inv_spd4(lik);
+        const float pp = 1.0f / c.iso_var;
+        Mat4 post_prec = prec;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) post_prec.m[i][i] += pp;
+        pcov = inv_spd4(post_prec);
+        const float am[4] = {anc.x, anc.y, anc.z, anc.w};
+        float inter[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += prec.m[i][k] * mu[k];
+            inter[i] = pp * am[i] + s;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += pcov.m[i][k] * inter[k];
+            pm[i] = s;
+        }
+    } else {
+        pcov = lik;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pm[i] = mu[i];
+    }
+    if (c.kitti_sh > 0.f) {                                       // (:147-167) S mu, S Sigma S^T
+        const float sc[4] = {c.kitti_sh, c.kitti_sw, c.kitti_sh, c.kitti_sw};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pm[i] *= sc[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pcov.m[i][j] = sc[i] * pcov.m[i][j] * sc[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pb.means[o * 4 + i] = pm[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb.covs[o * 16 + i * 4 + j] = pcov.m[i][j];
+    }
+    pb.ranking[o] = best;                                         // ranking_method 'score' (:202)
+    pb.anchor_index[o] = a;
+    // box_utils.vuhw_to_vuvu (:5-23)
+    pb.corners[o * 4 + 0] = pm[0] - pm[2] / 2.0f;
+    pb.corners[o * 4 + 1] = pm[1] - pm[3] / 2.0f;
+    pb.corners[o * 4 + 2] = pm[0] + pm[2] / 2.0f;
+    pb.corners[o * 4 + 3] = pm[1] + pm[3] / 2.0f;
+}
+
+hipError_t launch_posterior(const PostCfg& c, const PostBuffers& b, hipStream_t s) {
+    const int nblocks = (c.A + POST_BLOCK - 1) / POST_BLOCK;
+    dim3 grid(nblocks, c.B);
+    if (c.C == 8) {
+        hipLaunchKernelGGL(post_sample_kernel<8>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+        hipLaunchKernelGGL(post_scan_kernel, dim3(c.B), dim3(POST_BLOCK), 0, s, b, nblocks);
+        hipLaunchKernelGGL(post_fuse_kernel<8>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+    } else if (c.C == 4) {
+        hipLaunchKernelGGL(post_sample_kernel<4>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+        hipLaunchKernelGGL(post_scan_kernel, dim3(c.B), dim3(POST_BLOCK), 0, s, b, nblocks);
+        hipLaunchKernelGGL(post_fuse_kernel<4>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// joint-entropy ranking (:169-200): min-max normalised information gains, one block per image
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float det4(const float* m) {
+    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
+    const float s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
+    const float s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
+    const float c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
+    const float c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+}
+
+__global__ __launch_bounds__(POST_BLOCK) void joint_entropy_kernel(PostCfg c, PostBuffers pb) {
+    __shared__ float red[4][POST_BLOCK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int M = pb.num_kept[b];
+    const float two_pi_term = 2.0f + 2.0f * logf(2.0f * 3.14159265358979323846f);
+    const float iv = c.iso_var;
+    const float prior_ent = two_pi_term + 0.5f * logf(iv * iv * iv * iv);
+    const float cat_prior = logf((float)c.C);          // entropy of the uniform prior score
+    float gmin = INFINITY, gmax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+    for (int m = tid; m < M; m += POST_BLOCK) {
+        const size_t o = (size_t)b * c.A + m;
+        const float g = prior_ent - (two_pi_term + 0.5f * logf(det4(pb.covs + o * 16)));
+        float ce = 0.f;
+        for (int j = 0; j < c.C; ++j) { const float p = pb.score[o * c.C + j]; ce -= p * logf(p); }
+        const float cg = cat_prior - ce;
+        gmin = fminf(gmin, g); gmax = fmaxf(gmax, g);
+        cmin = fminf(cmin, cg); cmax = fmaxf(cmax, cg);
+    }
+    red[0][tid] = gmin; red[1][tid] = gmax; red[2][tid] = cmin; red[3][tid] = cmax;
+    __syncthreads();
+    for (int s = POST_BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] = fminf(red[0][tid], red[0][tid + s]);
+            red[1][tid] = fmaxf(red[1][tid], red[1][tid + s]);
+            red[2][tid] = fminf(red[2][tid], red[2][tid + s]);
+            red[3][tid] = fmaxf(red[3][tid], red[3][tid + s]);
+        }
+        __syncthreads();
+    }
+    gmin = red[0][0]; gmax = red[1][0]; cmin = red[2][0]; cmax = red[3][0];
+    const float gden = fmaxf(1.0f, gmax - gmin), cden = fmaxf(0.001f, cmax - cmin);
+    for (int m = tid; m < M; m += POST_BLOCK) {
+        const size_t o = (size_t)b * c.A + m;
+        const float g = prior_ent - (two_pi_term + 0.5f * logf(det4(pb.covs + o * 16)));
+        float ce = 0.f;
+        for (int j = 0; j < c.C; ++j) { const float p = pb.score[o * c.C + j]; ce -= p * logf(p); }
+        const float cg = cat_prior - ce;
+        pb.ranking[o] = (cg - cmin) / cden + (g - gmin) / gden;
+    }
+}
+
+hipError_t launch_joint_entropy_rank(const PostCfg& c, const PostBuffers& b, hipStream_t s) {
+    hipLaunchKernelGGL(joint_entropy_kernel, dim3(c.B), dim3(POST_BLOCK), 0, s, c, b);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: soft-NMS (NonMaxSuppressionV5). One wavefront per image walks the exact greedy order of
+// the TF op: pop the best live candidate, decay it by every box selected since it was last
+// examined (newest first), select iff unchanged, else re-queue.  The priority queue is replaced
+// by a per-lane cached arg-max over a strided slice + a 6-step wave butterfly (same order:
+// score desc, index asc).
+// ------------------------------------------------------------------------------------------------
+#define NMS_LDS_CAP 6144
+#define NMS_MAX_OUT 512
+
+__device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
+    const float ymin_i = fminf(bi.x, bi.z), xmin_i = fminf(bi.y, bi.w);
+    const float ymax_i = fmaxf(bi.x, bi.z), xmax_i = fmaxf(bi.y, bi.w);
+    const float ymin_j = fminf(bj.x, bj.z), xmin_j = fminf(bj.y, bj.w);
+    const float ymax_j = fmaxf(bj.x, bj.z), xmax_j = fmaxf(bj.y, bj.w);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.f || area_j <= 0.f) return 0.f;
+    const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+    const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+    const float inter = fmaxf(iy1 - iy0, 0.f) * fmaxf(ix1 - ix0, 0.f);
+    return inter / ((area_i + area_j) - inter);
+}
+
+__global__ __launch_bounds__(64) void nms_kernel(NmsArgs a) {
+    __shared__ float s_score[NMS_LDS_CAP];
+    __shared__ int s_begin[NMS_LDS_CAP];
+    __shared__ float4 s_selbox[NMS_MAX_OUT];
+    __shared__ float s_w[NMS_MAX_OUT];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int M = a.num_kept[b];
+    const float4* boxes = reinterpret_cast<const float4*>(a.corners) + (size_t)b * a.A;
+    float* score = (M <= NMS_LDS_CAP) ? s_score : a.work_scores + (size_t)b * a.A;
+    int* begin = (M <= NMS_LDS_CAP) ? s_begin : a.work_begin + (size_t)b * a.A;
+    int* sel = a.selected + (size_t)b * a.max_out;
+    const float scale = a.sigma > 0.f ? -0.5f / a.sigma : 0.f;
+    const bool soft = a.sigma > 0.f;
+    const float NEG_INF = -INFINITY;
+
+    for (int i = lane; i < M; i += 64) { score[i] = a.ranking[(size_t)b * a.A + i]; begin[i] = 0; }
+    __syncthreads();
+
+    // lane-local best over its strided slice
+    float lbest = NEG_INF; int lidx = -1;
+    auto rescan = [&]() {
+        lbest = NEG_INF; lidx = -1;
+        for (int i = lane; i < M; i += 64) {
+            if (begin[i] < 0) continue;
+            const float s = score[i];
+            if (lidx < 0 || s > lbest) { lbest = s; lidx = i; }    // ascending i => lowest index wins ties
+        }
+    };
+    rescan();
+    int nsel = 0;
+    while (nsel < a.max_out) {
+        // wave arg-max: (score desc, index asc)
+        float bs = lbest; int bi = lidx;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int oi = __shfl_xor(bi, off);
+            const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi < bi));
+            if (take) { bs = os; bi = oi; }
+        }
+        if (bi < 0) break;
+        const int idx = bi;
+        const float original = bs;
+        const int beg = begin[idx];
+        const float4 cb = boxes[idx];
+        // weights against selected[beg .. nsel), computed lane-parallel, multiplied newest-first
+        for (int j = beg + lane; j < nsel; j += 64) {
+            const float sim = nms_iou(cb, s_selbox[j]);
+            float w = (float)exp((double)(scale * (sim * sim)));
+            if (!(a.variant == 1 && soft) && !(sim <= a.iou_thr)) w = 0.f;
+            s_w[j] = w;
+        }
+        __syncthreads();
+        float s = original;
+        if (lane == 0)
+            for (int j = nsel - 1; j >= beg; --j) s = s * s_w[j];
+        s = __shfl(s, 0);
+        __syncthreads();
+        const bool owner = (idx & 63) == lane;
+        if (s == original) {
+            if (lane == 0) { sel[nsel] = idx; s_selbox[nsel] = cb; }
+            if (owner) begin[idx] = -1;
+            ++nsel;
+        } else if (s > NEG_INF) {
+            if (owner) { score[idx] = s; begin[idx] = nsel; }
+        } else {
+            if (owner) begin[idx] = -1;
+        }
+        __syncthreads();
+        if (owner) rescan();
+    }
+    if (lane == 0) a.num_selected[b] = nsel;
+}
+
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
+    if (a.max_out > NMS_MAX_OUT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: cluster-and-fuse. One workgroup per (centre, image); the M x M affinity matrix of the
+// reference (:214-215) is never built: IoU against the centre is evaluated on the fly.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float iou_plus1(const float4 p, const float4 q) {
+    // box_utils.bbox_iou_vuvu (:117-146) including the (min-max+1) area quirk
+    const float xi1 = fmaxf(p.y, q.y), yi1 = fmaxf(p.x, q.x);
+    const float xi2 = fminf(p.w, q.w), yi2 = fminf(p.z, q.z);
+    const float inter = fmaxf(xi2 - xi1 + 1.0f, 0.f) * fmaxf(yi2 - yi1 + 1.0f, 0.f);
+    const float a1 = (p.y - p.w + 1.0f) * (p.x - p.z + 1.0f);
+    const float a2 = (q.y - q.w + 1.0f) * (q.x - q.z + 1.0f);
+    const float uni = (a1 + a2) - inter;
+    return inter / (uni + 0.00001f);
+}
+
+#define CL_BLOCK 256
+template <int C>
+__global__ __launch_bounds__(CL_BLOCK) void cluster_fuse_kernel(ClusterArgs a) {
+    __shared__ float red[CL_BLOCK];
+    __shared__ float top_kl[CL_BLOCK * 3];
+    __shared__ int top_ix[CL_BLOCK * 3];
+    __shared__ int s_cnt;
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (k >= a.num_selected[b]) return;
+    const int M = a.num_kept[b];
+    const int centre = a.selected[(size_t)b * a.max_out + k];
+    const size_t base = (size_t)b * a.A;
+    const float4* boxes = reinterpret_cast<const float4*>(a.corners) + base;
+    const float4 cbox = boxes[centre];
+    float cs[C];
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) { cs[j] = a.counts[(base + centre) * C + j]; sum += cs[j]; }
+#pragma unroll
+        for (int j = 0; j < C; ++j) cs[j] = cs[j] / sum;
+        // scipy.stats.entropy renormalises pk
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) s2 += cs[j];
+#pragma unroll
+        for (int j = 0; j < C; ++j) cs[j] = cs[j] / s2;
+    }
+    float psum[10], pmsum[4], ssum[C], csum[C];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) psum[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pmsum[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) { ssum[j] = 0.f; csum[j] = 0.f; }
+    float tk[3] = {INFINITY, INFINITY, INFINITY};
+    int ti[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int cnt = 0;
+    for (int i = tid; i < M; i += CL_BLOCK) {
+        if (!(iou_plus1(boxes[i], cbox) > a.thr)) continue;
+        ++cnt;
+        Mat4 cv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cv.m[r][q] = a.covs[(base + i) * 16 + r * 4 + q];
+        const Mat4 pr = inv_spd4(cv);
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q <= r; ++q) psum[t++] += pr.m[r][q];
+        float mu[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mu[r] = a.means[(base + i) * 4 + r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += pr.m[r][q] * mu[q];
+            pmsum[r] += s;
+        }
+        float row[C], rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) { row[j] = a.counts[(base + i) * C + j]; rs += row[j]; }
+        float kl = 0.f, qs = 0.f;
+        float sc[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) { sc[j] = row[j] / rs; qs += sc[j]; }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float q = sc[j] / qs;
+            if (cs[j] > 0.f) kl += (q > 0.f) ? cs[j] * logf(cs[j] / q) : INFINITY;
+            ssum[j] += sc[j];
+            csum[j] += row[j];
+        }
+        // insert into this thread's sorted top-3 (kl asc, index asc)
+        if (kl < tk[2] || (kl == tk[2] && i < ti[2])) {
+            tk[2] = kl; ti[2] = i;
+            if (tk[2] < tk[1] || (tk[2] == tk[1] && ti[2] < ti[1])) {
+                float f = tk[1]; tk[1] = tk[2]; tk[2] = f; int g = ti[1]; ti[1] = ti[2]; ti[2] = g;
+                if (tk[1] < tk[0] || (tk[1] == tk[0] && ti[1] < ti[0])) {
+                    f = tk[0]; tk[0] = tk[1]; tk[1] = f; g = ti[0]; ti[0] = ti[1]; ti[1] = g;
+                }
+            }
+        }
+    }
+    // ---- block reductions
+    auto block_sum = [&](float v) -> float {
+        red[tid] = v;
+        __syncthreads();
+        for (int s = CL_BLOCK / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt, cnt);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) psum[q] = block_sum(psum[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pmsum[q] = block_sum(pmsum[q]);
+    const int total = s_cnt;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { top_kl[tid * 3 + q] = tk[q]; top_ix[tid * 3 + q] = ti[q]; }
+    if (total <= 3) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) { ssum[j] = block_sum(ssum[j]); csum[j] = block_sum(csum[j]); }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const size_t ob = (size_t)b * a.max_out + k;
+    // fused Gaussian: cov = inv(sum prec), mean = cov * sum(prec*mean)  (:321-331), x70 (:361)
+    Mat4 ps;
+    {
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q <= r; ++q) { ps.m[r][q] = psum[t]; ps.m[q][r] = psum[t]; ++t; }
+    }
+    const Mat4 fc = inv_spd4(ps);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += fc.m[r][q] * pmsum[q];
+        a.out_means[ob * 4 + r] = s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.out_covs[ob * 16 + r * 4 + q] = fc.m[r][q] * 70.0f;
+    }
+    if (total > 3) {
+        // global top-3 over the per-thread candidates (:338-349)
+        float bk[3] = {INFINITY, INFINITY, INFINITY};
+        int bx[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int t = 0; t < CL_BLOCK * 3; ++t) {
+            const float kl = top_kl[t]; const int ix = top_ix[t];
+            if (ix == 0x7fffffff) continue;
+            if (kl < bk[2] || (kl == bk[2] && ix < bx[2])) {
+                bk[2] = kl; bx[2] = ix;
+                if (bk[2] < bk[1] || (bk[2] == bk[1] && bx[2] < bx[1])) {
+                    float f = bk[1]; bk[1] = bk[2]; bk[2] = f; int g = bx[1]; bx[1] = bx[2]; bx[2] = g;
+                    if (bk[1] < bk[0] || (bk[1] == bk[0] && bx[1] < bx[0])) {
+                        f = bk[0]; bk[0] = bk[1]; bk[1] = f; g = bx[0]; bx[0] = bx[1]; bx[1] = g;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) { ssum[j] = 0.f; csum[j] = 0.f; }
+        for (int t = 0; t < 3; ++t) {
+            float row[C], rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) { row[j] = a.counts[(base + bx[t]) * C + j]; rs += row[j]; }
+#pragma unroll
+            for (int j = 0; j < C; ++j) { ssum[j] += row[j] / rs; csum[j] += row[j]; }
+        }
+    }
+    const float denom = (float)(total > 3 ? 3 : total);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        a.out_scores[ob * C + j] = ssum[j] / denom;
+        a.out_counts[ob * C + j] = csum[j];
+    }
+}
+
+hipError_t launch_cluster_fuse(const ClusterArgs& a, hipStream_t s) {
+    dim3 grid(a.max_out, a.B);
+    if (a.C == 8) hipLaunchKernelGGL(cluster_fuse_kernel<8>, grid, dim3(CL_BLOCK), 0, s, a);
+    else if (a.C == 4) hipLaunchKernelGGL(cluster_fuse_kernel<4>, grid, dim3(CL_BLOCK), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+__global__ void iou_matrix_kernel(const float4* boxes, int M, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < M) out[(size_t)i * M + j] = iou_plus1(boxes[i], boxes[j]);
+}
+
+hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(iou_matrix_kernel, dim3((M + 255) / 256, M), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(corners), M, out);
+    return hipGetLastError();
+}

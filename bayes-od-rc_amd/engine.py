@@ -1,0 +1,229 @@
+"""Object wrapper over one ``bod_handle`` (include/bayesod.h).  NumPy in / NumPy out.
+
+One Engine = one GPU, one HIP stream, one (image size, batch, MC sample count) geometry.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BodConfig, BodSizes, as_f32, fptr, iptr
+
+_KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
+
+
+def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
+                dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
+                has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
+                num_categorical_draws=30, layers=(3, 4, 5, 6, 7)):
+    """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
+    into a ``bod_config``."""
+    bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
+                             'gaussian_prior': {'type': 'isotropic', 'isotropic_variance': 100000.0}}
+    nms = nms_config or {'max_output_size': 100, 'iou_threshold': 0.5, 'soft_nms_sigma': 0.5}
+    cfg = BodConfig()
+    cfg.device = int(device)
+    cfg.image_h, cfg.image_w = int(image_hw[0]), int(image_hw[1])
+    cfg.batch, cfg.mc_samples = int(batch), int(mc_samples)
+    cfg.num_classes = int(num_classes)
+    cfg.anchors_per_location = int(anchors_per_location)
+    cfg.min_level, cfg.max_level = int(min(layers)), int(max(layers))
+    cfg.dropout_rate = float(dropout_rate)
+    cfg.use_full_covar = int(bool(use_full_covar))
+    cfg.dirichlet_non_informative = int(bo['dirichlet_prior']['type'] == 'non_informative')
+    cfg.gaussian_isotropic = int(bo['gaussian_prior']['type'] == 'isotropic')
+    cfg.isotropic_variance = float(bo['gaussian_prior'].get('isotropic_variance', 100000.0))
+    if bo['ranking_method'] not in ('score', 'joint_entropy'):
+        raise ValueError("ranking_method must be 'score' or 'joint_entropy'")
+    cfg.ranking_method = int(bo['ranking_method'] == 'joint_entropy')
+    cfg.nms_max_output_size = int(nms['max_output_size'])
+    cfg.nms_iou_threshold = float(nms['iou_threshold'])
+    cfg.nms_soft_sigma = float(nms['soft_nms_sigma'])
+    cfg.nms_variant = {'A': 0, 'B': 1}[nms_variant]
+    cfg.num_categorical_draws = int(num_categorical_draws)
+    cfg.has_covar_head = int(bool(has_covar_head))
+    if dataset_name == 'kitti':
+        if orig_size is None:
+            raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")
+        cfg.kitti_scale_h = float(orig_size[0]) / float(image_hw[0])
+        cfg.kitti_scale_w = float(orig_size[1]) / float(image_hw[1])
+    return cfg
+
+
+class Engine(object):
+    def __init__(self, cfg):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        st = self.lib.bod_create(C.byref(cfg), C.byref(self.h))
+        _lib.check(self.lib, None, st)
+        s = BodSizes()
+        self._chk(self.lib.bod_query_sizes(self.h, C.byref(s)))
+        self.P, self.A = s.num_pixels, s.num_anchors
+        self.levels = [(s.level_h[i], s.level_w[i]) for i in range(s.num_levels)]
+        self.B, self.N, self.Ccls = cfg.batch, cfg.mc_samples, cfg.num_classes
+        self.K = cfg.nms_max_output_size
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, st):
+        _lib.check(self.lib, self.h, st)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.bod_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        s = BodSizes()
+        self._chk(self.lib.bod_query_sizes(self.h, C.byref(s)))
+        return int(s.device_bytes)
+
+    def update_config(self, cfg):
+        self._chk(self.lib.bod_update_config(self.h, C.byref(cfg)))
+        self.cfg = cfg
+
+    # ------------------------------------------------------------------ weights / anchors
+    def load_weights(self, weights):
+        """weights: {keras_layer_name: {"kernel"/"bias"/"gamma"/"beta"/"mean"/"var": ndarray}}"""
+        for name, entry in weights.items():
+            for field, arr in entry.items():
+                if arr is None:
+                    continue
+                a = as_f32(arr)
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                self._chk(self.lib.bod_load_weight(self.h, name.encode(), _KINDS[field], shape, a.ndim, fptr(a)))
+        self._chk(self.lib.bod_finalize_weights(self.h))
+
+    def set_anchors(self, anchors):
+        a = as_f32(anchors)
+        self._chk(self.lib.bod_set_anchors(self.h, fptr(a), a.shape[0]))
+
+    # ------------------------------------------------------------------ stages
+    def _img(self, images):
+        a = as_f32(images)
+        expect = (self.B, self.cfg.image_h, self.cfg.image_w, 3)
+        if a.shape != expect:
+            raise ValueError("images must have shape %s, got %s" % (expect, a.shape))
+        return a
+
+    def upload_images(self, images):
+        a = self._img(images)
+        self._chk(self.lib.bod_upload_images(self.h, fptr(a)))
+
+    def forward(self, images=None, seed=0, first_image_id=0):
+        """images=None => use the device-resident buffer filled by upload_images()."""
+        if images is None:
+            ptr = self.lib.bod_device_images(self.h)
+            self._chk(self.lib.bod_forward(self.h, ptr, 1, seed, first_image_id))
+        else:
+            a = self._img(images)
+            self._chk(self.lib.bod_forward(self.h, a.ctypes.data, 0, seed, first_image_id))
+
+    def infer(self, images=None, seed=0, first_image_id=0):
+        if images is None:
+            ptr = self.lib.bod_device_images(self.h)
+            self._chk(self.lib.bod_infer(self.h, ptr, 1, seed, first_image_id))
+        else:
+            a = self._img(images)
+            self._chk(self.lib.bod_infer(self.h, a.ctypes.data, 0, seed, first_image_id))
+
+    def synchronize(self):
+        self._chk(self.lib.bod_synchronize(self.h))
+
+    def get_raw(self):
+        n = (self.B, self.N, self.A)
+        cls = np.empty(n + (self.Ccls,), np.float32)
+        box = np.empty(n + (4,), np.float32)
+        cov = np.empty(n + (10,), np.float32) if self.cfg.has_covar_head else None
+        self._chk(self.lib.bod_get_raw(self.h, fptr(cls), fptr(box), fptr(cov)))
+        return cls, box, cov
+
+    def set_raw(self, cls, box, cov=None):
+        cls, box = as_f32(cls), as_f32(box)
+        cov = as_f32(cov) if cov is not None else None
+        n = (self.B, self.N, self.A)
+        if cls.shape != n + (self.Ccls,) or box.shape != n + (4,) or (cov is not None and cov.shape != n + (10,)):
+            raise ValueError("raw head outputs have the wrong shape")
+        self._chk(self.lib.bod_set_raw(self.h, fptr(cls), fptr(box), fptr(cov)))
+
+    def get_pyramid(self, level_index):
+        h, w = self.levels[level_index]
+        out = np.empty((self.B, h, w, 256), np.float32)
+        self._chk(self.lib.bod_get_pyramid(self.h, level_index, fptr(out)))
+        return out
+
+    def posterior(self, seed=0, first_image_id=0):
+        self._chk(self.lib.bod_posterior(self.h, seed, first_image_id))
+
+    def num_kept(self):
+        out = np.zeros(self.B, np.int32)
+        self._chk(self.lib.bod_get_num_kept(self.h, iptr(out)))
+        return out
+
+    def get_posterior(self, image_index=0):
+        m = int(self.num_kept()[image_index])
+        counts = np.empty((m, self.Ccls), np.float32)
+        score = np.empty((m, self.Ccls), np.float32)
+        means = np.empty((m, 4), np.float32)
+        covs = np.empty((m, 4, 4), np.float32)
+        ranking = np.empty((m,), np.float32)
+        aidx = np.empty((m,), np.int32)
+        self._chk(self.lib.bod_get_posterior(self.h, image_index, fptr(counts), fptr(score), fptr(means),
+                                             fptr(covs), fptr(ranking), iptr(aidx)))
+        return {"counts": counts, "score": score, "means": means, "covs": covs, "ranking": ranking,
+                "anchor_index": aidx}
+
+    def set_posterior(self, image_index, counts, means, covs, ranking):
+        counts, means, covs, ranking = as_f32(counts), as_f32(means).reshape(-1, 4), as_f32(covs), as_f32(ranking)
+        m = means.shape[0]
+        self._chk(self.lib.bod_set_posterior(self.h, image_index, m, fptr(counts), fptr(means), fptr(covs),
+                                             fptr(ranking)))
+
+    def nms(self):
+        self._chk(self.lib.bod_nms(self.h))
+
+    def get_nms(self, image_index=0):
+        idx = np.zeros(self.K, np.int32)
+        n = C.c_int32(0)
+        self._chk(self.lib.bod_get_nms(self.h, image_index, iptr(idx), C.byref(n)))
+        return idx[:n.value].copy()
+
+    def get_iou_matrix(self, image_index=0):
+        m = int(self.num_kept()[image_index])
+        out = np.empty((m, m), np.float32)
+        if m:
+            self._chk(self.lib.bod_get_iou_matrix(self.h, image_index, fptr(out)))
+        return out
+
+    def cluster_fuse(self):
+        self._chk(self.lib.bod_cluster_fuse(self.h))
+
+    def get_detections(self, image_index=0):
+        k = self.K
+        scores = np.empty((k, self.Ccls), np.float32)
+        means = np.empty((k, 4), np.float32)
+        covs = np.empty((k, 4, 4), np.float32)
+        counts = np.empty((k, self.Ccls), np.float32)
+        n = C.c_int32(0)
+        self._chk(self.lib.bod_get_detections(self.h, image_index, C.byref(n), fptr(scores), fptr(means),
+                                              fptr(covs), fptr(counts)))
+        n = n.value
+        return scores[:n].copy(), means[:n].copy(), covs[:n].copy(), counts[:n].copy()
+
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self):
+        self._chk(self.lib.bod_profile_begin(self.h))
+
+    def profile_end(self):
+        hm, pm, fl = C.c_double(0), C.c_double(0), C.c_double(0)
+        hl, pl = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.bod_profile_end(self.h, C.byref(hm), C.byref(hl), C.byref(fl), C.byref(pm), C.byref(pl)))
+        return {"head_conv_ms": hm.value, "head_conv_launches": hl.value, "head_conv_flops": fl.value,
+                "posterior_ms": pm.value, "posterior_launches": pl.value}

@@ -1,0 +1,161 @@
+/*
+ * bayesod.h -- C ABI of libbayesod_hip.so, the MI355X (gfx950) BayesOD inference hot path.
+ *
+ * The reference (asharakeh/bayes-od-rc) is pure Python/TensorFlow and has no FFI or plugin
+ * interface; its boundary for this path is the Python call surface.
+ * Each entry point below names the reference interface it stands behind (paths relative to
+ * the reference root).  Plain pointers and sizes only; no torch / HIP types.  All host
+ * buffers are caller-owned; the library owns every device allocation.  A handle is not
+ * thread-safe: one handle per GPU / host thread.  Every call returns BOD_OK or an error code;
+ * bod_last_error() gives the message.  Empty results (M = 0 / K = 0) are not errors
+ * (src/retina_net/experiments/run_inference.py:147-161).
+ */
+#ifndef BAYESOD_H
+#define BAYESOD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bod_context* bod_handle;
+
+typedef enum {
+    BOD_OK = 0,
+    BOD_ERR_INVALID_ARG = 1,   /* maps to ValueError in the Python mirror            */
+    BOD_ERR_HIP = 2,           /* HIP runtime failure (message holds hipGetErrorString) */
+    BOD_ERR_OOM = 3,
+    BOD_ERR_NOT_READY = 4,     /* weights / anchors not loaded, or stage order violated */
+    BOD_ERR_NO_DEVICE = 5
+} bod_status;
+
+enum { BOD_RANK_SCORE = 0, BOD_RANK_JOINT_ENTROPY = 1 };
+enum { BOD_NMS_VARIANT_A = 0, BOD_NMS_VARIANT_B = 1 };      /* SURVEY.md App. A.8 */
+enum { BOD_HEAD_CLS = 0, BOD_HEAD_REG = 1, BOD_HEAD_COV = 2 };
+
+/* Mirrors model_config / testing_config of src/retina_net/configs/retinanet_bdd_covar.yaml
+ * (:61-143) plus the geometry the reference derives at run time. */
+typedef struct {
+    int32_t device;              /* HIP device ordinal (--gpu_device, run_inference.py:267)           */
+    int32_t image_h, image_w;    /* network input size                                                */
+    int32_t batch;               /* images per call (reference: 1, run_inference.py:68)               */
+    int32_t mc_samples;          /* model_config.mc_dropout_samples (yaml :66)                        */
+    int32_t num_classes;         /* header.num_classes + 1 background (multitask_headers.py:86-88)    */
+    int32_t anchors_per_location;/* len(scales)*len(aspect_ratios) (config_utils.py:81-86)            */
+    int32_t min_level, max_level;/* anchor_generator.layers (yaml :53) -> 3..7                         */
+    float   dropout_rate;        /* header.dropout_rate (yaml :82)                                    */
+    int32_t use_full_covar;      /* testing_config.use_full_covar (yaml :125)                         */
+    int32_t dirichlet_non_informative; /* bayes_od_config.dirichlet_prior.type == 'non_informative'   */
+    int32_t gaussian_isotropic;  /* bayes_od_config.gaussian_prior.type == 'isotropic'                */
+    float   isotropic_variance;  /* yaml :141                                                         */
+    int32_t ranking_method;      /* BOD_RANK_*  (yaml :133)                                           */
+    int32_t nms_max_output_size; /* nms_config.max_output_size (yaml :128)                            */
+    float   nms_iou_threshold;   /* nms_config.iou_threshold, also the clustering affinity threshold
+                                    (run_inference.py:148-149)                                        */
+    float   nms_soft_sigma;      /* nms_config.soft_nms_sigma                                         */
+    int32_t nms_variant;         /* BOD_NMS_VARIANT_*                                                 */
+    int32_t num_categorical_draws; /* Categorical.sample(30) (inference_utils.py:42)                  */
+    int32_t has_covar_head;      /* 'regression_covar' in output_names (retinanet_model.py:50)        */
+    float   kitti_scale_h, kitti_scale_w; /* orig/net size; 0 => dataset != 'kitti'
+                                    (inference_utils.py:147-167)                                      */
+    int32_t reserved[8];
+} bod_config;
+
+/* Sizes the caller needs to allocate host buffers. */
+typedef struct {
+    int32_t num_pixels;          /* P: sum over levels of h*w            */
+    int32_t num_anchors;         /* A = P * anchors_per_location         */
+    int32_t level_h[8], level_w[8];
+    int32_t num_levels;
+    int32_t max_detections;      /* nms_max_output_size                  */
+    int64_t device_bytes;        /* total HBM the handle holds           */
+} bod_sizes;
+
+const char* bod_version(void);
+const char* bod_last_error(bod_handle h);         /* h may be NULL: last create() failure */
+
+/* RetinaNetModel(model_config)  (src/retina_net/models/retinanet_model.py:19-65) */
+bod_status bod_create(const bod_config* cfg, bod_handle* out);
+bod_status bod_destroy(bod_handle h);
+bod_status bod_query_sizes(bod_handle h, bod_sizes* out);
+/* Change the testing_config-derived fields (use_full_covar, priors, ranking, nms_*, kitti scale,
+ * num_categorical_draws) of a live handle; geometry / batch / mc_samples / heads must be unchanged. */
+bod_status bod_update_config(bod_handle h, const bod_config* cfg);
+
+/* ckpt.restore(...) (run_inference.py:120): one call per Keras variable, fp32 host data.
+ * kind: 0 conv kernel HWIO [kh,kw,cin,cout]; 1 conv bias [cout]; 2..5 BN gamma/beta/mean/var.
+ * name: Keras layer name ('conv1', 'bn_conv1', 'res2a_branch2a', 'C5_reduced', 'P3',
+ * 'pyramid_classification_0', 'pyramid_classification', 'pyramid_regression', 'pyramid_cov' ...;
+ * feature_extractor.py:154-155,231-232; feature_decoder.py:28-132; multitask_headers.py:30-314). */
+bod_status bod_load_weight(bod_handle h, const char* name, int32_t kind,
+                           const int64_t* shape, int32_t ndim, const float* data);
+/* Folds frozen BN (feature_extractor.py:108 ... training=False), packs bf16 OHWI, uploads. */
+bod_status bod_finalize_weights(bod_handle h);
+
+/* sample_dict['anchors'] (src/core/constants.py:50; bdd_dataset_handler.py:183-186): [A,4] (v,u,h,w) */
+bod_status bod_set_anchors(bod_handle h, const float* anchors_vuhw, int32_t num_anchors);
+
+/* model(image, train_val_test='testing')  (retinanet_model.py:67-112).
+ * images: [batch,H,W,3] fp32 normalised BGR (sample_dict['image_normalized']), host pointer or,
+ * if images_on_device != 0, a device pointer already resident in HBM.
+ * seed / first_image_id key the Philox dropout + categorical streams (DESIGN.md RNG contract). */
+bod_status bod_forward(bod_handle h, const float* images, int32_t images_on_device,
+                       uint64_t seed, uint32_t first_image_id);
+/* prediction_dict tensors (src/core/constants.py:61-63), copied to host:
+ * cls [batch,N,A,C], box [batch,N,A,4], covar params [batch,N,A,10] (pre fill_triangular).
+ * Any pointer may be NULL. */
+bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* covar_params);
+/* Replace the head outputs with caller-supplied ones (stage-level parity tests). */
+bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const float* covar_params);
+/* Backbone / FPN taps for parity tests: which = 0..4 -> p3..p7 ([batch,h,w,256] fp32 out). */
+bod_status bod_get_pyramid(bod_handle h, int32_t level_index, float* out);
+
+/* bayes_od_inference after the model call (src/retina_net/experiments/inference_utils.py:25-202):
+ * decode, softmax, mean over MC, categorical sampling, filter, per-anchor mean / 4x4 covariance,
+ * aleatoric L D L^T, mixing, Dirichlet + Gaussian prior fusion, ranking; compacted in anchor order. */
+bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id);
+/* Per image results of bod_posterior. num_kept[batch]; the arrays are [M,...] for image_index.
+ * counts/score [M,C], means [M,4], covs [M,16], ranking [M], anchor_index [M]. NULLs skipped. */
+bod_status bod_get_num_kept(bod_handle h, int32_t* num_kept);
+bod_status bod_get_posterior(bod_handle h, int32_t image_index, float* counts, float* score,
+                             float* means, float* covs, float* ranking, int32_t* anchor_index);
+/* Inject a posterior (stage-level parity of NMS / clustering): arrays as above, M rows. */
+bod_status bod_set_posterior(bod_handle h, int32_t image_index, int32_t m, const float* counts,
+                             const float* means, const float* covs, const float* ranking);
+
+/* tf.image.non_max_suppression_with_scores on vuhw_to_vuvu(means) (inference_utils.py:204-212). */
+bod_status bod_nms(bod_handle h);
+bod_status bod_get_nms(bod_handle h, int32_t image_index, int32_t* indices, int32_t* num_selected);
+/* box_utils.bbox_iou_vuvu(corners, corners) (inference_utils.py:214-215): [M,M] fp32 to host. */
+bod_status bod_get_iou_matrix(bod_handle h, int32_t image_index, float* iou);
+
+/* bayes_od_clustering (inference_utils.py:285-364) on the device, affinity = the IoU above,
+ * threshold = nms_iou_threshold; covariances x70. */
+bod_status bod_cluster_fuse(bod_handle h);
+/* Final detections of one image: K <= max_detections rows.
+ * scores [K,C], means [K,4] (v,u,h,w), covs [K,16], counts [K,C]. */
+bod_status bod_get_detections(bod_handle h, int32_t image_index, int32_t* num_detections,
+                              float* scores, float* means, float* covs, float* counts);
+
+/* The whole per-image body of run_inference.test_model's loop (:137-149) for `batch` images:
+ * forward -> posterior -> nms -> cluster_fuse, one stream, no host round trip. */
+bod_status bod_infer(bod_handle h, const float* images, int32_t images_on_device,
+                     uint64_t seed, uint32_t first_image_id);
+
+/* Device buffer of [batch,H,W,3] fp32 owned by the handle (fill with bod_upload_images, then
+ * pass to bod_forward/bod_infer with images_on_device=1). */
+bod_status bod_upload_images(bod_handle h, const float* host_images);
+const float* bod_device_images(bod_handle h);
+bod_status bod_synchronize(bod_handle h);
+
+/* Measurement hooks (bench.py): HIP-event timing of the dominant kernel on the handle's stream. */
+bod_status bod_profile_begin(bod_handle h);
+/* total ms in head 3x3 conv launches since begin, number of launches, FLOPs (2*MACs) issued */
+bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
+                           double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESOD_H */

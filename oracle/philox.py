@@ -1,0 +1,74 @@
+"""Philox4x32-10 counter-based RNG (Salmon et al., SC'11; the generator behind rocRAND's
+``rocrand_state_philox4x32_10``), vectorised in NumPy.  Oracle-side twin of
+``bayes-od-rc_amd/csrc/philox.h``.
+
+The reference draws its randomness from unseeded TF streams (Dropout:
+models/multitask_headers.py:104-116; ``Categorical.sample(30)``:
+experiments/inference_utils.py:37-46), which cannot be reproduced.  The build therefore
+*defines* the streams (DESIGN.md "RNG contract") so the HIP path and this oracle consume
+identical random numbers:
+
+dropout   counter = (pixel p in the image's p3..p7 concatenated pyramid,
+                     channel group c//4,
+                     sample n | layer_id << 16,      layer_id = head*4 + layer, head cls/reg/cov = 0/1/2
+                     image id)
+          key     = (seed_lo, seed_hi)
+          word j of the result decides channel 4*(c//4)+j: keep iff word >= DROP_THRESHOLD(rate)
+
+categorical  counter = (anchor a, draw group g, CAT_TAG, image id); draw d = 4*g + j uses word j,
+          u = (word >> 8) * 2**-24 in [0, 1)
+"""
+import numpy as np
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = 0x9E3779B9
+_W1 = 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+_S32 = np.uint64(32)
+
+CAT_TAG = 0x00CA7E60
+NUM_CAT_DRAWS = 30
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Returns 4 uint32 arrays. Counter words broadcast against each other; key is scalar."""
+    c0, c1, c2, c3 = np.broadcast_arrays(*(np.asarray(c, dtype=np.uint64) for c in (c0, c1, c2, c3)))
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> _S32, p0 & _MASK
+        hi1, lo1 = p1 >> _S32, p1 & _MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def drop_threshold(rate):
+    """keep iff word >= floor(rate * 2**32)  (P[keep] = 1 - rate to within 2**-32)."""
+    return np.uint32(int(np.floor(float(rate) * 4294967296.0)))
+
+
+def dropout_keep_mask(seed, image_id, sample, layer_id, num_pixels, channels, rate):
+    """bool [num_pixels, channels]: True where the activation is kept."""
+    assert channels % 4 == 0
+    p = np.arange(num_pixels, dtype=np.uint64)[:, None]
+    g = np.arange(channels // 4, dtype=np.uint64)[None, :]
+    z = np.uint64((int(sample) & 0xFFFF) | (int(layer_id) << 16))
+    words = philox4x32_10(p, g, z, np.uint64(image_id), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    keep = np.stack([w >= drop_threshold(rate) for w in words], axis=-1)  # [P, C/4, 4]
+    return keep.reshape(num_pixels, channels)
+
+
+def categorical_uniforms(seed, image_id, num_anchors, num_draws=NUM_CAT_DRAWS):
+    """float32 [num_anchors, num_draws] uniforms in [0,1) (24-bit)."""
+    groups = (num_draws + 3) // 4
+    a = np.arange(num_anchors, dtype=np.uint64)[:, None]
+    g = np.arange(groups, dtype=np.uint64)[None, :]
+    words = philox4x32_10(a, g, np.uint64(CAT_TAG), np.uint64(image_id),
+                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(words, axis=-1).reshape(num_anchors, groups * 4)[:, :num_draws]
+    return ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

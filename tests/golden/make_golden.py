@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors from the reference's importable NumPy half.
+
+Run ONCE in the build container (``/root/reference`` must exist); the GPU box never
+runs this.  TensorFlow / tensorflow-probability are not installed, so the module-level
+``import tensorflow`` in the reference files is satisfied by an empty stub whose only
+attribute is an identity ``tf.function`` decorator.  Only NumPy/SciPy code
+of the reference is executed:
+
+  * ``bayes_od_clustering``      src/retina_net/experiments/inference_utils.py:285-364
+  * ``map_dataset_classes``      src/retina_net/experiments/inference_utils.py:372-404
+  * ``vuhw_to_vuvu_np`` / ``vuvu_to_vuhw_np``   src/retina_net/anchor_generator/box_utils.py:49-91
+  * ``compute_gaussian_entropy_np`` / ``compute_categorical_entropy_np``
+                                 src/core/evaluation_utils_2d.py:280-290
+  * ``two_d_iou`` / ``get_ap``   src/core/evaluation_utils_2d.py:12-49,253-269
+  * ``predictions_to_bdd_format`` / ``predictions_to_kitti_format`` / ``strip_checkpoint_id``
+                                 src/retina_net/experiments/validation_utils.py:96-107,183-272
+
+Outputs (data only, no reference source text): ``tests/golden/*.npz`` + ``writers.json``.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("BAYESOD_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_tf_stub():
+    tf = types.ModuleType("tensorflow")
+    tf.function = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    tf.keras = types.SimpleNamespace()
+    tfp = types.ModuleType("tensorflow_probability")
+    sys.modules["tensorflow"] = tf
+    sys.modules["tensorflow_probability"] = tfp
+    # numpy aliases removed in numpy>=1.24 that a few reference helpers still use
+    for name, typ in (("int", int), ("float", float), ("bool", bool)):
+        if not hasattr(np, name):
+            setattr(np, name, typ)
+
+
+def _random_spd(rng, n, scale):
+    a = rng.normal(size=(n, 4, 4))
+    m = a @ np.transpose(a, (0, 2, 1)) + 0.5 * np.eye(4)[None]
+    return (m * scale).astype(np.float32)
+
+
+def _boxes_vuhw(rng, n, n_objects):
+    """n boxes jittered around n_objects centres so IoU clusters exist."""
+    centres = rng.uniform(60, 440, size=(n_objects, 2))
+    dims = rng.uniform(30, 120, size=(n_objects, 2))
+    which = rng.integers(0, n_objects, size=n)
+    vu = centres[which] + rng.normal(scale=2.0, size=(n, 2))
+    hw = dims[which] * np.exp(rng.normal(scale=0.04, size=(n, 2)))
+    return np.concatenate([vu, hw], axis=1).astype(np.float32), which
+
+
+def _iou_matrix_ref_convention(vuvu):
+    """IoU exactly as box_utils.bbox_iou_vuvu:117-146 (float32, +1 convention, area quirk)."""
+    b = vuvu.astype(np.float32)
+    y1, x1, y2, x2 = b[:, 0:1], b[:, 1:2], b[:, 2:3], b[:, 3:4]
+    xi1 = np.maximum(x1, x1.T)
+    yi1 = np.maximum(y1, y1.T)
+    xi2 = np.minimum(x2, x2.T)
+    yi2 = np.minimum(y2, y2.T)
+    one = np.float32(1.0)
+    inter = np.maximum(xi2 - xi1 + one, 0) * np.maximum(yi2 - yi1 + one, 0)
+    area = (x1 - x2 + one) * (y1 - y2 + one)
+    union = area + area.T - inter
+    return (inter / (union + np.float32(0.00001))).astype(np.float32)
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not found at %s" % REF)
+    _install_tf_stub()
+    sys.path.insert(0, REF)
+    from src.retina_net.experiments import inference_utils as ref_iu
+    from src.retina_net.anchor_generator import box_utils as ref_bu
+    from src.core import evaluation_utils_2d as ref_ev
+    from src.retina_net.experiments import validation_utils as ref_vu
+
+    # ------------------------------------------------------------------ clustering
+    cases = {}
+    idx = 0
+    for seed in range(5):
+        for (m, n_obj, k, c) in ((1, 1, 1, 8), (4, 1, 1, 8), (12, 3, 2, 4),
+                                 (60, 5, 5, 8), (200, 12, 17, 8)):
+            rng = np.random.default_rng(1000 * seed + m)
+            vuhw, which = _boxes_vuhw(rng, m, n_obj)
+            vuvu = ref_bu.vuhw_to_vuvu_np(vuhw)
+            iou = _iou_matrix_ref_convention(vuvu)
+            covs = _random_spd(rng, m, 4.0)
+            # counts: 30 categorical draws + 1/C prior, with distinct rows to avoid KL ties
+            probs = rng.dirichlet(np.ones(c) * 0.6, size=m)
+            counts = np.stack([rng.multinomial(30, p) for p in probs]).astype(np.float32)
+            counts = counts + np.float32(1.0 / c)
+            k_eff = min(k, m)
+            centres = rng.choice(m, size=k_eff, replace=False).astype(np.int32)
+            means = vuhw[:, :, None].astype(np.float32)
+            scores, fmeans, fcovs, fcounts = ref_iu.bayes_od_clustering(
+                counts, means, covs, centres, iou, affinity_threshold=0.5)
+            # record KL margins so the test can skip argpartition ties
+            tag = "c%02d" % idx
+            cases[tag + "_counts"] = counts
+            cases[tag + "_means"] = means
+            cases[tag + "_covs"] = covs
+            cases[tag + "_centres"] = centres
+            cases[tag + "_iou"] = iou
+            cases[tag + "_out_scores"] = np.asarray(scores)
+            cases[tag + "_out_means"] = np.asarray(fmeans)
+            cases[tag + "_out_covs"] = np.asarray(fcovs)
+            cases[tag + "_out_counts"] = np.asarray(fcounts)
+            idx += 1
+    cases["n_cases"] = np.int32(idx)
+    cases["affinity_threshold"] = np.float32(0.5)
+    np.savez_compressed(os.path.join(OUT, "clustering.npz"), **cases)
+
+    # ------------------------------------------------------------------ box utils
+    rng = np.random.default_rng(7)
+    vuhw = np.concatenate([rng.uniform(0, 500, (64, 2)), rng.uniform(1, 200, (64, 2))], 1)
+    vuhw32 = vuhw.astype(np.float32)
+    np.savez_compressed(
+        os.path.join(OUT, "box_utils.npz"),
+        vuhw64=vuhw, vuvu64=ref_bu.vuhw_to_vuvu_np(vuhw),
+        back64=ref_bu.vuvu_to_vuhw_np(ref_bu.vuhw_to_vuvu_np(vuhw)),
+        vuhw32=vuhw32, vuvu32=ref_bu.vuhw_to_vuvu_np(vuhw32),
+        back32=ref_bu.vuvu_to_vuhw_np(ref_bu.vuhw_to_vuvu_np(vuhw32)))
+
+    # ------------------------------------------------------------------ class mapping
+    rng = np.random.default_rng(11)
+    sc = rng.dirichlet(np.ones(8), size=40).astype(np.float32)
+    mapped = ref_iu.map_dataset_classes("bdd", "kitti", sc)
+    same = ref_iu.map_dataset_classes("coco", "pascal", sc)  # empty mapping dict -> identity
+    np.savez_compressed(os.path.join(OUT, "class_map.npz"),
+                        scores=sc, bdd_to_kitti=mapped, identity=same)
+
+    # ------------------------------------------------------------------ entropies / eval helpers
+    rng = np.random.default_rng(13)
+    covs = _random_spd(rng, 16, 3.0).astype(np.float64)
+    g_ent = np.array([ref_ev.compute_gaussian_entropy_np(c) for c in covs])
+    cat = rng.dirichlet(np.ones(8), size=16)
+    c_ent = np.array([ref_ev.compute_categorical_entropy_np(c) for c in cat])
+    box = np.array([10., 20., 110., 220.])
+    boxes = np.concatenate([rng.uniform(0, 100, (32, 2)), rng.uniform(100, 300, (32, 2))], 1)
+    iou = ref_ev.two_d_iou(box, boxes)
+    rec = np.sort(rng.uniform(0, 1, 50))
+    prec = np.sort(rng.uniform(0, 1, 50))[::-1].copy()
+    ap = ref_ev.get_ap(rec.copy(), prec.copy())
+    np.savez_compressed(os.path.join(OUT, "eval_helpers.npz"),
+                        covs=covs, gaussian_entropy=g_ent, cat=cat, categorical_entropy=c_ent,
+                        box=box, boxes=boxes, two_d_iou=iou, recalls=rec, precisions=prec,
+                        ap=np.float64(ap))
+
+    # ------------------------------------------------------------------ writers
+    rng = np.random.default_rng(17)
+    out_boxes = np.concatenate([rng.uniform(0, 200, (6, 2)), rng.uniform(200, 500, (6, 2))], 1)
+    out_boxes = out_boxes.astype(np.float32)
+    cls8 = rng.dirichlet(np.ones(8) * 0.3, size=6).astype(np.float32)
+    cls8[0] = np.eye(8, dtype=np.float32)[7] * 0.9 + 0.0125   # background-dominant row is dropped
+    bdd = ref_vu.predictions_to_bdd_format(
+        out_boxes, cls8, "frame_0001",
+        category_list=['car', 'truck', 'bus', 'person', 'rider', 'bike', 'motor'])
+    cls5 = ref_iu.map_dataset_classes("bdd", "kitti", cls8)
+    kitti = ref_vu.predictions_to_kitti_format(out_boxes, cls5)
+    with open(os.path.join(OUT, "writers.json"), "w") as fp:
+        json.dump({
+            "boxes": out_boxes.tolist(), "cls8": cls8.tolist(), "cls5": cls5.tolist(),
+            "bdd": bdd, "kitti": [[str(v) for v in row] for row in kitti.tolist()],
+            "ckpt_ids": {p: ref_vu.strip_checkpoint_id(p)
+                         for p in ("a/b/ckpt-101", "x/retinanet_bdd_covar-7", "ckpt-000012")},
+        }, fp, indent=1)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
