@@ -58,6 +58,7 @@ SIGNATURES = {
     "bod_set_posterior": (C.c_int, [_H, C.c_int32, C.c_int32, _F, _F, _F, _F]),
     "bod_nms": (C.c_int, [_H]),
     "bod_get_nms": (C.c_int, [_H, C.c_int32, _I, _I]),
+    "bod_set_nms": (C.c_int, [_H, C.c_int32, _I, C.c_int32]),
     "bod_get_iou_matrix": (C.c_int, [_H, C.c_int32, _F]),
     "bod_cluster_fuse": (C.c_int, [_H]),
     "bod_get_detections": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
@@ -65,6 +66,9 @@ SIGNATURES = {
     "bod_upload_images": (C.c_int, [_H, _F]),
     "bod_device_images": (C.c_void_p, [_H]),
     "bod_synchronize": (C.c_int, [_H]),
+    "bod_stage_conv": (C.c_int, [C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F,
+                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F,
+                                 C.c_float, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, _F]),
     "bod_profile_begin": (C.c_int, [_H]),
     "bod_profile_end": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -917,6 +917,23 @@ bod_status bod_get_nms(bod_handle h, int32_t img, int32_t* indices, int32_t* num
     return BOD_OK;
 }
 
+bod_status bod_set_nms(bod_handle h, int32_t img, const int32_t* indices, int32_t n) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior / bod_set_posterior has not run");
+    if (img < 0 || img >= h->cfg.batch || n < 0 || n > h->cfg.nms_max_output_size || (n > 0 && !indices))
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_set_nms: bad image index or count (max %d)", h->cfg.nms_max_output_size);
+    int32_t m = 0;
+    BODCHK(image_m(h, img, &m));
+    for (int i = 0; i < n; ++i)
+        if (indices[i] < 0 || indices[i] >= m) return h->fail(BOD_ERR_INVALID_ARG, "cluster centre %d out of range [0,%d)", indices[i], m);
+    if (n > 0)
+        HIPCHK(h, hipMemcpyAsync(h->nms_sel + (size_t)img * h->cfg.nms_max_output_size, indices, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->nms_nsel + img, &n, 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->nms_done = true; h->cluster_done = false;
+    return BOD_OK;
+}
+
 bod_status bod_get_iou_matrix(bod_handle h, int32_t img, float* iou) {
     if (!h || !iou) return BOD_ERR_INVALID_ARG;
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
@@ -970,6 +987,112 @@ bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint6
     BODCHK(run_posterior(h, seed, first_image_id));
     BODCHK(run_nms(h));
     return run_cluster(h);
+}
+
+bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          const float* w, const float* bias, int32_t KH, int32_t KW, int32_t Cout,
+                          int32_t stride, int32_t same_padding, int32_t relu, const float* residual,
+                          float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
+                          int32_t round_output_bf16, float* out) {
+    bod_context ctx;                      // scratch context: owns the temporary device buffers
+    bod_context* h = &ctx;
+    auto done = [&](bod_status s) {
+        if (s != BOD_OK) g_create_error = h->err;
+        if (h->stream) hipStreamSynchronize(h->stream);
+        for (void* p : h->allocs) hipFree(p);
+        if (h->stream) hipStreamDestroy(h->stream);
+        h->allocs.clear(); h->stream = nullptr;
+        return s;
+    };
+    if (!x || !w || !out || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || stride > 2)
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad argument"));
+    if (Cin % 64 != 0 || ((round_output_bf16 || dropout_rate > 0.f) && Cout % 4 != 0))
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: Cin must be a multiple of 64 (and Cout of 4 for bf16 output); got %d, %d", Cin, Cout));
+    if (KH > 3 || KW > 3) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: kernel larger than 3x3 needs a wider zero border"));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return done(h->fail(BOD_ERR_NO_DEVICE, "no HIP device %d: libbayesod_hip has no CPU fallback", device));
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return done(h->fail(BOD_ERR_HIP, "cannot set up device %d", device));
+    h->cfg.batch = B;
+    int OH, OW, oy = 1, ox = 1;
+    if (same_padding) {
+        OH = (H + stride - 1) / stride; OW = (W + stride - 1) / stride;
+        oy = 1 - same_pad_before(H, KH, stride); ox = 1 - same_pad_before(W, KW, stride);
+    } else {
+        OH = (H - KH) / stride + 1; OW = (W - KW) / stride + 1;
+    }
+    if (OH < 1 || OW < 1) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: empty output"));
+    auto run = [&]() -> bod_status {
+        Plane in, res;
+        BODCHK(new_plane(h, &in, B, H, W, Cin));
+        std::vector<uint16_t> hx((size_t)B * in.bstride * Cin, 0);
+        for (int b = 0; b < B; ++b)
+            for (int y = 0; y < H; ++y)
+                for (int xx = 0; xx < W; ++xx)
+                    for (int c = 0; c < Cin; ++c)
+                        hx[((size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1)) * Cin + c] =
+                            f2bf(x[(((size_t)b * H + y) * W + xx) * Cin + c]);
+        HIPCHK(h, hipMemcpyAsync(in.d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, h->stream));
+        if (residual) {
+            BODCHK(new_plane(h, &res, B, OH, OW, Cout));
+            std::vector<uint16_t> hr((size_t)B * res.bstride * Cout, 0);
+            for (int b = 0; b < B; ++b)
+                for (int y = 0; y < OH; ++y)
+                    for (int xx = 0; xx < OW; ++xx)
+                        for (int c = 0; c < Cout; ++c)
+                            hr[((size_t)b * res.bstride + (size_t)(y + 1) * res.pitch + (xx + 1)) * Cout + c] =
+                                f2bf(residual[(((size_t)b * OH + y) * OW + xx) * Cout + c]);
+            HIPCHK(h, hipMemcpyAsync(res.d, hr.data(), hr.size() * 2, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        HostTensor k; k.shape = {KH, KW, Cin, Cout}; k.data.assign(w, w + (size_t)KH * KW * Cin * Cout);
+        h->host_w["stage/0"] = std::move(k);
+        if (bias) { HostTensor bt; bt.shape = {Cout}; bt.data.assign(bias, bias + Cout); h->host_w["stage/1"] = std::move(bt); }
+        PackedConv pc;
+        BODCHK(pack_conv(h, "stage", "", 64, &pc));
+        // dense fp32 / bf16 output [B,OH,OW,Cout]
+        const bool drop = dropout_rate > 0.f;
+        const size_t n_out = (size_t)B * OH * OW * Cout;
+        float* d_out32 = nullptr; uint16_t* d_out16 = nullptr;
+        const bool f32_out = !round_output_bf16 && !drop;
+        if (f32_out) BODCHK(h->dalloc(&d_out32, n_out)); else BODCHK(h->dalloc(&d_out16, n_out));
+        std::vector<RowEnt> rows((size_t)B * OH * OW);
+        size_t r = 0;
+        for (int b = 0; b < B; ++b)
+            for (int y = 0; y < OH; ++y)
+                for (int xx = 0; xx < OW; ++xx) {
+                    RowEnt e{};
+                    e.in_off = (int32_t)(b * in.bstride + (int64_t)(y * stride + oy) * in.pitch + (xx * stride + ox));
+                    e.in_pitch = in.pitch;
+                    e.out_off = (int32_t)(((int64_t)b * OH + y) * OW + xx);
+                    if (residual) e.res_off = (int32_t)(b * res.bstride + (int64_t)(y + 1) * res.pitch + (xx + 1));
+                    e.rng_p = y * OW + xx;
+                    e.rng_zs = b;
+                    rows[r++] = e;
+                }
+        RowEnt* d_rows = nullptr;
+        BODCHK(h->dalloc(&d_rows, rows.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        ConvArgs a = base_args(pc, d_rows, B * OH * OW, Cin, Cout);
+        a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id};
+        a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | (f32_out ? CONV_OUT_F32 : 0);
+        a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
+        a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 4294967296.0);
+        a.drop_scale = (float)(1.0 / (1.0 - (double)dropout_rate));
+        HIPCHK(h, launch_conv_igemm(a, h->stream));
+        if (f32_out) {
+            HIPCHK(h, hipMemcpyAsync(out, d_out32, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        } else {
+            std::vector<uint16_t> ho(n_out);
+            HIPCHK(h, hipMemcpyAsync(ho.data(), d_out16, n_out * 2, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n_out; ++i) out[i] = bf2f(ho[i]);
+        }
+        return BOD_OK;
+    };
+    return done(run());
 }
 
 bod_status bod_profile_begin(bod_handle h) {

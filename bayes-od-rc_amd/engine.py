@@ -195,6 +195,10 @@ class Engine(object):
         self._chk(self.lib.bod_get_nms(self.h, image_index, iptr(idx), C.byref(n)))
         return idx[:n.value].copy()
 
+    def _set_centres(self, image_index, centres):
+        c = np.ascontiguousarray(centres, dtype=np.int32)
+        self._chk(self.lib.bod_set_nms(self.h, image_index, iptr(c), c.shape[0]))
+
     def get_iou_matrix(self, image_index=0):
         m = int(self.num_kept()[image_index])
         out = np.empty((m, m), np.float32)
@@ -227,3 +231,27 @@ class Engine(object):
         self._chk(self.lib.bod_profile_end(self.h, C.byref(hm), C.byref(hl), C.byref(fl), C.byref(pm), C.byref(pl)))
         return {"head_conv_ms": hm.value, "head_conv_launches": hl.value, "head_conv_flops": fl.value,
                 "posterior_ms": pm.value, "posterior_launches": pl.value}
+
+
+def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=None, dropout_rate=0.0,
+               seed=0, layer_id=0, image_id=0, round_output_bf16=False, device=0):
+    """One convolution through the pipeline's MFMA kernel (``bod_stage_conv``), for parity tests.
+    x [B,H,W,Cin], w HWIO; returns [B,OH,OW,Cout] float32."""
+    lib = _lib.load()
+    x, w = as_f32(x), as_f32(w)
+    b, h, wd, cin = x.shape
+    kh, kw, cin2, cout = w.shape
+    if cin2 != cin:
+        raise ValueError("kernel Cin %d != input Cin %d" % (cin2, cin))
+    if padding == "same":
+        oh, ow = -(-h // stride), -(-wd // stride)
+    else:
+        oh, ow = (h - kh) // stride + 1, (wd - kw) // stride + 1
+    out = np.empty((b, oh, ow, cout), np.float32)
+    bias = as_f32(bias) if bias is not None else None
+    residual = as_f32(residual) if residual is not None else None
+    st = lib.bod_stage_conv(device, fptr(x), b, h, wd, cin, fptr(w), fptr(bias), kh, kw, cout, stride,
+                            int(padding == "same"), int(relu), fptr(residual), float(dropout_rate), seed,
+                            layer_id, image_id, int(round_output_bf16), fptr(out))
+    _lib.check(lib, None, st)
+    return out

@@ -1,0 +1,131 @@
+"""``RetinaNetModel`` with the reference's constructor / call surface
+(src/retina_net/models/retinanet_model.py:17-149) over the HIP engine.
+
+    model = RetinaNetModel(config['model_config'])
+    model.load_weights(weights_dict)                      # stands in for ckpt.restore (run_inference.py:120)
+    prediction_dict = model(image_normalized, train_val_test='testing')
+
+The engine (device buffers, row tables, packed weights) is built on the first call for the
+image shape seen, like ``@tf.function`` tracing per input signature (inference_utils.py:13).
+Only 'testing' and 'validation' modes exist here: training is outside the hot path
+(SURVEY.md section 8f).
+"""
+import numpy as np
+
+from . import constants
+from .engine import Engine, make_config
+
+
+def fill_triangular_4(x):
+    """tfp.math.fill_triangular for 10 -> 4x4 lower (retinanet_model.py:110)."""
+    idx = ((4, -1, -1, -1), (8, 9, -1, -1), (7, 6, 5, -1), (3, 2, 1, 0))
+    out = np.zeros(x.shape[:-1] + (4, 4), dtype=x.dtype)
+    for r in range(4):
+        for c in range(4):
+            if idx[r][c] >= 0:
+                out[..., r, c] = x[..., idx[r][c]]
+    return out
+
+
+class RetinaNetModel(object):
+    def __init__(self, model_config, device=0, batch=1, seed=0):
+        self.model_config = model_config
+        names = model_config['output_names']
+        self.compute_cls = 'classification' in names
+        self.compute_reg = 'regression' in names
+        self.compute_covar = 'regression_covar' in names
+        if not (self.compute_cls and self.compute_reg):
+            raise ValueError("the BayesOD path needs both 'classification' and 'regression' outputs")
+        header = model_config['header']
+        if 'num_classes' not in header or 'anchors_per_location' not in header:
+            raise ValueError("model_config['header'] lacks num_classes / anchors_per_location: "
+                             "run config_utils.setup(config, args) first")
+        self.num_classes = int(header['num_classes'])                  # excl. background
+        self.anchors_per_location = int(header['anchors_per_location'])
+        self.dropout_rate = float(header['dropout_rate'])
+        self.mc_dropout_samples = int(model_config['mc_dropout_samples'])
+        self.device = device
+        self.batch = batch
+        self.seed = seed
+        self.image_counter = 0
+        self.prediction_dict = None
+        self._weights = None
+        self._engines = {}
+        self._testing_overrides = {}
+
+    # -- weights ---------------------------------------------------------------------------
+    def load_weights(self, weights):
+        """weights: dict or path to an .npz with keys '<layer>/<field>' (field in kernel, bias,
+        gamma, beta, mean, var) -- Keras layer names, HWIO kernels."""
+        if isinstance(weights, str):
+            z = np.load(weights)
+            d = {}
+            for k in z.files:
+                layer, field = k.rsplit('/', 1)
+                d.setdefault(layer, {})[field] = z[k]
+            weights = d
+        self._weights = weights
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+    @staticmethod
+    def save_weights_npz(weights, path):
+        flat = {"%s/%s" % (l, f): a for l, e in weights.items() for f, a in e.items() if a is not None}
+        np.savez(path, **flat)
+
+    # -- engine ----------------------------------------------------------------------------
+    def engine_for(self, image_hw, batch=None, mc_samples=None, **testing):
+        if self._weights is None:
+            raise ValueError("no weights loaded: call model.load_weights(...) (the reference raises "
+                             "ValueError for a missing checkpoint, run_inference.py:56-58)")
+        batch = batch or self.batch
+        n = mc_samples or self.mc_dropout_samples
+        key = (int(image_hw[0]), int(image_hw[1]), batch, n)
+        cfg = make_config(image_hw, batch=batch, mc_samples=n, num_classes=self.num_classes + 1,
+                          anchors_per_location=self.anchors_per_location, device=self.device,
+                          dropout_rate=self.dropout_rate, has_covar_head=self.compute_covar, **testing)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = Engine(cfg)
+            eng.load_weights(self._weights)
+            self._engines[key] = eng
+        else:
+            eng.update_config(cfg)
+        return eng
+
+    # -- call ------------------------------------------------------------------------------
+    def __call__(self, input_tensor, train_val_test='testing', seed=None, image_id=None):
+        """input_tensor: [B,H,W,3] float32 normalised BGR.  Returns the prediction dict with the
+        reference's keys; tensors are [B*N, A, .] with the MC samples of an image contiguous,
+        which for B == 1 is exactly the reference's [N, A, .] (retinanet_model.py:78-112)."""
+        x = np.asarray(input_tensor, dtype=np.float32)
+        if x.ndim != 4 or x.shape[-1] != 3:
+            raise ValueError("expected an NHWC image batch with 3 channels, got shape %s" % (x.shape,))
+        if train_val_test == 'training':
+            raise ValueError("training mode is outside the MI355X inference hot path")
+        n = self.mc_dropout_samples if train_val_test == 'testing' else 1
+        eng = self.engine_for(x.shape[1:3], batch=x.shape[0], mc_samples=n)
+        seed = self.seed if seed is None else seed
+        if image_id is None:
+            image_id = self.image_counter
+            self.image_counter += x.shape[0]
+        eng.forward(x, seed=seed, first_image_id=image_id)
+        cls, box, cov = eng.get_raw()
+        b, nn, a = cls.shape[:3]
+        self.prediction_dict = {
+            constants.ANCHORS_CLASS_PREDICTIONS_KEY: cls.reshape(b * nn, a, -1),
+            constants.ANCHORS_BOX_PREDICTIONS_KEY: box.reshape(b * nn, a, 4),
+        }
+        if self.compute_covar:
+            self.prediction_dict[constants.ANCHORS_COVAR_PREDICTIONS_KEY] = \
+                fill_triangular_4(cov.reshape(b * nn, a, 10))
+        self._last_engine = eng
+        self._last_seed, self._last_image_id = seed, image_id
+        return self.prediction_dict
+
+    call = __call__
+
+    def get_loss(self, sample_dict, prediction_dict):
+        raise NotImplementedError("losses belong to the training step (SURVEY.md section 8f-1), "
+                                  "not to the inference hot path")

@@ -127,6 +127,8 @@ bod_status bod_set_posterior(bod_handle h, int32_t image_index, int32_t m, const
 /* tf.image.non_max_suppression_with_scores on vuhw_to_vuvu(means) (inference_utils.py:204-212). */
 bod_status bod_nms(bod_handle h);
 bod_status bod_get_nms(bod_handle h, int32_t image_index, int32_t* indices, int32_t* num_selected);
+/* Inject cluster centres (the `cluster_centers` argument of bayes_od_clustering, :289). */
+bod_status bod_set_nms(bod_handle h, int32_t image_index, const int32_t* indices, int32_t num_selected);
 /* box_utils.bbox_iou_vuvu(corners, corners) (inference_utils.py:214-215): [M,M] fp32 to host. */
 bod_status bod_get_iou_matrix(bod_handle h, int32_t image_index, float* iou);
 
@@ -148,6 +150,21 @@ bod_status bod_infer(bod_handle h, const float* images, int32_t images_on_device
 bod_status bod_upload_images(bod_handle h, const float* host_images);
 const float* bod_device_images(bod_handle h);
 bod_status bod_synchronize(bod_handle h);
+
+/* Stage entry point for parity tests of the hot kernel: ONE convolution of the forward pass
+ * (keras Conv2D semantics) through the same implicit-GEMM MFMA kernel and
+ * epilogue the pipeline uses.  x [B,H,W,Cin] and w [KH,KW,Cin,Cout] (HWIO) are fp32 host arrays
+ * and are rounded to bf16 exactly as stored activations / packed weights are; bias fp32 (may be
+ * NULL); residual [B,OH,OW,Cout] optional (added before ReLU, like the bottleneck shortcut,
+ * feature_extractor.py:210-212).  dropout_rate > 0 applies the head-tower epilogue
+ * (multitask_headers.py:102-116): batch item b plays MC sample b, pixel index = y*OW+x.
+ * out [B,OH,OW,Cout] fp32; round_output_bf16 != 0 rounds it like a stored activation.
+ * Errors are reported through bod_last_error(NULL). */
+bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          const float* w, const float* bias, int32_t KH, int32_t KW, int32_t Cout,
+                          int32_t stride, int32_t same_padding, int32_t relu, const float* residual,
+                          float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
+                          int32_t round_output_bf16, float* out);
 
 /* Measurement hooks (bench.py): HIP-event timing of the dominant kernel on the handle's stream. */
 bod_status bod_profile_begin(bod_handle h);

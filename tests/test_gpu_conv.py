@@ -1,0 +1,111 @@
+"""GPU parity of the hot kernel in isolation: one convolution through the pipeline's
+implicit-GEMM MFMA kernel (C ABI ``bod_stage_conv``) vs the oracle's conv on IDENTICAL inputs
+(both sides see the same bf16-rounded activations and weights; accumulation is fp32 on the device,
+float64 in the oracle).  Tolerance: BASELINE.json north_star, 1e-3 relative."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+
+
+def _case(rng, b, h, w, cin, cout, k):
+    x = rng.normal(0, 1, (b, h, w, cin)).astype(np.float32)
+    wt = (rng.normal(0, 1, (k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    return x, wt, bias
+
+
+def _oracle(x, wt, bias, stride, padding, relu=False, residual=None):
+    from oracle import network
+    xb = network.bf16_round(x).astype(np.float64)
+    wb = network.bf16_round(wt).astype(np.float64)
+    y = network.conv2d(xb, wb, bias.astype(np.float64), stride, padding)
+    if residual is not None:
+        y = y + network.bf16_round(residual).astype(np.float64)
+    if relu:
+        y = np.maximum(y, 0)
+    return y
+
+
+CASES = [
+    # b, h, w, cin, cout, k, stride, padding          what it stands for
+    (2, 16, 16, 256, 256, 3, 1, "same"),            # head tower / FPN output conv
+    (1, 9, 13, 64, 64, 3, 1, "same"),               # ragged size, 64-wide cout tile
+    (2, 12, 12, 64, 256, 1, 1, "valid"),            # bottleneck 1x1 expand
+    (1, 15, 17, 256, 128, 1, 2, "valid"),           # ConvBlock strided 1x1 (odd input)
+    (1, 16, 16, 128, 256, 3, 2, "same"),            # P6: stride 2 SAME on even input (pad 0/1)
+    (1, 7, 5, 128, 256, 3, 2, "same"),              # stride 2 SAME on odd input (pad 1/1)
+    (1, 8, 8, 256, 72, 1, 1, "same"),               # cls output conv (fp32 out, padded cout)
+    (1, 8, 8, 256, 36, 1, 1, "same"),               # reg output conv
+    (1, 8, 8, 256, 90, 1, 1, "same"),               # cov output conv (cout not a multiple of 4)
+    (1, 40, 36, 512, 128, 3, 1, "same"),            # many K tiles, M not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,padding", CASES)
+def test_conv_matches_oracle(b, h, w, cin, cout, k, stride, padding):
+    from bayes_od_rc_amd.engine import stage_conv
+    rng = np.random.default_rng(cin * 131 + cout * 7 + k + h)
+    x, wt, bias = _case(rng, b, h, w, cin, cout, k)
+    got = stage_conv(x, wt, bias, stride=stride, padding=padding)
+    ref = _oracle(x, wt, bias, stride, padding)
+    assert got.shape == ref.shape
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert rel_err(got, ref, floor=rms) < REL_TOL
+
+
+def test_conv_residual_relu_bf16_store():
+    """Bottleneck tail: conv + shortcut + ReLU, stored as bf16 (feature_extractor.py:208-213)."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(5)
+    x, wt, bias = _case(rng, 2, 10, 14, 128, 512, 1)
+    res = rng.normal(0, 1, (2, 10, 14, 512)).astype(np.float32)
+    got = stage_conv(x, wt, bias, padding="valid", relu=True, residual=res, round_output_bf16=True)
+    ref = _oracle(x, wt, bias, 1, "valid", relu=True, residual=res)
+    assert np.array_equal(got, network.bf16_round(got))          # really bf16-valued
+    ref_b = network.bf16_round(ref.astype(np.float32))
+    # identical up to rare 1-ulp bf16 rounding flips (fp32 vs float64 accumulation)
+    mism = got != ref_b
+    assert mism.mean() < 2e-3
+    assert np.all(np.abs(got - ref_b)[mism] <= np.abs(ref_b[mism]) * 2.0 ** -7 + 1e-30)
+    assert np.all(got >= 0)
+
+
+def test_conv_dropout_matches_philox_contract():
+    """Head-tower epilogue: ReLU -> x/(1-rate) -> Philox keep mask -> bf16
+    (multitask_headers.py:102-116; DESIGN.md RNG contract)."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network, philox
+    rng = np.random.default_rng(9)
+    b, h, w = 3, 6, 10
+    x, wt, bias = _case(rng, b, h, w, 256, 256, 3)
+    seed, lid, img, rate = (0xDEADBEEF << 20) + 12345, 6, 41, 0.3
+    got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=rate, seed=seed,
+                     layer_id=lid, image_id=img)
+    ref = _oracle(x, wt, bias, 1, "same", relu=True)
+    keep = np.stack([philox.dropout_keep_mask(seed, img, s, lid, h * w, 256, rate).reshape(h, w, 256)
+                     for s in range(b)])
+    # dropped elements are exactly zero, kept ones are scaled by float32(1/(1-rate))
+    assert np.all(got[~keep] == 0)
+    assert abs(keep.mean() - (1 - rate)) < 0.01
+    scaled = ref * np.float64(np.float32(1.0 / (1.0 - rate))) * keep
+    ref_b = network.bf16_round(scaled.astype(np.float32))
+    mism = got != ref_b
+    assert mism.mean() < 2e-3
+    assert np.all(np.abs(got - ref_b)[mism] <= np.abs(ref_b[mism]) * 2.0 ** -7 + 1e-30)
+    # a different image id / layer id / seed gives a different mask
+    other = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=rate, seed=seed,
+                       layer_id=lid + 1, image_id=img)
+    assert ((other == 0) != (got == 0)).mean() > 0.2
+
+
+def test_stage_conv_rejects_bad_arguments():
+    from bayes_od_rc_amd.engine import stage_conv
+    x = np.zeros((1, 4, 4, 48), np.float32)
+    w = np.zeros((3, 3, 48, 64), np.float32)
+    with pytest.raises(ValueError):
+        stage_conv(x, w)                     # Cin not a multiple of 64

@@ -1,0 +1,118 @@
+"""GPU: the fused pipeline (bod_infer) and the reference-surface mirror, checked stage by stage
+against the oracle chained on the device's own intermediates (so every stage sees identical
+inputs), and for batch / API consistency."""
+import numpy as np
+import pytest
+
+from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG, rel_err
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+
+
+def _model(n=6, fg_bias=-1.0):
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.model import RetinaNetModel
+    cfg = {"output_names": ["classification", "regression", "regression_covar"],
+           "mc_dropout_samples": n,
+           "header": {"dropout_rate": 0.3, "num_classes": 7, "anchors_per_location": 9}}
+    model = RetinaNetModel(cfg)
+    model.load_weights(synthetic.make_weights(cls_fg_bias=fg_bias))
+    return model
+
+
+def test_infer_stage_chain_matches_oracle():
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.inference_utils import BayesOdPipeline
+    from oracle import bayes_od, philox, network, nms, clustering, geometry
+    hw, batch, n = (160, 160), 3, 6
+    model = _model(n)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    pipe = BayesOdPipeline(model, hw, batch, BAYES_CFG, NMS_CFG, use_full_covar=True, anchors=anchors)
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=11)
+    seed, first = 77, 100
+    dets = pipe(frames, seed=seed, first_image_id=first)
+    eng = pipe.engine
+    cls, box, cov = eng.get_raw()
+    for b in range(batch):
+        # stage 1: posterior on the device's own head outputs
+        u = philox.categorical_uniforms(seed, first + b, eng.A)
+        pred = {"anchors_class_predictions": cls[b], "anchors_box_predictions": box[b],
+                "anchors_box_covar_predictions": network.fill_triangular_4(cov[b])}
+        ref = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64)
+        got = eng.get_posterior(b)
+        m = got["means"].shape[0]
+        assert m > 50, "calibration should leave a few hundred anchors"
+        if not np.array_equal(np.nonzero(ref["keep"])[0], got["anchor_index"]):
+            continue                      # a draw on a float rounding boundary: covered in test_gpu_post
+        assert rel_err(got["means"], ref["means"][:, :, 0], 1.0) < REL_TOL
+        # stage 2: NMS on the device's posterior
+        ref_idx, _ = nms.soft_nms(geometry.vuhw_to_vuvu(got["means"]), got["ranking"], 100, 0.5, 0.5)
+        assert np.array_equal(eng.get_nms(b), ref_idx)
+        # stage 3: clustering on the device's posterior + centres, IoU from the reference formula
+        iou = geometry.bbox_iou_vuvu(geometry.vuhw_to_vuvu(got["means"]), geometry.vuhw_to_vuvu(got["means"]))
+        s, mu, cv, cn, margins = clustering.bayes_od_clustering(
+            got["counts"].astype(np.float64), got["means"][:, :, None].astype(np.float64),
+            got["covs"].astype(np.float64), ref_idx, iou, 0.5, return_margins=True)
+        scores, means, covs, counts = dets[b]
+        ok = margins > 1e-6               # argpartition ties are implementation-defined
+        assert scores.shape[0] == len(ref_idx)
+        assert rel_err(means[ok], mu[ok][:, :, 0], 1.0) < REL_TOL
+        floor = np.abs(cv).reshape(len(cv), -1).max(axis=1)[:, None, None] * 1e-2
+        assert (np.abs(covs - cv) / (np.abs(cv) + floor))[ok].max() < REL_TOL
+        assert rel_err(scores[ok], s[ok], 1e-6) < REL_TOL
+        assert rel_err(counts[ok], cn[ok], 1e-6) < 1e-5
+
+
+def test_batched_equals_single_image():
+    """Images are independent units: image b of a batch == the same frame run alone with the same id."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.inference_utils import BayesOdPipeline
+    hw, n = (128, 128), 4
+    model = _model(n)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(3, hw[0], hw[1], seed=5)
+    batched = BayesOdPipeline(model, hw, 3, BAYES_CFG, NMS_CFG, anchors=anchors)(frames, seed=1, first_image_id=10)
+    single = BayesOdPipeline(model, hw, 1, BAYES_CFG, NMS_CFG, anchors=anchors)
+    for b in range(3):
+        one = single(frames[b:b + 1], seed=1, first_image_id=10 + b)[0]
+        for x, y in zip(batched[b], one):
+            assert np.array_equal(x, y)
+
+
+def test_reference_surface_bayes_od_inference():
+    """bayes_od_inference / bayes_od_clustering with the reference's signatures and shapes
+    (inference_utils.py:14-19,217 and :285-291,364)."""
+    from bayes_od_rc_amd import synthetic, constants
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd import inference_utils, box_utils
+    hw = (128, 128)
+    model = _model(5)
+    gen = FpnAnchorGenerator(ANCHOR_CFG)
+    anchors = np.concatenate([gen.generate_anchors((hw[0], hw[1], 3), l) for l in ANCHOR_CFG["layers"]])
+    sample = {constants.IMAGE_NORMALIZED_KEY: synthetic.make_frames(1, hw[0], hw[1], seed=2),
+              constants.ANCHORS_KEY: anchors[None],
+              constants.ORIGINAL_IM_SIZE_KEY: np.array([[hw[0], hw[1], 3]])}
+    counts, means, covs, nms_idx, iou = inference_utils.bayes_od_inference(
+        model, sample, BAYES_CFG, NMS_CFG, use_full_covar=True, dataset_name="bdd", seed=3, image_id=0)
+    m = counts.shape[0]
+    assert counts.shape == (m, 8) and means.shape == (m, 4, 1) and covs.shape == (m, 4, 4)
+    assert iou.shape == (m, m) and nms_idx.ndim == 1 and len(nms_idx) <= 100 and m > 0
+    out_cls, out_means, out_covs, out_counts = inference_utils.bayes_od_clustering(
+        counts, means, covs, nms_idx, iou, affinity_threshold=NMS_CFG["iou_threshold"],
+        engine=model._last_engine)
+    k = len(nms_idx)
+    assert out_cls.shape == (k, 8) and out_means.shape == (k, 4, 1) and out_covs.shape == (k, 4, 4)
+    assert np.allclose(out_cls.sum(1), 1.0, atol=1e-5)
+    boxes = box_utils.vuhw_to_vuvu_np(np.squeeze(out_means, axis=2))
+    assert boxes.shape == (k, 4)
+    # prediction dict of the plain model call (constants.py:61-63)
+    pred = model(sample[constants.IMAGE_NORMALIZED_KEY], train_val_test="testing", seed=3, image_id=0)
+    assert pred[constants.ANCHORS_CLASS_PREDICTIONS_KEY].shape == (5, anchors.shape[0], 8)
+    assert pred[constants.ANCHORS_BOX_PREDICTIONS_KEY].shape == (5, anchors.shape[0], 4)
+    assert pred[constants.ANCHORS_COVAR_PREDICTIONS_KEY].shape == (5, anchors.shape[0], 4, 4)
+    with pytest.raises(ValueError):
+        model.mc_dropout_samples = 1
+        inference_utils.bayes_od_inference(model, sample, BAYES_CFG, NMS_CFG)
