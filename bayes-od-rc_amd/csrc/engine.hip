@@ -976,6 +976,25 @@ bod_status bod_get_detections(bod_handle h, int32_t img, int32_t* num, float* sc
     return BOD_OK;
 }
 
+bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, float* means, float* covs, float* counts) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_cluster_fuse has not run");
+    const size_t BK = (size_t)h->cfg.batch * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
+    BODCHK(d2h(h, num, h->nms_nsel, (size_t)h->cfg.batch));
+    BODCHK(d2h(h, scores, h->out_scores, BK * C));
+    BODCHK(d2h(h, means, h->out_means, BK * 4));
+    BODCHK(d2h(h, covs, h->out_covs, BK * 16));
+    BODCHK(d2h(h, counts, h->out_counts, BK * C));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_device_detections(bod_handle h, void** p) {
+    if (!h || !p) return BOD_ERR_INVALID_ARG;
+    p[0] = h->nms_nsel; p[1] = h->out_scores; p[2] = h->out_means; p[3] = h->out_covs; p[4] = h->out_counts;
+    return BOD_OK;
+}
+
 bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
     if (!h) return BOD_ERR_INVALID_ARG;
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");

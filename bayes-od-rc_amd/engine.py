@@ -221,6 +221,25 @@ class Engine(object):
         n = n.value
         return scores[:n].copy(), means[:n].copy(), covs[:n].copy(), counts[:n].copy()
 
+    def get_detections_batch(self, out=None):
+        """One D2H per array for the whole batch. Returns dict of padded arrays + 'num' [B]."""
+        b, k, c = self.B, self.K, self.Ccls
+        if out is None:
+            out = {"num": np.empty(b, np.int32), "scores": np.empty((b, k, c), np.float32),
+                   "means": np.empty((b, k, 4), np.float32), "covs": np.empty((b, k, 4, 4), np.float32),
+                   "counts": np.empty((b, k, c), np.float32)}
+        self._chk(self.lib.bod_get_detections_batch(self.h, iptr(out["num"]), fptr(out["scores"]),
+                                                    fptr(out["means"]), fptr(out["covs"]), fptr(out["counts"])))
+        return out
+
+    def device_detection_pointers(self):
+        ptrs = (C.c_void_p * 5)()
+        self._chk(self.lib.bod_device_detections(self.h, ptrs))
+        b, k, c = self.B, self.K, self.Ccls
+        shapes = [(b,), (b, k, c), (b, k, 4), (b, k, 16), (b, k, c)]
+        names = ["num", "scores", "means", "covs", "counts"]
+        return {n: (int(p), s) for n, p, s in zip(names, ptrs, shapes)}
+
     # ------------------------------------------------------------------ measurement
     def profile_begin(self):
         self._chk(self.lib.bod_profile_begin(self.h))

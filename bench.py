@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the BayesOD inference hot path at N=10 MC samples on
+512x512 BDD-shape synthetic frames (BASELINE.json `metric`, config[2]).
+
+A "step" = one pass of the whole hot path (RetinaNet forward -> MC posterior -> soft-NMS ->
+cluster-and-fuse -> detections on the host) over one batch of frames that is already resident in
+HBM.  One process per GPU; frames are sharded across ranks (weak scaling: fixed per-GPU batch); the
+only inter-GPU traffic is one RCCL gather of the final detection records per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+ANCHOR_CFG = {"layers": [3, 4, 5, 6, 7], "aspect_ratios": [[1.0, 1.0], [1.0, 2.0], [2.0, 1.0]],
+              "scales": [1.0, 1.26, 1.59]}
+BAYES_CFG = {"ranking_method": "score", "dirichlet_prior": {"type": "non_informative"},
+             "gaussian_prior": {"type": "isotropic", "isotropic_variance": 100000.0}}
+NMS_CFG = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# cls foreground bias calibrated so that 500 <= M <= 1500 anchors survive the background filter
+# at 512x512 with synthetic.make_weights() (python bench.py --calibrate)
+CALIBRATED_FG_BIAS = -2.775
+
+
+def head_flops_per_image(P, N, dedup=True):
+    conv = 2.0 * P * 256 * 2304
+    if dedup:
+        return 3 * conv + N * 8 * conv
+    return N * 11 * conv
+
+
+def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0):
+    """Reference-literal CPU timing with the oracle (kind='port'): PyTorch-CPU fp32 forward
+    (oracle/torch_ref.py) + NumPy posterior / soft-NMS / clustering, all host cores."""
+    import torch
+    from oracle import bayes_od, clustering, geometry, network, nms, philox, torch_ref
+    tw = torch_ref.prepare(weights)
+    # big hosts lose to thread oversubscription on these small convs: probe a few pool sizes on one
+    # head-tower conv and keep the fastest
+    import torch.nn.functional as F
+    ncpu = os.cpu_count() or 1
+    probe_x = torch.randn(n, 256, hw[0] // 8, hw[1] // 8)
+    best = (float("inf"), 1)
+    for cand in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(cand)
+        with torch.no_grad():
+            F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
+            t0 = time.perf_counter()
+            F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
+            dt = time.perf_counter() - t0
+        if dt < best[0]:
+            best = (dt, cand)
+    threads = best[1]
+    torch.set_num_threads(threads)
+    done, t_total = 0, 0.0
+    parts = {"forward": 0.0, "posterior": 0.0, "nms": 0.0, "cluster": 0.0}
+    while done < len(frames) and (done == 0 or t_total < seconds_budget):
+        t0 = time.perf_counter()
+        out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw)
+        t1 = time.perf_counter()
+        u = philox.categorical_uniforms(0, done, anchors.shape[0])
+        post = bayes_od.bayes_od_posterior(out, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float32)
+        t2 = time.perf_counter()
+        corners = post["corners"].astype(np.float32)
+        idx, _ = nms.soft_nms(corners, post["ranking"], 100, 0.5, 0.5)
+        t3 = time.perf_counter()
+        if len(idx):
+            iou = geometry.bbox_iou_vuvu(corners, corners)
+            clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, iou, 0.5)
+        t4 = time.perf_counter()
+        parts["forward"] += t1 - t0; parts["posterior"] += t2 - t1
+        parts["nms"] += t3 - t2; parts["cluster"] += t4 - t3
+        t_total += t4 - t0
+        done += 1
+    return {"value": done / t_total, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d frame(s) of %dx%d at N=%d, reference-literal (11*N head convs, no dedup), "
+                      "torch %s fp32 CPU forward + NumPy Bayesian stages; seconds: %s" %
+                      (done, hw[0], hw[1], n, torch.__version__,
+                       {k: round(v, 2) for k, v in parts.items()})}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--mc", type=int, default=10)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate", action="store_true", help="print the cls foreground bias for M~1000")
+    ap.add_argument("--fg-bias", type=float, default=CALIBRATED_FG_BIAS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd import distributed as bdist
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    hw, n, B = (args.height, args.width), args.mc, args.batch
+    weights = synthetic.make_weights(cls_fg_bias=args.fg_bias)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    eng = Engine(make_config(hw, batch=B, mc_samples=n, device=local_rank, bayes_od_config=BAYES_CFG,
+                             nms_config=NMS_CFG, use_full_covar=True))
+    eng.load_weights(weights)
+    eng.set_anchors(anchors)
+    # this rank's shard of a (world*B)-frame synthetic clip, resident in HBM before timing starts
+    lo, hi = bdist.shard_range(world * B, world, rank)
+    frames = synthetic.make_frames(hi - lo, hw[0], hw[1], seed=lo)
+    eng.upload_images(frames)
+
+    if args.calibrate:
+        eng.forward(None, seed=0, first_image_id=lo)
+        cls = eng.get_raw()[0]
+        print("calibrated cls foreground bias:", synthetic.calibrate_fg_bias(cls[0], args.fg_bias))
+        return
+
+    views = bdist.torch_views(eng) if world > 1 else None
+    host_out = None
+    C = eng.Ccls
+
+    def step(i):
+        nonlocal host_out
+        eng.infer(None, seed=0, first_image_id=lo + i * world * B)
+        if world > 1:
+            eng.synchronize()
+            rec = bdist.pack_records(views["num"], views["scores"], views["means"], views["covs"], views["counts"])
+            allrec = bdist.gather_records(rec, dst=0)
+            if rank == 0:
+                host_out = allrec.cpu()
+        else:
+            host_out = eng.get_detections_batch(host_out)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_images = world * B * args.steps
+    value = total_images / elapsed
+    kept = eng.num_kept()
+
+    # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM), HIP events on the engine's stream
+    prof_steps = max(1, min(3, args.steps))
+    eng.profile_begin()
+    for i in range(prof_steps):
+        eng.infer(None, seed=0, first_image_id=lo + i * world * B)
+    prof = eng.profile_end()
+    launches = max(1, prof["head_conv_launches"])
+    # algorithmic FLOPs: de-duplicated head convs = exactly what the 4 launches/step issue
+    algo_flops = head_flops_per_image(eng.P, n) * B * prof_steps
+    assert abs(algo_flops - prof["head_conv_flops"]) / algo_flops < 1e-6
+    achieved = algo_flops / (prof["head_conv_ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (head 3x3 256->256 towers)",
+                "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(prof["head_conv_ms"] / launches, 4), "launches_per_step": launches // prof_steps,
+                "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
+    post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
+
+    out = {"metric": "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency",
+           "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic",
+           "config": {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, full BayesOD "
+                                  "pipeline (forward+posterior+soft-NMS+cluster-fuse)" % (n, hw[0], hw[1]),
+                      "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
+                      "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
+                      "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
+                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4)},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(hw, n, frames, weights, anchors)
+        out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,16 @@ bod_status bod_cluster_fuse(bod_handle h);
 bod_status bod_get_detections(bod_handle h, int32_t image_index, int32_t* num_detections,
                               float* scores, float* means, float* covs, float* counts);
 
+/* All images of the batch in one call (one device->host copy per array, one sync):
+ * num_detections [batch]; scores/counts [batch,max_detections,C]; means [batch,max_detections,4];
+ * covs [batch,max_detections,16]; rows >= num_detections[b] are unspecified. NULLs skipped. */
+bod_status bod_get_detections_batch(bod_handle h, int32_t* num_detections, float* scores, float* means,
+                                    float* covs, float* counts);
+/* Device addresses of the same five arrays (order: num, scores, means, covs, counts) for
+ * zero-copy hand-off to a collective library (the RCCL gather of SURVEY.md section 8e). Valid
+ * until bod_destroy; contents are defined after bod_cluster_fuse/bod_infer + bod_synchronize. */
+bod_status bod_device_detections(bod_handle h, void** ptrs5);
+
 /* The whole per-image body of run_inference.test_model's loop (:137-149) for `batch` images:
  * forward -> posterior -> nms -> cluster_fuse, one stream, no host round trip. */
 bod_status bod_infer(bod_handle h, const float* images, int32_t images_on_device,
