@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace results .db (rocpd sqlite) into the text table committed
+under profiles/.   usage: rocprof_summary.py results.db "header line" > profiles/xxx.txt"""
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+cur = con.cursor()
+rows = cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
+                   "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+for line in sys.argv[2:]:
+    print("# " + line)
+print("%-72s %6s %12s %7s %10s %10s %10s" % ("kernel", "calls", "total_ms", "pct", "avg_us", "min_us", "max_us"))
+for r in rows:
+    print("%-72s %6d %12.3f %6.1f%% %10.1f %10.1f %10.1f" % (r[0][:72], r[1], r[2], 100 * r[2] / tot, r[3], r[4], r[5]))
+print()
+print("# largest launches by grid (the head-tower 3x3 convs are the grid.z>=2 conv_igemm launches):")
+rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), avg(end-start)/1e3, vgpr_count, "
+                   "accum_vgpr_count, lds_size from kernels group by name, grid_x, grid_y, grid_z "
+                   "order by 7 desc limit 10").fetchall()
+for r in rows:
+    print("%-48s grid=(%d,%d,%d) wg=%d calls=%d avg_us=%.1f vgpr=%s agpr=%s lds=%s" % ((r[0][:48],) + tuple(r[1:])))
