@@ -63,8 +63,10 @@ SIGNATURES = {
     "bod_cluster_fuse": (C.c_int, [_H]),
     "bod_get_detections": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
     "bod_get_detections_batch": (C.c_int, [_H, _I, _F, _F, _F, _F]),
-    "bod_device_detections": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "bod_device_detections": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),
     "bod_infer": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32]),
+    "bod_infer_async": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32, _I]),
+    "bod_collect": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
     "bod_upload_images": (C.c_int, [_H, _F]),
     "bod_device_images": (C.c_void_p, [_H]),
     "bod_synchronize": (C.c_int, [_H]),

@@ -11,69 +11,103 @@ __device__ __forceinline__ uint32_t f32_to_bf16_a(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32_a(uint32_t v) { return __uint_as_float(v << 16); }
 
-// Block: 4 output rows x 32 output cols x 64 channels. thread: co = tid&63, row = tid>>6.
-// LDS: weights [7][7][3][64] fp32 (37.6 KB) + input patch [13][69*3] fp32 (10.8 KB).
-constexpr int ST_TR = 4, ST_TC = 32, ST_PR = ST_TR * 2 + 5, ST_PC = ST_TC * 2 + 5;
+// Stem as an exact-fp32 implicit GEMM on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate, bitwise an
+// fmaf chain): D[cout 64][pixel] with K ordered (ky, kx*3+ci) and each ky row padded 21 -> 24, so the
+// B operand of one k-step is 4 CONSECUTIVE floats of an input row.  Each wave keeps ALL weights as
+// MFMA A fragments in registers (42 k-steps x 4 cout fragments = 168 VGPRs, one wave per SIMD, 4
+// independent accumulators = the f32 MFMA issue rate) and the block walks (image,row,64-pixel
+// segment) tasks persistently; the 7 x 133 x 3 input patch of the next task is prefetched into the
+// other LDS buffer while the current one is multiplied.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int ST_SEG = 64;                      // output pixels per task (4 waves x 16)
+constexpr int ST_ROWF = 2 * ST_SEG * 3 + 5 * 3 + 5;   // 404 floats: (2*63+7) pixels * 3 ch = 399, + the 3 zero-weight k slots, padded
+constexpr int ST_KSTEPS = 42;                   // 7 rows x 24 (21 real + 3 zero) / 4
 
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img,
-                                                        const float* __restrict__ w,
-                                                        const float* __restrict__ bias,
-                                                        uint16_t* __restrict__ out,
-                                                        int H, int W, int oh, int ow) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sw = reinterpret_cast<float*>(smem);               // 7*7*3*64
-    float* sp = sw + 7 * 7 * 3 * 64;                          // ST_PR * ST_PC * 3
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int oy0 = blockIdx.y * ST_TR, ox0 = blockIdx.x * ST_TC;
-    for (int i = tid; i < 7 * 7 * 3 * 64; i += 256) sw[i] = w[i];
-    const float* im = img + (size_t)b * H * W * 3;
-    const int iy0 = oy0 * 2, ix0 = ox0 * 2;
-    for (int i = tid; i < ST_PR * ST_PC * 3; i += 256) {
-        const int r = i / (ST_PC * 3), c = i % (ST_PC * 3);
-        const int iy = iy0 + r, ixc = ix0 * 3 + c;
-        sp[i] = (iy < H && ixc < W * 3) ? im[(size_t)iy * W * 3 + ixc] : 0.f;
+__global__ __launch_bounds__(256, 1) void stem_conv_kernel(const float* __restrict__ img,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           uint16_t* __restrict__ out,
+                                                           int B, int H, int W, int oh, int ow) {
+    __shared__ float patch[2][7][ST_ROWF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    // A fragments: a[s][f] = W[k = s*4+lq][cout = f*16+li], k -> (ky = s/6, t = (s%6)*4+lq), zero for t >= 21
+    float a[ST_KSTEPS][4];
+#pragma unroll
+    for (int s = 0; s < ST_KSTEPS; ++s) {
+        const int ky = s / 6, t = (s % 6) * 4 + lq;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) a[s][f] = t < 21 ? w[(ky * 21 + t) * 64 + f * 16 + li] : 0.f;
     }
+    float bv[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[f][r] = bias[f * 16 + lq * 4 + r];
+
+    const int segs = (ow + ST_SEG - 1) / ST_SEG;
+    const int ntasks = B * oh * segs;
+    constexpr int ST_PER = (7 * ST_ROWF + 255) / 256;          // staged floats per thread
+    float stage[ST_PER];
+    auto fetch = [&](int task) {                               // global -> registers (in flight during the MFMAs)
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        const float* src = img + ((size_t)b * H + 2 * oy) * W * 3 + (size_t)seg * ST_SEG * 2 * 3;
+        const int valid = W * 3 - seg * ST_SEG * 2 * 3;           // floats left in the row
+#pragma unroll
+        for (int q = 0; q < ST_PER; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / ST_ROWF, c = i % ST_ROWF;
+            stage[q] = (i < 7 * ST_ROWF && c < valid) ? src[(size_t)r * W * 3 + c] : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {                               // registers -> LDS
+#pragma unroll
+        for (int q = 0; q < ST_PER; ++q) {
+            const int i = tid + q * 256;
+            if (i < 7 * ST_ROWF) (&patch[buf][0][0])[i] = stage[q];
+        }
+    };
+    int task = blockIdx.x, buf = 0;
+    if (task < ntasks) { fetch(task); commit(0); }
     __syncthreads();
-    const int co = tid & 63, row = tid >> 6;
-    const int oy = oy0 + row;
-    const float bv = bias[co];
-    for (int seg = 0; seg < ST_TC / 8; ++seg) {
-        float acc[8];
+    for (; task < ntasks; task += gridDim.x, buf ^= 1) {
+        const int nxt = task + gridDim.x;
+        if (nxt < ntasks) fetch(nxt);
+        f32x4_t acc[4];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) acc[p] = 0.f;
-        for (int ky = 0; ky < 7; ++ky) {
-            const float* prow = sp + (row * 2 + ky) * (ST_PC * 3) + seg * 16 * 3;
+        for (int f = 0; f < 4; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // B operand: lane (pixel li of this wave's 16, k offset lq): patch[ky][(wave*16+li)*6 + t]
+        const float* pb = &patch[buf][0][(wave * 16 + li) * 6 + lq];
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                float in[21];
+        for (int s = 0; s < ST_KSTEPS; ++s) {
+            const float bq = pb[(s / 6) * ST_ROWF + (s % 6) * 4];
 #pragma unroll
-                for (int t = 0; t < 21; ++t) in[t] = prow[t * 3 + ci];
+            for (int f = 0; f < 4; ++f)
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][f], bq, acc[f], 0, 0, 0);
+        }
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        const int ox = seg * ST_SEG + wave * 16 + li;
+        if (ox < ow) {
+            uint16_t* o = out + (((size_t)b * oh + oy) * ow + ox) * 64 + lq * 4;
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const float wv = sw[((ky * 7 + kx) * 3 + ci) * 64 + co];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) acc[p] = fmaf(in[2 * p + kx], wv, acc[p]);
-                }
+            for (int f = 0; f < 4; ++f) {
+                uint2 pk;
+                pk.x = f32_to_bf16_a(fmaxf(acc[f][0] + bv[f][0], 0.f)) | (f32_to_bf16_a(fmaxf(acc[f][1] + bv[f][1], 0.f)) << 16);
+                pk.y = f32_to_bf16_a(fmaxf(acc[f][2] + bv[f][2], 0.f)) | (f32_to_bf16_a(fmaxf(acc[f][3] + bv[f][3], 0.f)) << 16);
+                *reinterpret_cast<uint2*>(o + f * 16) = pk;
             }
         }
-        if (oy < oh) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int ox = ox0 + seg * 8 + p;
-                if (ox < ow)
-                    out[(((size_t)b * oh + oy) * ow + ox) * 64 + co] =
-                        (uint16_t)f32_to_bf16_a(fmaxf(acc[p] + bv, 0.f));
-            }
-        }
+        if (nxt < ntasks) commit(buf ^ 1);
+        __syncthreads();
     }
 }
 
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, uint16_t* out,
                             int B, int H, int W, int oh, int ow, hipStream_t s) {
-    const size_t lds = (7 * 7 * 3 * 64 + ST_PR * ST_PC * 3) * sizeof(float);
-    dim3 grid((ow + ST_TC - 1) / ST_TC, (oh + ST_TR - 1) / ST_TR, B);
-    hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), lds, s, img, w, bias, out, H, W, oh, ow);
+    const int segs = (ow + ST_SEG - 1) / ST_SEG;
+    const int ntasks = B * oh * segs;
+    const int grid = ntasks < 1024 ? ntasks : 1024;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
     return hipGetLastError();
 }
 

@@ -83,8 +83,24 @@ struct bod_context {
     // post
     float* d_anchors = nullptr;
     PostBuffers pb{};
-    float* nms_scores = nullptr; int32_t* nms_begin = nullptr; int32_t* nms_sel = nullptr; int32_t* nms_nsel = nullptr;
+    float* nms_scores = nullptr; int32_t* nms_begin = nullptr;
+    // detection records are double-buffered ("slots") so the latency-bound NMS + cluster-fuse of one
+    // batch can run on a side stream underneath the next batch's convolutions
+    int32_t* nms_sel_s[2] = {nullptr, nullptr}; int32_t* nms_nsel_s[2] = {nullptr, nullptr};
+    float* out_scores_s[2] = {nullptr, nullptr}; float* out_means_s[2] = {nullptr, nullptr};
+    float* out_covs_s[2] = {nullptr, nullptr}; float* out_counts_s[2] = {nullptr, nullptr};
+    int32_t* nms_sel = nullptr; int32_t* nms_nsel = nullptr;          // = current slot
     float* out_scores = nullptr; float* out_means = nullptr; float* out_covs = nullptr; float* out_counts = nullptr;
+    int slot = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_posterior = nullptr; hipEvent_t ev_done[2] = {nullptr, nullptr};
+    bool side_pending[2] = {false, false};
+    void select_slot(int sidx) {
+        slot = sidx;
+        nms_sel = nms_sel_s[sidx]; nms_nsel = nms_nsel_s[sidx];
+        out_scores = out_scores_s[sidx]; out_means = out_means_s[sidx];
+        out_covs = out_covs_s[sidx]; out_counts = out_counts_s[sidx];
+    }
     float* iou_scratch = nullptr; int64_t iou_cap = 0;
 
     // profiling
@@ -531,12 +547,15 @@ bod_status alloc_post(bod_context* h) {
     BODCHK(h->dalloc(&h->nms_scores, BA));
     BODCHK(h->dalloc(&h->nms_begin, BA));
     const size_t BK = (size_t)c.batch * c.nms_max_output_size;
-    BODCHK(h->dalloc(&h->nms_sel, BK));
-    BODCHK(h->dalloc(&h->nms_nsel, (size_t)c.batch));
-    BODCHK(h->dalloc(&h->out_scores, BK * c.num_classes));
-    BODCHK(h->dalloc(&h->out_means, BK * 4));
-    BODCHK(h->dalloc(&h->out_covs, BK * 16));
-    BODCHK(h->dalloc(&h->out_counts, BK * c.num_classes));
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        BODCHK(h->dalloc(&h->nms_sel_s[sidx], BK));
+        BODCHK(h->dalloc(&h->nms_nsel_s[sidx], (size_t)c.batch));
+        BODCHK(h->dalloc(&h->out_scores_s[sidx], BK * c.num_classes));
+        BODCHK(h->dalloc(&h->out_means_s[sidx], BK * 4));
+        BODCHK(h->dalloc(&h->out_covs_s[sidx], BK * 16));
+        BODCHK(h->dalloc(&h->out_counts_s[sidx], BK * c.num_classes));
+    }
+    h->select_slot(0);
     BODCHK(h->dalloc(&h->d_images, (size_t)c.batch * c.image_h * c.image_w * 3));
     return BOD_OK;
 }
@@ -589,6 +608,8 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
 
 bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
     if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
+    for (int sidx = 0; sidx < 2; ++sidx)
+        if (h->side_pending[sidx]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[sidx], 0));
     PostCfg pc = post_cfg(h, seed, first_image);
     PostBuffers pb = h->pb;
     pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
@@ -605,18 +626,18 @@ bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
     return BOD_OK;
 }
 
-bod_status run_nms(bod_context* h) {
+bod_status run_nms(bod_context* h, hipStream_t st) {
     const bod_config& c = h->cfg;
     NmsArgs a{};
     a.B = c.batch; a.A = h->A; a.num_kept = h->pb.num_kept; a.corners = h->pb.corners; a.ranking = h->pb.ranking;
     a.work_scores = h->nms_scores; a.work_begin = h->nms_begin; a.selected = h->nms_sel; a.num_selected = h->nms_nsel;
     a.max_out = c.nms_max_output_size; a.iou_thr = c.nms_iou_threshold; a.sigma = c.nms_soft_sigma; a.variant = c.nms_variant;
-    HIPCHK(h, launch_nms(a, h->stream));
+    HIPCHK(h, launch_nms(a, st));
     h->nms_done = true; h->cluster_done = false;
     return BOD_OK;
 }
 
-bod_status run_cluster(bod_context* h) {
+bod_status run_cluster(bod_context* h, hipStream_t st) {
     const bod_config& c = h->cfg;
     ClusterArgs a{};
     a.B = c.batch; a.A = h->A; a.C = c.num_classes; a.max_out = c.nms_max_output_size;
@@ -624,7 +645,7 @@ bod_status run_cluster(bod_context* h) {
     a.corners = h->pb.corners; a.counts = h->pb.counts; a.means = h->pb.means; a.covs = h->pb.covs;
     a.thr = c.nms_iou_threshold;
     a.out_scores = h->out_scores; a.out_means = h->out_means; a.out_covs = h->out_covs; a.out_counts = h->out_counts;
-    HIPCHK(h, launch_cluster_fuse(a, h->stream));
+    HIPCHK(h, launch_cluster_fuse(a, st));
     h->cluster_done = true;
     return BOD_OK;
 }
@@ -680,6 +701,11 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreateWithFlags(&h->ev_posterior, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_done[1], hipEventDisableTiming) != hipSuccess)
+        return bail(h->fail(BOD_ERR_HIP, "hipEventCreate failed"));
     bod_status s = build_geometry(h.get());
     if (s != BOD_OK) return bail(s);
     if ((int64_t)c.batch * c.mc_samples * h->Ppad >= (1LL << 31))
@@ -694,6 +720,9 @@ bod_status bod_destroy(bod_handle h) {
     if (!h) return BOD_OK;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->ev_posterior) hipEventDestroy(h->ev_posterior);
+    for (int sidx = 0; sidx < 2; ++sidx) if (h->ev_done[sidx]) hipEventDestroy(h->ev_done[sidx]);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -778,6 +807,8 @@ const float* bod_device_images(bod_handle h) { return h ? h->d_images : nullptr;
 bod_status bod_synchronize(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->side));
+    h->side_pending[0] = h->side_pending[1] = false;
     return BOD_OK;
 }
 
@@ -903,7 +934,7 @@ bod_status bod_nms(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    return run_nms(h);
+    return run_nms(h, h->stream);
 }
 
 bod_status bod_get_nms(bod_handle h, int32_t img, int32_t* indices, int32_t* num) {
@@ -958,7 +989,7 @@ bod_status bod_cluster_fuse(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
     if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    return run_cluster(h);
+    return run_cluster(h, h->stream);
 }
 
 bod_status bod_get_detections(bod_handle h, int32_t img, int32_t* num, float* scores, float* means, float* covs, float* counts) {
@@ -989,9 +1020,10 @@ bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, f
     return BOD_OK;
 }
 
-bod_status bod_device_detections(bod_handle h, void** p) {
-    if (!h || !p) return BOD_ERR_INVALID_ARG;
-    p[0] = h->nms_nsel; p[1] = h->out_scores; p[2] = h->out_means; p[3] = h->out_covs; p[4] = h->out_counts;
+bod_status bod_device_detections(bod_handle h, int32_t sidx, void** p) {
+    if (!h || !p || sidx < 0 || sidx > 1) return BOD_ERR_INVALID_ARG;
+    p[0] = h->nms_nsel_s[sidx]; p[1] = h->out_scores_s[sidx]; p[2] = h->out_means_s[sidx];
+    p[3] = h->out_covs_s[sidx]; p[4] = h->out_counts_s[sidx];
     return BOD_OK;
 }
 
@@ -1004,8 +1036,49 @@ bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint6
     BODCHK(stage_images(h, images, on_device, &dev));
     BODCHK(run_forward(h, dev, seed, first_image_id));
     BODCHK(run_posterior(h, seed, first_image_id));
-    BODCHK(run_nms(h));
-    return run_cluster(h);
+    BODCHK(run_nms(h, h->stream));
+    return run_cluster(h, h->stream);
+}
+
+bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id, int32_t* slot_out) {
+    if (!h || !slot_out) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
+    if (h->cfg.mc_samples < 2) return h->fail(BOD_ERR_INVALID_ARG, "bayes_od needs mc_samples >= 2 (sample covariance divides by N-1)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int sidx = h->slot ^ 1;
+    if (h->side_pending[sidx])
+        return h->fail(BOD_ERR_NOT_READY, "slot %d still holds uncollected detections: call bod_collect first", sidx);
+    const float* dev = nullptr;
+    BODCHK(stage_images(h, images, on_device, &dev));
+    BODCHK(run_forward(h, dev, seed, first_image_id));
+    BODCHK(run_posterior(h, seed, first_image_id));           // waits for the side stream's previous readers
+    HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
+    h->select_slot(sidx);
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
+    BODCHK(run_nms(h, h->side));
+    BODCHK(run_cluster(h, h->side));
+    HIPCHK(h, hipEventRecord(h->ev_done[sidx], h->side));
+    h->side_pending[sidx] = true;
+    *slot_out = sidx;
+    return BOD_OK;
+}
+
+bod_status bod_collect(bod_handle h, int32_t sidx, int32_t* num, float* scores, float* means, float* covs, float* counts) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (sidx < 0 || sidx > 1 || !h->side_pending[sidx]) return h->fail(BOD_ERR_NOT_READY, "slot %d has no pending batch", sidx);
+    const size_t BK = (size_t)h->cfg.batch * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
+    hipStream_t st = h->side;
+    auto cp = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
+    HIPCHK(h, cp(num, h->nms_nsel_s[sidx], (size_t)h->cfg.batch * 4));
+    HIPCHK(h, cp(scores, h->out_scores_s[sidx], BK * C * 4));
+    HIPCHK(h, cp(means, h->out_means_s[sidx], BK * 16));
+    HIPCHK(h, cp(covs, h->out_covs_s[sidx], BK * 64));
+    HIPCHK(h, cp(counts, h->out_counts_s[sidx], BK * C * 4));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->side_pending[sidx] = false;
+    return BOD_OK;
 }
 
 bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,

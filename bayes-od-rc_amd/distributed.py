@@ -67,9 +67,9 @@ class DeviceArray(object):
                                          "data": (int(ptr), False), "version": 2}
 
 
-def torch_views(engine):
-    """torch tensors aliasing the engine's detection buffers on its GPU."""
-    p = engine.device_detection_pointers()
+def torch_views(engine, slot=0):
+    """torch tensors aliasing the engine's detection buffers (record slot 0/1) on its GPU."""
+    p = engine.device_detection_pointers(slot)
     dev = torch.device("cuda", engine.cfg.device)
     views = {}
     for name, (ptr, shape) in p.items():

@@ -134,6 +134,27 @@ class Engine(object):
             a = self._img(images)
             self._chk(self.lib.bod_infer(self.h, a.ctypes.data, 0, seed, first_image_id))
 
+    def infer_async(self, images=None, seed=0, first_image_id=0):
+        """Enqueue a whole pass; returns the slot ticket for collect()."""
+        slot = C.c_int32(-1)
+        if images is None:
+            ptr = self.lib.bod_device_images(self.h)
+            self._chk(self.lib.bod_infer_async(self.h, ptr, 1, seed, first_image_id, C.byref(slot)))
+        else:
+            a = self._img(images)
+            self._chk(self.lib.bod_infer_async(self.h, a.ctypes.data, 0, seed, first_image_id, C.byref(slot)))
+        return slot.value
+
+    def collect(self, slot, out=None):
+        b, k, c = self.B, self.K, self.Ccls
+        if out is None:
+            out = {"num": np.empty(b, np.int32), "scores": np.empty((b, k, c), np.float32),
+                   "means": np.empty((b, k, 4), np.float32), "covs": np.empty((b, k, 4, 4), np.float32),
+                   "counts": np.empty((b, k, c), np.float32)}
+        self._chk(self.lib.bod_collect(self.h, slot, iptr(out["num"]), fptr(out["scores"]), fptr(out["means"]),
+                                       fptr(out["covs"]), fptr(out["counts"])))
+        return out
+
     def synchronize(self):
         self._chk(self.lib.bod_synchronize(self.h))
 
@@ -232,9 +253,13 @@ class Engine(object):
                                                     fptr(out["means"]), fptr(out["covs"]), fptr(out["counts"])))
         return out
 
-    def device_detection_pointers(self):
+    def wait_slot(self, slot):
+        """Block until the batch in ``slot`` is complete without copying anything."""
+        self._chk(self.lib.bod_collect(self.h, slot, None, None, None, None, None))
+
+    def device_detection_pointers(self, slot=0):
         ptrs = (C.c_void_p * 5)()
-        self._chk(self.lib.bod_device_detections(self.h, ptrs))
+        self._chk(self.lib.bod_device_detections(self.h, slot, ptrs))
         b, k, c = self.B, self.K, self.Ccls
         shapes = [(b,), (b, k, c), (b, k, 4), (b, k, 16), (b, k, c)]
         names = ["num", "scores", "means", "covs", "counts"]

@@ -145,15 +145,27 @@ bod_status bod_get_detections(bod_handle h, int32_t image_index, int32_t* num_de
  * covs [batch,max_detections,16]; rows >= num_detections[b] are unspecified. NULLs skipped. */
 bod_status bod_get_detections_batch(bod_handle h, int32_t* num_detections, float* scores, float* means,
                                     float* covs, float* counts);
-/* Device addresses of the same five arrays (order: num, scores, means, covs, counts) for
- * zero-copy hand-off to a collective library (the RCCL gather of SURVEY.md section 8e). Valid
- * until bod_destroy; contents are defined after bod_cluster_fuse/bod_infer + bod_synchronize. */
-bod_status bod_device_detections(bod_handle h, void** ptrs5);
+/* Device addresses of the same five arrays of record slot 0/1 (order: num, scores, means, covs,
+ * counts) for zero-copy hand-off to a collective library (the RCCL gather of SURVEY.md section
+ * 8e).  Valid until bod_destroy; contents are defined once the batch that filled the slot has
+ * completed (bod_synchronize, or bod_collect with NULL destinations). Synchronous calls use slot 0
+ * until the first bod_infer_async. */
+bod_status bod_device_detections(bod_handle h, int32_t slot, void** ptrs5);
 
 /* The whole per-image body of run_inference.test_model's loop (:137-149) for `batch` images:
  * forward -> posterior -> nms -> cluster_fuse, one stream, no host round trip. */
 bod_status bod_infer(bod_handle h, const float* images, int32_t images_on_device,
                      uint64_t seed, uint32_t first_image_id);
+
+/* Pipelined form for sustained throughput: enqueue the whole pass and return at once.  The
+ * latency-bound soft-NMS + cluster-fuse of this batch run on a side stream underneath the next
+ * batch's convolutions; detection records are double-buffered ("slots").  *slot receives the
+ * ticket to pass to bod_collect, which waits for that batch and copies its padded records
+ * (layout as bod_get_detections_batch).  At most two batches may be in flight. */
+bod_status bod_infer_async(bod_handle h, const float* images, int32_t images_on_device,
+                           uint64_t seed, uint32_t first_image_id, int32_t* slot);
+bod_status bod_collect(bod_handle h, int32_t slot, int32_t* num_detections, float* scores,
+                       float* means, float* covs, float* counts);
 
 /* Device buffer of [batch,H,W,3] fp32 owned by the handle (fill with bod_upload_images, then
  * pass to bod_forward/bod_infer with images_on_device=1). */
