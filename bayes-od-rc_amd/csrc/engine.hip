@@ -1187,6 +1187,29 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     return done(run());
 }
 
+bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters, double* mean_ms, double* flops) {
+    if (!h || !mean_ms || iters < 1 || layer < 0 || layer > 3) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int seen = 0; Op* op = nullptr;
+    for (Op& o : h->ops) if (o.is_head3x3 && seen++ == layer) { op = &o; break; }
+    if (!op) return h->fail(BOD_ERR_INVALID_ARG, "no head layer %d", layer);
+    ConvArgs a = op->conv;
+    a.variant = variant;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, launch_conv_igemm(a, h->stream));            // warm-up
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv_igemm(a, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *mean_ms = ms / iters;
+    if (flops) *flops = op->flops;
+    return BOD_OK;
+}
+
 bod_status bod_profile_begin(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }

@@ -53,6 +53,7 @@ struct ConvArgs {
     float drop_scale;
     uint32_t image_base;   // global id of image 0 of the batch
     int32_t groups;
+    int32_t variant;       // 0 = production kernel; >0 = ablation / experimental builds (tests/tools)
 };
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);

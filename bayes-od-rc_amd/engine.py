@@ -265,6 +265,11 @@ class Engine(object):
         names = ["num", "scores", "means", "covs", "counts"]
         return {n: (int(p), s) for n, p, s in zip(names, ptrs, shapes)}
 
+    def bench_head_conv(self, layer=1, variant=0, iters=10):
+        ms, fl = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.bod_bench_head_conv(self.h, layer, variant, iters, C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value
+
     # ------------------------------------------------------------------ measurement
     def profile_begin(self):
         self._chk(self.lib.bod_profile_begin(self.h))

@@ -188,6 +188,13 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
                           int32_t round_output_bf16, float* out);
 
+/* Kernel micro-benchmark (tests/tools): re-launches the handle's layer-`layer` head-tower conv
+ * (0 = de-duplicated fan-out layer, 1..3 = per-sample layers) `iters` times on the handle's own
+ * buffers and returns the mean duration; `variant` selects an ablation build of the kernel
+ * (0 = production). */
+bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters,
+                               double* mean_ms, double* flops_per_launch);
+
 /* Measurement hooks (bench.py): HIP-event timing of the dominant kernel on the handle's stream. */
 bod_status bod_profile_begin(bod_handle h);
 /* total ms in head 3x3 conv launches since begin, number of launches, FLOPs (2*MACs) issued */

@@ -42,6 +42,8 @@ CASES = [
     (1, 8, 8, 256, 36, 1, 1, "same"),               # reg output conv
     (1, 8, 8, 256, 90, 1, 1, "same"),               # cov output conv (cout not a multiple of 4)
     (1, 40, 36, 512, 128, 3, 1, "same"),            # many K tiles, M not a multiple of the tile
+    (1, 130, 128, 64, 256, 3, 1, "same"),           # M >= 16384: 256x256-tile 8-wave configuration
+    (2, 96, 100, 128, 512, 1, 1, "valid"),          # 256-tile config, two cout tiles, ragged M
 ]
 
 
