@@ -56,11 +56,15 @@ struct ConvCfg {
 // ABL: 0 = production; 1 = no epilogue; 2 = no global->LDS traffic after the first tile;
 //      3 = no MFMA / LDS fragment reads; 4 = dropout without the Philox call
 //      (ablation builds for tests/tools/bench_head_conv.py)
-template <int BC, int BP, int WC, int WP, int ABL>
+// SPLIT: only the upper half of the waves issues the global->LDS staging (2x the pieces each), so the
+//      lower half starts its MFMAs right after the barrier and the two waves of every SIMD run
+//      out of phase (the matrix pipe stays fed while the other wave issues loads / waits).
+template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG>
 __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<BC, BP, WC, WP>;
     constexpr int THREADS = Cfg::THREADS;
-    constexpr int RPI = THREADS / 8;             // tile rows covered by one staging instruction
+    constexpr int LTHREADS = SPLIT ? THREADS / 2 : THREADS;   // threads that stage
+    constexpr int RPI = LTHREADS / 8;            // tile rows covered by one staging instruction
     constexpr int BK = 64;                       // bf16 per K-tile row (128 B)
     constexpr int ROWB = BK * 2;
     constexpr int W_BYTES = BC * ROWB, STAGE = Cfg::STAGE;
@@ -88,8 +92,11 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     const int KT = a.taps * cpt;
 
     // ---- per-thread staging descriptors
-    const int ldrow = tid >> 3;                              // 0..RPI-1 (+RPI*i)
-    const int ldchunk = (tid & 7) ^ ((tid >> 4) & 7);        // source chunk (pre-swizzled)
+    const bool loader = !SPLIT || tid >= THREADS / 2;
+    const int ltid = SPLIT ? (tid & (LTHREADS - 1)) : tid;
+    const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
+    const int ldrow = ltid >> 3;                             // 0..RPI-1 (+RPI*i)
+    const int ldchunk = (ltid & 7) ^ ((ltid >> 4) & 7);      // source chunk (pre-swizzled)
     const char* xsrc[NX];
     int xpitch[NX];
 #pragma unroll
@@ -112,18 +119,25 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         s_off[i] = m < a.M ? a.rows[m].out_off : -1;
     }
 
-    auto issue = [&](int stage, int kt, int ky, int kx, int cc) {
+    auto issue_w = [&](int stage, int kt) {
         char* sb = smem + stage * STAGE;
+        if (ABL == 11 && kt > 0) return;             // timing probe: no weight traffic
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wsrc[i] + (size_t)kt * ROWB),
-                                             LDS_PTR(sb + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                                             LDS_PTR(sb + (i * LTHREADS + lwave * 64) * 16), 16, 0, 0);
+    };
+    auto issue_x = [&](int stage, int ky, int kx, int cc) {
+        char* sb = smem + stage * STAGE;
         const int tapoff = (kx * a.in_cstride + cc * BK) * 2;
+        if (ABL == 6 && (kx | ky)) return;          // timing probe: X traffic of a halo-reuse scheme (1 of 9 taps)
+        if (ABL == 12 && (kx | ky | cc)) return;    // timing probe: no activation traffic
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xsrc[i] + ky * xpitch[i] + tapoff),
-                                             LDS_PTR(sb + W_BYTES + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                                             LDS_PTR(sb + W_BYTES + (i * LTHREADS + lwave * 64) * 16), 16, 0, 0);
     };
+    auto issue = [&](int stage, int kt, int ky, int kx, int cc) { issue_w(stage, kt); issue_x(stage, ky, kx, cc); };
 
     f32x16 acc[FC][FP];
 #pragma unroll
@@ -138,14 +152,62 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     const int fhalf = lane >> 5;
 
     int ky = 0, kx = 0, cc = 0;
-    issue(0, 0, 0, 0, 0);
+    if (loader) issue(0, 0, 0, 0, 0);
     int cur = 0;
+    if constexpr (STAG) {
+        // Staggered schedule (the two wave rows of the block run one barrier apart): every k-step is a
+        // memory segment {stage pieces of the next tile, ds_read this k-step's fragments, wait} and a
+        // compute segment {8 MFMAs at raised priority}, separated by block barriers.  Wave row 1 is
+        // offset by one barrier, so on every SIMD one wave is always in its compute segment while its
+        // partner is in its memory segment.  Hazards: a stage is re-filled only after the barrier that
+        // follows the other row's last (waited) fragment read of it; a tile is read only after the
+        // barrier that follows every wave's vmcnt(0) for it.
+        static_assert(WC == 2 && !SPLIT, "staggered schedule is written for two wave rows");
+        const bool row1 = wc == 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        for (int kt = 0; kt < KT; ++kt) {
+            const int st = kt & 1;
+            const bool more = kt + 1 < KT;
+            if (more) { if (++cc == cpt) { cc = 0; if (++kx == a.KW) { kx = 0; ++ky; } } }
+            const char* wb = smem + st * STAGE + (wc * WTC + frow) * ROWB;
+            const char* xb = smem + st * STAGE + W_BYTES + (wp * WTP + frow) * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks == 0 && more && ABL != 2) issue_w(st ^ 1, kt + 1);
+                if (ks == 1 && more && ABL != 2) issue_x(st ^ 1, ky, kx, cc);
+                const int ch = ((ks * 2 + fhalf) ^ fswz) << 4;
+                bf16x8 af[FC], bfr[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * ROWB + ch);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(xb + j * 32 * ROWB + ch);
+                if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    } else
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < KT) {
             if (++cc == cpt) { cc = 0; if (++kx == a.KW) { kx = 0; ++ky; } }
-            if (ABL != 2) issue(cur ^ 1, kt + 1, ky, kx, cc);
+            if (ABL != 2 && loader) issue(cur ^ 1, kt + 1, ky, kx, cc);
         }
         if (ABL == 3) { cur ^= 1; continue; }
         const char* wb = smem + cur * STAGE + (wc * WTC + frow) * ROWB;
@@ -296,11 +358,11 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     }
 }
 
-template <int BC, int BP, int WC, int WP, int ABL>
+template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT = false, bool STAG = false>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<BC, BP, WC, WP>;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL>;
+    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, SPLIT, STAG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -327,6 +389,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         case 2: return launch_cfg<256, 256, 2, 4, 2>(a, s);
         case 3: return launch_cfg<256, 256, 2, 4, 3>(a, s);
         case 4: return launch_cfg<256, 256, 2, 4, 4>(a, s);
+        case 5: return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
+        case 6: return launch_cfg<256, 256, 2, 4, 6>(a, s);
+        case 11: return launch_cfg<256, 256, 2, 4, 11>(a, s);
+        case 12: return launch_cfg<256, 256, 2, 4, 12>(a, s);
+        case 7: return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
+        case 8: return launch_cfg<256, 256, 2, 4, 1, false, true>(a, s);
+        case 9: return launch_cfg<256, 256, 2, 4, 2, false, true>(a, s);
         case 10: return launch_cfg<128, 128, 2, 2, 0>(a, s);
         default: return hipErrorInvalidValue;
     }
