@@ -38,6 +38,16 @@ __device__ __forceinline__ uint32_t f32_to_bf16(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);          // round to nearest even (finite inputs)
     return u >> 16;
 }
+// two fp32 -> packed bf16x2 (lo | hi << 16), round-to-nearest-even in ONE instruction on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#else
+    return f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
+#endif
+}
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
     const uint32_t lo = (w & 0x8000u) ? 0u : (w & 0xFFFFu);
     const uint32_t hi = (w & 0x80000000u) ? 0u : (w & 0xFFFF0000u);
@@ -50,7 +60,13 @@ struct ConvCfg {
     static constexpr int STAGE = (BC + BP) * 128;
     static constexpr int EP_BYTES = BP * BC * 2;
     static constexpr int MAIN = (2 * STAGE > EP_BYTES) ? 2 * STAGE : EP_BYTES;
-    static constexpr int LDS = MAIN + BP * 4;
+    // after the staging / epilogue area: per-tile metadata read by the epilogue (kept out of registers
+    // during the K loop and out of global memory in the epilogue)
+    static constexpr int OFF_OUT = MAIN;                 // int   [BP] output pixel (-1 = invalid row)
+    static constexpr int OFF_RES = OFF_OUT + BP * 4;     // int   [BP] residual pixel
+    static constexpr int OFF_RNG = OFF_RES + BP * 4;     // int2  [BP] dropout counters
+    static constexpr int OFF_BIAS = OFF_RNG + BP * 8;    // float [BC]
+    static constexpr int LDS = OFF_BIAS + BC * 4;
 };
 
 // ABL: 0 = production; 1 = no epilogue; 2 = no global->LDS traffic after the first tile;
@@ -74,7 +90,10 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     constexpr int CPR = BC / 8;                  // 16-B chunks per pixel row of the epilogue tile
     static_assert(BC % RPI == 0 && BP % RPI == 0 && RPI % 16 == 0, "tile / thread mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_off = reinterpret_cast<int*>(smem + Cfg::MAIN);
+    int* s_off = reinterpret_cast<int*>(smem + Cfg::OFF_OUT);
+    int* s_res = reinterpret_cast<int*>(smem + Cfg::OFF_RES);
+    int2* s_rng = reinterpret_cast<int2*>(smem + Cfg::OFF_RNG);
+    float* s_bias = reinterpret_cast<float*>(smem + Cfg::OFF_BIAS);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,6 +107,16 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int bp0 = bx * BP, bc0 = blockIdx.y * BC;
+    if (ABL >= 20) {
+        // De-phase the CUs once: every block of a launch takes the same time, so the chip otherwise runs
+        // in lock-step rounds and all 256 CUs hit their store epilogue (33 MB) in the same few microseconds.
+        // A one-off start offset for the first resident round spreads the bursts for all later rounds.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < 256) {
+            const int steps = (int)((lin * 2654435761u) >> 28) * (ABL - 19);     // 0..15 x (ABL-19)
+            for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(32);            // 32*64 clk ~ 0.9 us
+        }
+    }
     const int cpt = a.cin / BK;                  // K-tiles per tap
     const int KT = a.taps * cpt;
 
@@ -116,8 +145,13 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     }
     for (int i = tid; i < BP; i += THREADS) {
         const int m = bp0 + i;
-        s_off[i] = m < a.M ? a.rows[m].out_off : -1;
+        const int mm = m < a.M ? m : a.M - 1;
+        const int4 e0 = *reinterpret_cast<const int4*>(&a.rows[mm]);
+        s_off[i] = m < a.M ? e0.z : -1;
+        s_res[i] = e0.w;
+        s_rng[i] = *(reinterpret_cast<const int2*>(&a.rows[mm]) + 2);
     }
+    for (int i = tid; i < BC; i += THREADS) s_bias[i] = G.bias[bc0 + i];
 
     auto issue_w = [&](int stage, int kt) {
         char* sb = smem + stage * STAGE;
@@ -274,10 +308,8 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
     int res_off[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
-        int m = bp0 + wp * WTP + j * 32 + frow;
-        m = m < a.M ? m : a.M - 1;
-        rng[j] = *(reinterpret_cast<const int2*>(&a.rows[m]) + 2);            // rng_p, rng_zs
-        res_off[j] = a.rows[m].res_off;
+        rng[j] = s_rng[wp * WTP + j * 32 + frow];                             // rng_p, rng_zs
+        res_off[j] = s_res[wp * WTP + j * 32 + frow];
     }
     // phase A: finish the arithmetic and pack to bf16 (halves the live registers before the RNG):
     // rounding(x*scale) then zeroing == zeroing then rounding, so the mask is applied on packed words
@@ -288,8 +320,9 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         for (int i = 0; i < FC; ++i) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int co = bc0 + wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(G.bias + co);
+                const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
+                const int co = bc0 + col;
+                const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
                 float v[4] = {acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
                               acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w};
                 if (G.res) {
@@ -305,12 +338,25 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] *= a.drop_scale;
                 }
-                pk[i][j][g4].x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16);
-                pk[i][j][g4].y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
+                pk[i][j][g4].x = pack_bf16x2(v[0], v[1]);
+                pk[i][j][g4].y = pack_bf16x2(v[2], v[3]);
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 31) {
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(pk[i][j][g4].x), "v"(pk[i][j][g4].y));
+#endif
+                }
+        return;
+    }
     const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
     for (int n = 0; n < fan; ++n) {
 #pragma unroll
@@ -347,6 +393,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
             const uint4 v = *reinterpret_cast<const uint4*>(smem + pixl * (BC * 2) + cp * 16);
             const int c16 = (cp ^ pixl) & (CPR - 1);
             const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 + c16 * 8;
+            if (ABL == 30) { if (v.x == 0x12345678u && e == 0) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out)) = v; continue; }
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + e) = v;
             if (G.out_relu) {
                 uint4 r;
@@ -381,6 +428,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     // overrides the size heuristic (tests exercise both configurations on small inputs)
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     bool big = a.cout_pad % 256 == 0 && a.M >= 16384 && !(a.flags & CONV_OUT_F32);
+    // the N-way dropout fan-out epilogue is VALU-bound (N Philox rounds per tile): run it with two
+    // resident blocks per CU (128x128 tiles) so one block's epilogue overlaps the other's MFMA loop
+    if (a.fan_count > 1) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
     if (forced == 128) big = false;
     switch (a.variant) {
@@ -391,6 +441,11 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         case 4: return launch_cfg<256, 256, 2, 4, 4>(a, s);
         case 5: return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
         case 6: return launch_cfg<256, 256, 2, 4, 6>(a, s);
+        case 30: return launch_cfg<256, 256, 2, 4, 30>(a, s);
+        case 31: return launch_cfg<256, 256, 2, 4, 31>(a, s);
+        case 20: return launch_cfg<256, 256, 2, 4, 20>(a, s);
+        case 21: return launch_cfg<256, 256, 2, 4, 21>(a, s);
+        case 23: return launch_cfg<256, 256, 2, 4, 23>(a, s);
         case 11: return launch_cfg<256, 256, 2, 4, 11>(a, s);
         case 12: return launch_cfg<256, 256, 2, 4, 12>(a, s);
         case 7: return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
