@@ -28,4 +28,21 @@ BOD_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     return Philox4{c0, c1, c2, c3};
 }
 
+// The same generator as a resumable state, so a call can be spread over several schedule slots.
+struct PhiloxState { uint32_t c0, c1, c2, c3, k0, k1; };
+BOD_HD void philox_rounds(PhiloxState& s, int n) {
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * s.c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * s.c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
+        const uint32_t n3 = (uint32_t)p0;
+        s.c0 = n0; s.c1 = n1; s.c2 = n2; s.c3 = n3;
+        s.k0 += 0x9E3779B9u;
+        s.k1 += 0xBB67AE85u;
+    }
+}
+
 #define BOD_CAT_TAG 0x00CA7E60u
