@@ -21,7 +21,8 @@ class BodConfig(C.Structure):
         ("ranking_method", C.c_int32), ("nms_max_output_size", C.c_int32),
         ("nms_iou_threshold", C.c_float), ("nms_soft_sigma", C.c_float), ("nms_variant", C.c_int32),
         ("num_categorical_draws", C.c_int32), ("has_covar_head", C.c_int32),
-        ("kitti_scale_h", C.c_float), ("kitti_scale_w", C.c_float), ("reserved", C.c_int32 * 8),
+        ("kitti_scale_h", C.c_float), ("kitti_scale_w", C.c_float), ("precision", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -72,7 +73,7 @@ SIGNATURES = {
     "bod_synchronize": (C.c_int, [_H]),
     "bod_stage_conv": (C.c_int, [C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F,
-                                 C.c_float, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, _F]),
+                                 C.c_float, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, _F]),
     "bod_bench_head_conv": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bod_profile_begin": (C.c_int, [_H]),
     "bod_profile_end": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64),

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libbayesod_hip.so")
 
 SOURCES = [
     ("conv_igemm.hip", []),
+    ("conv_igemm_f32.hip", []),
     ("aux_kernels.hip", []),
     # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
     ("post_kernels.hip", ["-ffp-contract=off"]),

@@ -23,10 +23,11 @@ constexpr int ST_SEG = 64;                      // output pixels per task (4 wav
 constexpr int ST_ROWF = 2 * ST_SEG * 3 + 5 * 3 + 5;   // 404 floats: (2*63+7) pixels * 3 ch = 399, + the 3 zero-weight k slots, padded
 constexpr int ST_KSTEPS = 42;                   // 7 rows x 24 (21 real + 3 zero) / 4
 
+template <bool OUT_F32>
 __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const float* __restrict__ img,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
-                                                           uint16_t* __restrict__ out,
+                                                           void* __restrict__ out_,
                                                            int B, int H, int W, int oh, int ow) {
     __shared__ float patch[2][7][ST_ROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,8 +88,15 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const float* __restri
         }
         const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
         const int ox = seg * ST_SEG + wave * 16 + li;
-        if (ox < ow) {
-            uint16_t* o = out + (((size_t)b * oh + oy) * ow + ox) * 64 + lq * 4;
+        if (ox < ow && OUT_F32) {
+            float* o = reinterpret_cast<float*>(out_) + (((size_t)b * oh + oy) * ow + ox) * 64 + lq * 4;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                *reinterpret_cast<float4*>(o + f * 16) =
+                    make_float4(fmaxf(acc[f][0] + bv[f][0], 0.f), fmaxf(acc[f][1] + bv[f][1], 0.f),
+                                fmaxf(acc[f][2] + bv[f][2], 0.f), fmaxf(acc[f][3] + bv[f][3], 0.f));
+        } else if (ox < ow) {
+            uint16_t* o = reinterpret_cast<uint16_t*>(out_) + (((size_t)b * oh + oy) * ow + ox) * 64 + lq * 4;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 uint2 pk;
@@ -102,13 +110,41 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const float* __restri
     }
 }
 
-hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, uint16_t* out,
+hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s) {
     const int segs = (ow + ST_SEG - 1) / ST_SEG;
     const int ntasks = B * oh * segs;
     const int grid = ntasks < 1024 ? ntasks : 1024;
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
+    if (out_f32) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
+    else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
     return hipGetLastError();
+}
+
+// fp32 variant of the pooling kernel below (thread = output pixel x 4-channel group)
+__global__ __launch_bounds__(256) void stem_pool_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int B, int ih, int iw, int oh, int ow, int out_pitch,
+                                                            int out_plane) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int total = B * oh * ow * 16;
+    if (gid >= total) return;
+    const int cg = gid & 15;
+    int p = gid >> 4;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        if (iy < 0 || iy >= ih) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx - 2;
+            if (ix < 0 || ix >= iw) continue;
+            const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * ih + iy) * iw + ix) * 64 + cg * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    const size_t opix = (size_t)b * out_plane + (size_t)(oy + 1) * out_pitch + (ox + 1);
+    *reinterpret_cast<float4*>(out + opix * 64 + cg * 4) = m;
 }
 
 // thread = (output pixel, 8-channel group); 16-byte loads/stores. Pads are zeros: inputs are
@@ -152,10 +188,18 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const uint16_t* __restri
     *reinterpret_cast<uint4*>(out + opix * 64 + cg * 8) = o;
 }
 
-hipError_t launch_stem_pool(const uint16_t* in, uint16_t* out, int B, int ih, int iw, int oh, int ow,
+hipError_t launch_stem_pool(const void* in, void* out, int f32, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s) {
+    if (f32) {
+        const int total = B * oh * ow * 16;
+        hipLaunchKernelGGL(stem_pool_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), B, ih, iw, oh, ow,
+                           out_pitch, out_plane);
+        return hipGetLastError();
+    }
     const int total = B * oh * ow * 8;
-    hipLaunchKernelGGL(stem_pool_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, out, B, ih,
+    hipLaunchKernelGGL(stem_pool_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const uint16_t*>(in), reinterpret_cast<uint16_t*>(out), B, ih,
                        iw, oh, ow, out_pitch, out_plane);
     return hipGetLastError();
 }

@@ -346,7 +346,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
                 float v[4] = {acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
                               acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w};
                 if (G.res) {
-                    const uint2 r = *reinterpret_cast<const uint2*>(G.res + (size_t)res_off[j] * a.res_cstride + co);
+                    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)res_off[j] * a.res_cstride + co);
                     v[0] += bf16_to_f32(r.x & 0xFFFFu); v[1] += bf16_to_f32(r.x >> 16);
                     v[2] += bf16_to_f32(r.y & 0xFFFFu); v[3] += bf16_to_f32(r.y >> 16);
                 }
@@ -425,7 +425,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             if (G.out_relu) {
                 uint4 r;
                 r.x = relu_bf16x2(v.x); r.y = relu_bf16x2(v.y); r.z = relu_bf16x2(v.z); r.w = relu_bf16x2(v.w);
-                *reinterpret_cast<uint4*>(G.out_relu + e) = r;
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out_relu) + e) = r;
             }
         }
         if (n + 1 < fan) __syncthreads();
@@ -530,6 +530,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         case 6: return launch_cfg<256, 256, 2, 4, 6>(a, s);
         case 30: return launch_cfg<256, 256, 2, 4, 30>(a, s);
         case 31: return launch_cfg<256, 256, 2, 4, 31>(a, s);
+        case 60: return launch_cfg<256, 256, 2, 2, 0>(a, s);
+        case 61: return launch_cfg<256, 256, 2, 2, 1>(a, s);
+        case 62: return launch_cfg<256, 256, 2, 2, 2>(a, s);
         case 50: return launch_cfg<256, 256, 2, 4, 50>(a, s);
         case 51: return launch_cfg<256, 256, 2, 4, 51>(a, s);
         case 52: return launch_cfg<256, 256, 2, 4, 52>(a, s);

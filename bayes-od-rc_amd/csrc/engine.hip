@@ -23,14 +23,14 @@ thread_local std::string g_create_error;
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
-struct Plane {               // bf16 NHWC view with a 1-pixel zero border
-    uint16_t* d = nullptr;
+struct Plane {               // NHWC view (bf16, or fp32 in fp32 precision mode) with a 1-pixel zero border
+    char* d = nullptr;
     int64_t base = 0;        // pixel offset of this view inside d
     int64_t bstride = 0;     // pixels between consecutive batch items
     int h = 0, w = 0, C = 0, pitch = 0;
 };
 
-struct PackedConv { uint16_t* w = nullptr; float* bias = nullptr; int cout = 0, cout_pad = 0, taps = 0, kw = 0, cin = 0; };
+struct PackedConv { char* w = nullptr; float* bias = nullptr; int cout = 0, cout_pad = 0, taps = 0, kw = 0, cin = 0; };
 
 struct Op {
     enum Kind { STEM, POOL, CONV } kind;
@@ -72,9 +72,10 @@ struct bod_context {
 
     // activations
     float* d_images = nullptr;
-    uint16_t* stem_out = nullptr;
+    char* stem_out = nullptr;
+    int es = 2;                                          // bytes per activation / weight element (2 = bf16, 4 = fp32)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
-    uint16_t* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
+    char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
     float* raw[3] = {nullptr};                           // cls [B,N,P,9C] box [B,N,P,36] cov [B,N,P,90]
     std::map<std::string, RowEnt*> tables;
     std::vector<Op> ops;
@@ -153,7 +154,7 @@ int same_pad_before(int in, int k, int s) {
 bod_status new_plane(bod_context* h, Plane* p, int B, int hh, int ww, int C) {
     p->h = hh; p->w = ww; p->C = C; p->pitch = ww + 2; p->base = 0;
     p->bstride = (int64_t)(hh + 2) * (ww + 2);
-    return h->dalloc(&p->d, (size_t)B * p->bstride * C);
+    return h->dalloc(&p->d, (size_t)B * p->bstride * C * h->es);
 }
 
 // row table for plane -> plane convolutions. org_* = padded coordinate of the window origin of
@@ -218,19 +219,23 @@ bod_status pack_conv(bod_context* h, const std::string& name, const std::string&
     PackedConv pc;
     pc.cout = cout; pc.taps = kh * kw; pc.kw = kw; pc.cin = cin;
     pc.cout_pad = ((cout + cout_pad_to - 1) / cout_pad_to) * cout_pad_to;
-    std::vector<uint16_t> w((size_t)pc.cout_pad * pc.taps * cin, 0);
+    const size_t nw = (size_t)pc.cout_pad * pc.taps * cin;
+    std::vector<uint16_t> w(h->es == 2 ? nw : 0, 0);
+    std::vector<float> w32(h->es == 4 ? nw : 0, 0.f);
     std::vector<float> bias(pc.cout_pad, 0.f);
     for (int o = 0; o < cout; ++o) {
         bias[o] = (float)shift[o];
         for (int t = 0; t < pc.taps; ++t)
             for (int c = 0; c < cin; ++c) {
                 const double v = (double)k->data[((size_t)t * cin + c) * cout + o] * scale[o];
-                w[((size_t)o * pc.taps + t) * cin + c] = f2bf((float)v);
+                const size_t idx = ((size_t)o * pc.taps + t) * cin + c;
+                if (h->es == 2) w[idx] = f2bf((float)v); else w32[idx] = (float)v;
             }
     }
-    BODCHK(h->dalloc(&pc.w, w.size(), false));
+    BODCHK(h->dalloc(&pc.w, nw * h->es, false));
     BODCHK(h->dalloc(&pc.bias, bias.size(), false));
-    HIPCHK(h, hipMemcpyAsync(pc.w, w.data(), w.size() * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pc.w, h->es == 2 ? (const void*)w.data() : (const void*)w32.data(), nw * h->es,
+                             hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->packed[name] = pc;
@@ -250,7 +255,7 @@ ConvArgs base_args(const PackedConv& pc, const RowEnt* rows, int M, int in_cstri
 // conv + folded BN (+residual) (+ReLU) between two planes
 bod_status add_conv(bod_context* h, const std::string& name, const std::string& bn, const Plane& in,
                     const Plane& out, int stride, bool same, bool relu, const Plane* res,
-                    uint16_t* out_relu = nullptr) {
+                    char* out_relu = nullptr) {
     PackedConv pc;
     BODCHK(pack_conv(h, name, bn, 64, &pc));
     if (pc.cin != in.C || pc.cout != out.C)
@@ -339,7 +344,7 @@ bod_status build_plan(bod_context* h) {
         HIPCHK(h, hipMemcpyAsync(h->stem_w, w.data(), w.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->stem_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        BODCHK(h->dalloc(&h->stem_out, (size_t)B * h->sh * h->sw * 64));
+        BODCHK(h->dalloc(&h->stem_out, (size_t)B * h->sh * h->sw * 64 * h->es));
         Op s; s.kind = Op::STEM; h->ops.push_back(s);
         Op p; p.kind = Op::POOL; h->ops.push_back(p);
     }
@@ -395,14 +400,14 @@ bod_status build_plan(bod_context* h) {
 
     // ---------------- FPN (feature_decoder.py:136-171)
     h->pyramid.C = 256; h->pyramid.bstride = h->Ppad;
-    BODCHK(h->dalloc(&h->pyramid.d, (size_t)B * h->Ppad * 256));
+    BODCHK(h->dalloc(&h->pyramid.d, (size_t)B * h->Ppad * 256 * h->es));
     Plane c5r, m4, m3, p6relu;
     BODCHK(new_plane(h, &c5r, B, h->lh[2], h->lw[2], 256));
     BODCHK(new_plane(h, &m4, B, h->lh[1], h->lw[1], 256));
     BODCHK(new_plane(h, &m3, B, h->lh[0], h->lw[0], 256));
     // relu(P6) shares the pyramid layout so one row table serves both outputs of the P6 conv
-    uint16_t* p6relu_buf = nullptr;
-    BODCHK(h->dalloc(&p6relu_buf, (size_t)B * h->Ppad * 256));
+    char* p6relu_buf = nullptr;
+    BODCHK(h->dalloc(&p6relu_buf, (size_t)B * h->Ppad * 256 * h->es));
     p6relu = h->pyramid; p6relu.d = p6relu_buf;
     BODCHK(add_conv(h, "C5_reduced", "", c5, c5r, 1, false, false, nullptr));
     BODCHK(add_conv(h, "P5", "", c5r, level_view(h, 2), 1, true, false, nullptr));
@@ -417,7 +422,7 @@ bod_status build_plan(bod_context* h) {
     BODCHK(add_conv(h, "P3", "", m3, level_view(h, 0), 1, true, false, nullptr));
 
     // ---------------- heads (multitask_headers.py; retinanet_model.py:78-109)
-    const size_t act_elems = (size_t)B * N * h->Ppad * 256;
+    const size_t act_elems = (size_t)B * N * h->Ppad * 256 * h->es;
     for (int hd = 0; hd < 3; ++hd) {
         if (hd == 2 && !c.has_covar_head) continue;
         BODCHK(h->dalloc(&h->head_act[hd][0], act_elems));
@@ -576,11 +581,11 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
     for (Op& op : h->ops) {
         switch (op.kind) {
             case Op::STEM:
-                HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, c.batch, c.image_h,
+                HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, h->stream));
                 break;
             case Op::POOL:
-                HIPCHK(h, launch_stem_pool(h->stem_out, reinterpret_cast<uint16_t*>(op.conv.g[0].out), c.batch,
+                HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->es == 4, c.batch,
                                            h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
                 break;
             case Op::CONV: {
@@ -592,7 +597,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
                     HIPCHK(h, hipEventRecord(e0, h->stream));
                 }
-                HIPCHK(h, launch_conv_igemm(op.conv, h->stream));
+                HIPCHK(h, h->es == 4 ? launch_conv_igemm_f32(op.conv, h->stream) : launch_conv_igemm(op.conv, h->stream));
                 if (timed) {
                     HIPCHK(h, hipEventRecord(e1, h->stream));
                     h->ev_head.emplace_back(e0, e1);
@@ -699,6 +704,9 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) return bail(h->fail(BOD_ERR_INVALID_ARG, "dropout_rate must be in [0,1)"));
     if (c.num_categorical_draws < 1 || c.num_categorical_draws > 1024) return bail(h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range"));
     if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
+    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0) or BOD_PRECISION_FP32 (1)"));
+    h->es = c.precision == BOD_PRECISION_FP32 ? 4 : 2;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
@@ -748,7 +756,8 @@ bod_status bod_update_config(bod_handle h, const bod_config* cfg) {
     if (cfg->device != o.device || cfg->image_h != o.image_h || cfg->image_w != o.image_w || cfg->batch != o.batch ||
         cfg->mc_samples != o.mc_samples || cfg->num_classes != o.num_classes ||
         cfg->anchors_per_location != o.anchors_per_location || cfg->min_level != o.min_level ||
-        cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate)
+        cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate ||
+        cfg->precision != o.precision)
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: geometry / model fields cannot change on a live handle");
     if (cfg->nms_max_output_size != o.nms_max_output_size)
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: nms_max_output_size sizes device buffers and cannot change");
@@ -854,16 +863,21 @@ bod_status bod_get_pyramid(bod_handle h, int32_t l, float* out) {
     if (!h->forward_done || !h->pyramid.d) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
     if (l < 0 || l >= h->nlev) return h->fail(BOD_ERR_INVALID_ARG, "level index %d out of range", l);
     const int B = h->cfg.batch;
-    std::vector<uint16_t> tmp((size_t)B * h->Ppad * 256);
-    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pyramid.d, tmp.size() * 2, hipMemcpyDeviceToHost, h->stream));
+    std::vector<char> tmp((size_t)B * h->Ppad * 256 * h->es);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pyramid.d, tmp.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int hh = h->lh[l], ww = h->lw[l], pitch = ww + 2;
     for (int b = 0; b < B; ++b)
         for (int y = 0; y < hh; ++y)
             for (int x = 0; x < ww; ++x) {
-                const uint16_t* s = &tmp[((size_t)b * h->Ppad + h->lvl_off[l] + (size_t)(y + 1) * pitch + (x + 1)) * 256];
+                const size_t pix = ((size_t)b * h->Ppad + h->lvl_off[l] + (size_t)(y + 1) * pitch + (x + 1)) * 256;
                 float* d = out + (((size_t)b * hh + y) * ww + x) * 256;
-                for (int ch = 0; ch < 256; ++ch) d[ch] = bf2f(s[ch]);
+                if (h->es == 2) {
+                    const uint16_t* s = reinterpret_cast<const uint16_t*>(tmp.data()) + pix;
+                    for (int ch = 0; ch < 256; ++ch) d[ch] = bf2f(s[ch]);
+                } else {
+                    std::memcpy(d, reinterpret_cast<const float*>(tmp.data()) + pix, 256 * sizeof(float));
+                }
             }
     return BOD_OK;
 }
@@ -1085,9 +1099,11 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           const float* w, const float* bias, int32_t KH, int32_t KW, int32_t Cout,
                           int32_t stride, int32_t same_padding, int32_t relu, const float* residual,
                           float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
-                          int32_t round_output_bf16, float* out) {
+                          int32_t round_output_bf16, int32_t precision, float* out) {
     bod_context ctx;                      // scratch context: owns the temporary device buffers
     bod_context* h = &ctx;
+    const bool f32 = precision == BOD_PRECISION_FP32;
+    h->es = f32 ? 4 : 2;
     auto done = [&](bod_status s) {
         if (s != BOD_OK) g_create_error = h->err;
         if (h->stream) hipStreamSynchronize(h->stream);
@@ -1098,7 +1114,9 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     };
     if (!x || !w || !out || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || stride > 2)
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad argument"));
-    if (Cin % 64 != 0 || ((round_output_bf16 || dropout_rate > 0.f) && Cout % 4 != 0))
+    if (precision != BOD_PRECISION_BF16 && !f32) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad precision"));
+    if (f32 && round_output_bf16) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: round_output_bf16 is meaningless in fp32 precision"));
+    if (Cin % 64 != 0 || ((round_output_bf16 || (dropout_rate > 0.f && !f32)) && Cout % 4 != 0))
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: Cin must be a multiple of 64 (and Cout of 4 for bf16 output); got %d, %d", Cin, Cout));
     if (KH > 3 || KW > 3) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: kernel larger than 3x3 needs a wider zero border"));
     int ndev = 0;
@@ -1118,24 +1136,33 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     auto run = [&]() -> bod_status {
         Plane in, res;
         BODCHK(new_plane(h, &in, B, H, W, Cin));
-        std::vector<uint16_t> hx((size_t)B * in.bstride * Cin, 0);
+        std::vector<uint16_t> hx(f32 ? 0 : (size_t)B * in.bstride * Cin, 0);
+        std::vector<float> hx32(f32 ? (size_t)B * in.bstride * Cin : 0, 0.f);
         for (int b = 0; b < B; ++b)
             for (int y = 0; y < H; ++y)
                 for (int xx = 0; xx < W; ++xx)
-                    for (int c = 0; c < Cin; ++c)
-                        hx[((size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1)) * Cin + c] =
-                            f2bf(x[(((size_t)b * H + y) * W + xx) * Cin + c]);
-        HIPCHK(h, hipMemcpyAsync(in.d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, h->stream));
+                    for (int c = 0; c < Cin; ++c) {
+                        const size_t di = ((size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1)) * Cin + c;
+                        const float v = x[(((size_t)b * H + y) * W + xx) * Cin + c];
+                        if (f32) hx32[di] = v; else hx[di] = f2bf(v);
+                    }
+        HIPCHK(h, hipMemcpyAsync(in.d, f32 ? (const void*)hx32.data() : (const void*)hx.data(),
+                                 (size_t)B * in.bstride * Cin * h->es, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         if (residual) {
             BODCHK(new_plane(h, &res, B, OH, OW, Cout));
-            std::vector<uint16_t> hr((size_t)B * res.bstride * Cout, 0);
+            std::vector<uint16_t> hr(f32 ? 0 : (size_t)B * res.bstride * Cout, 0);
+            std::vector<float> hr32(f32 ? (size_t)B * res.bstride * Cout : 0, 0.f);
             for (int b = 0; b < B; ++b)
                 for (int y = 0; y < OH; ++y)
                     for (int xx = 0; xx < OW; ++xx)
-                        for (int c = 0; c < Cout; ++c)
-                            hr[((size_t)b * res.bstride + (size_t)(y + 1) * res.pitch + (xx + 1)) * Cout + c] =
-                                f2bf(residual[(((size_t)b * OH + y) * OW + xx) * Cout + c]);
-            HIPCHK(h, hipMemcpyAsync(res.d, hr.data(), hr.size() * 2, hipMemcpyHostToDevice, h->stream));
+                        for (int c = 0; c < Cout; ++c) {
+                            const size_t di = ((size_t)b * res.bstride + (size_t)(y + 1) * res.pitch + (xx + 1)) * Cout + c;
+                            const float v = residual[(((size_t)b * OH + y) * OW + xx) * Cout + c];
+                            if (f32) hr32[di] = v; else hr[di] = f2bf(v);
+                        }
+            HIPCHK(h, hipMemcpyAsync(res.d, f32 ? (const void*)hr32.data() : (const void*)hr.data(),
+                                     (size_t)B * res.bstride * Cout * h->es, hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
         HostTensor k; k.shape = {KH, KW, Cin, Cout}; k.data.assign(w, w + (size_t)KH * KW * Cin * Cout);
@@ -1147,7 +1174,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         const bool drop = dropout_rate > 0.f;
         const size_t n_out = (size_t)B * OH * OW * Cout;
         float* d_out32 = nullptr; uint16_t* d_out16 = nullptr;
-        const bool f32_out = !round_output_bf16 && !drop;
+        const bool f32_out = f32 || (!round_output_bf16 && !drop);
         if (f32_out) BODCHK(h->dalloc(&d_out32, n_out)); else BODCHK(h->dalloc(&d_out16, n_out));
         std::vector<RowEnt> rows((size_t)B * OH * OW);
         size_t r = 0;
@@ -1168,11 +1195,11 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         HIPCHK(h, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
         ConvArgs a = base_args(pc, d_rows, B * OH * OW, Cin, Cout);
         a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id};
-        a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | (f32_out ? CONV_OUT_F32 : 0);
+        a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
         a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 4294967296.0);
         a.drop_scale = (float)(1.0 / (1.0 - (double)dropout_rate));
-        HIPCHK(h, launch_conv_igemm(a, h->stream));
+        HIPCHK(h, f32 ? launch_conv_igemm_f32(a, h->stream) : launch_conv_igemm(a, h->stream));
         if (f32_out) {
             HIPCHK(h, hipMemcpyAsync(out, d_out32, n_out * 4, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));

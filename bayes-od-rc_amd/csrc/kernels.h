@@ -21,13 +21,13 @@ struct RowEnt {            // 32 B per output pixel
     int32_t pad0, pad1;
 };
 
-struct ConvGroup {
-    const uint16_t* in;    // bf16 activations
-    const uint16_t* w;     // bf16 [Cout_pad][taps][Cin]
+struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (default) or fp32 (fp32 precision mode)
+    const void* in;        // activations
+    const void* w;         // [Cout_pad][taps][Cin]
     const float* bias;     // fp32 [Cout_pad]
-    void* out;             // bf16 or fp32
-    const uint16_t* res;   // bf16 residual or nullptr
-    uint16_t* out_relu;    // optional second output relu(out) (P6 -> P7 input) or nullptr
+    void* out;             // activation type, or fp32 with CONV_OUT_F32
+    const void* res;       // residual or nullptr
+    void* out_relu;        // optional second output relu(out) (P6 -> P7 input) or nullptr
     int32_t in_coff;       // channel offset inside an input pixel
     int32_t layer_id;      // dropout stream id (head*4 + layer)
 };
@@ -57,15 +57,16 @@ struct ConvArgs {
 };
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
 
 // ------------------------------------------------------------------------------------------------
 // Stem + pooling + small elementwise (aux_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 // 7x7 s2 VALID conv (fp32 image, fp32 folded weights [7][7][3][64]) + bias + ReLU -> bf16 [B,oh,ow,64]
-hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, uint16_t* out,
+hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s);
 // ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on bf16 [B,ih,iw,64] -> padded-plane bf16 output
-hipError_t launch_stem_pool(const uint16_t* in, uint16_t* out, int B, int ih, int iw, int oh, int ow,
+hipError_t launch_stem_pool(const void* in, void* out, int f32, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ _KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
 def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
                 dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
                 has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
-                num_categorical_draws=30, layers=(3, 4, 5, 6, 7)):
+                num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16'):
     """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
     into a ``bod_config``."""
     bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
@@ -42,6 +42,9 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
     cfg.nms_variant = {'A': 0, 'B': 1}[nms_variant]
     cfg.num_categorical_draws = int(num_categorical_draws)
     cfg.has_covar_head = int(bool(has_covar_head))
+    if precision not in ('bf16', 'fp32'):
+        raise ValueError("precision must be 'bf16' or 'fp32'")
+    cfg.precision = int(precision == 'fp32')
     if dataset_name == 'kitti':
         if orig_size is None:
             raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")
@@ -283,7 +286,7 @@ class Engine(object):
 
 
 def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=None, dropout_rate=0.0,
-               seed=0, layer_id=0, image_id=0, round_output_bf16=False, device=0):
+               seed=0, layer_id=0, image_id=0, round_output_bf16=False, device=0, precision='bf16'):
     """One convolution through the pipeline's MFMA kernel (``bod_stage_conv``), for parity tests.
     x [B,H,W,Cin], w HWIO; returns [B,OH,OW,Cout] float32."""
     lib = _lib.load()
@@ -301,6 +304,6 @@ def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=N
     residual = as_f32(residual) if residual is not None else None
     st = lib.bod_stage_conv(device, fptr(x), b, h, wd, cin, fptr(w), fptr(bias), kh, kw, cout, stride,
                             int(padding == "same"), int(relu), fptr(residual), float(dropout_rate), seed,
-                            layer_id, image_id, int(round_output_bf16), fptr(out))
+                            layer_id, image_id, int(round_output_bf16), int(precision == 'fp32'), fptr(out))
     _lib.check(lib, None, st)
     return out

@@ -28,7 +28,7 @@ def fill_triangular_4(x):
 
 
 class RetinaNetModel(object):
-    def __init__(self, model_config, device=0, batch=1, seed=0):
+    def __init__(self, model_config, device=0, batch=1, seed=0, precision='bf16'):
         self.model_config = model_config
         names = model_config['output_names']
         self.compute_cls = 'classification' in names
@@ -47,6 +47,7 @@ class RetinaNetModel(object):
         self.device = device
         self.batch = batch
         self.seed = seed
+        self.precision = precision        # 'bf16' (throughput) or 'fp32' (reference-exact arithmetic)
         self.image_counter = 0
         self.prediction_dict = None
         self._weights = None
@@ -81,10 +82,11 @@ class RetinaNetModel(object):
                              "ValueError for a missing checkpoint, run_inference.py:56-58)")
         batch = batch or self.batch
         n = mc_samples or self.mc_dropout_samples
-        key = (int(image_hw[0]), int(image_hw[1]), batch, n)
+        key = (int(image_hw[0]), int(image_hw[1]), batch, n, self.precision)
         cfg = make_config(image_hw, batch=batch, mc_samples=n, num_classes=self.num_classes + 1,
                           anchors_per_location=self.anchors_per_location, device=self.device,
-                          dropout_rate=self.dropout_rate, has_covar_head=self.compute_covar, **testing)
+                          dropout_rate=self.dropout_rate, has_covar_head=self.compute_covar,
+                          precision=self.precision, **testing)
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(cfg)

@@ -33,6 +33,7 @@ typedef enum {
 enum { BOD_RANK_SCORE = 0, BOD_RANK_JOINT_ENTROPY = 1 };
 enum { BOD_NMS_VARIANT_A = 0, BOD_NMS_VARIANT_B = 1 };      /* SURVEY.md App. A.8 */
 enum { BOD_HEAD_CLS = 0, BOD_HEAD_REG = 1, BOD_HEAD_COV = 2 };
+enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1 };
 
 /* Mirrors model_config / testing_config of src/retina_net/configs/retinanet_bdd_covar.yaml
  * (:61-143) plus the geometry the reference derives at run time. */
@@ -59,7 +60,10 @@ typedef struct {
     int32_t has_covar_head;      /* 'regression_covar' in output_names (retinanet_model.py:50)        */
     float   kitti_scale_h, kitti_scale_w; /* orig/net size; 0 => dataset != 'kitti'
                                     (inference_utils.py:147-167)                                      */
-    int32_t reserved[8];
+    int32_t precision;           /* BOD_PRECISION_BF16 (default, throughput path: bf16 storage + bf16 MFMA)
+                                    or BOD_PRECISION_FP32 (fp32 storage + exact-fp32 MFMA: matches the
+                                    reference's fp32 arithmetic end to end; ~1/10 of the speed)          */
+    int32_t reserved[7];
 } bod_config;
 
 /* Sizes the caller needs to allocate host buffers. */
@@ -181,12 +185,13 @@ bod_status bod_synchronize(bod_handle h);
  * feature_extractor.py:210-212).  dropout_rate > 0 applies the head-tower epilogue
  * (multitask_headers.py:102-116): batch item b plays MC sample b, pixel index = y*OW+x.
  * out [B,OH,OW,Cout] fp32; round_output_bf16 != 0 rounds it like a stored activation.
+ * precision = BOD_PRECISION_FP32 runs the fp32 twin of the kernel on unrounded fp32 operands.
  * Errors are reported through bod_last_error(NULL). */
 bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                           const float* w, const float* bias, int32_t KH, int32_t KW, int32_t Cout,
                           int32_t stride, int32_t same_padding, int32_t relu, const float* residual,
                           float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
-                          int32_t round_output_bf16, float* out);
+                          int32_t round_output_bf16, int32_t precision, float* out);
 
 /* Kernel micro-benchmark (tests/tools): re-launches the handle's layer-`layer` head-tower conv
  * (0 = de-duplicated fan-out layer, 1..3 = per-sample layers) `iters` times on the handle's own

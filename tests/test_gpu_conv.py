@@ -140,3 +140,35 @@ def test_alternative_schedules_are_bit_identical(schedule):
             outs.append(np.load(path))
     assert np.array_equal(outs[0], outs[1])
     assert (outs[0][0] == 0).mean() > 0.25          # dropout really applied
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,padding", CASES[:10])
+def test_fp32_conv_matches_oracle(b, h, w, cin, cout, k, stride, padding):
+    """fp32 precision mode: unrounded fp32 operands through v_mfma_f32_32x32x2_f32 vs float64."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(cin + cout + k + w)
+    x, wt, bias = _case(rng, b, h, w, cin, cout, k)
+    got = stage_conv(x, wt, bias, stride=stride, padding=padding, precision="fp32")
+    ref = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), stride, padding)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert rel_err(got, ref, floor=rms) < 2e-5          # fp32 accumulation over up to K=4608 terms
+
+
+def test_fp32_conv_residual_relu_dropout():
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network, philox
+    rng = np.random.default_rng(8)
+    b, h, w = 2, 7, 9
+    x, wt, bias = _case(rng, b, h, w, 128, 256, 3)
+    res = rng.normal(0, 1, (b, h, w, 256)).astype(np.float32)
+    got = stage_conv(x, wt, bias, padding="same", relu=True, residual=res, precision="fp32")
+    ref = np.maximum(network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same") + res, 0)
+    assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 2e-5
+    got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=0.3, seed=11, layer_id=2, image_id=5,
+                     precision="fp32")
+    keep = np.stack([philox.dropout_keep_mask(11, 5, s, 2, h * w, 256, 0.3).reshape(h, w, 256) for s in range(b)])
+    ref = np.maximum(network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same"), 0)
+    ref = ref * np.float64(np.float32(1.0 / 0.7)) * keep
+    assert np.all(got[~keep] == 0)
+    assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 2e-5

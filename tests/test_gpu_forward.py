@@ -99,3 +99,30 @@ def test_geometry_mismatch_is_rejected():
     from bayes_od_rc_amd.engine import Engine, make_config
     with pytest.raises(ValueError):
         Engine(make_config((100, 100), batch=1, mc_samples=2))
+
+
+@pytest.mark.parametrize("hw,batch,n", [((128, 128), 2, 3), ((96, 160), 1, 1)])
+def test_fp32_mode_end_to_end(hw, batch, n):
+    """precision='fp32' (fp32 storage + exact-fp32 MFMA): the whole forward pass -- stem, 53 backbone
+    convs, FPN, MC-dropout heads -- agrees with the float64 oracle element-wise within the 1e-3 bar of
+    BASELINE.json's north_star (observed ~1e-5, fp32 summation noise through ~50 layers)."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    seed, first = 99, 3
+    w = synthetic.make_weights()
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision="fp32"))
+    eng.load_weights(w)
+    eng.forward(frames, seed=seed, first_image_id=first)
+    cls, box, cov = eng.get_raw()
+    pyr = [eng.get_pyramid(l) for l in range(5)]
+    for b in range(batch):
+        _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P)
+        items = [("P%d" % (l + 3), pyr[l][b], f64["_pyramid"][l][0]) for l in range(5)]
+        items += [("cls", cls[b], f64["anchors_class_predictions"]), ("box", box[b], f64["anchors_box_predictions"]),
+                  ("cov", cov[b], f64["_covar_params"])]
+        for name, got, t in items:
+            rms = _rms(t)
+            err = float(np.max(np.abs(got - t) / (np.abs(t) + rms)))
+            assert err < 1e-3, (name, err)
+            assert _rms(got - t) / rms < 1e-4, (name, _rms(got - t) / rms)

@@ -148,3 +148,52 @@ def test_async_pipeline_equals_synchronous():
             k = a["num"][img]
             for key in ("scores", "means", "covs", "counts"):
                 assert np.array_equal(a[key][img, :k], b[key][img, :k])
+
+
+def test_fp32_pipeline_matches_oracle_end_to_end():
+    """fp32 precision mode, whole pipeline against the float64 oracle run from the raw frame: same
+    kept anchors, same soft-NMS centres, detections within 1e-3 (images whose categorical draw or
+    centre ordering sits on a float rounding boundary are skipped, they are covered stage-wise)."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.model import RetinaNetModel
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.inference_utils import BayesOdPipeline
+    from oracle import bayes_od, philox, network, nms, clustering, geometry
+    hw, batch, n, seed = (128, 128), 2, 4, 31
+    cfg = {"output_names": ["classification", "regression", "regression_covar"], "mc_dropout_samples": n,
+           "header": {"dropout_rate": 0.3, "num_classes": 7, "anchors_per_location": 9}}
+    w = synthetic.make_weights(cls_fg_bias=-1.0)
+    model = RetinaNetModel(cfg, precision="fp32")
+    model.load_weights(w)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    pipe = BayesOdPipeline(model, hw, batch, BAYES_CFG, NMS_CFG, use_full_covar=True, anchors=anchors)
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=40)
+    dets = pipe(frames, seed=seed, first_image_id=0)
+    eng = pipe.engine
+    checked = 0
+    for b in range(batch):
+        km = lambda s, lid: philox.dropout_keep_mask(seed, b, s, lid, eng.P, 256, 0.3)
+        pred = network.retinanet_forward(w, frames[b][None], n, 8, mode="literal", dtype=np.float64, keep_masks=km)
+        u = philox.categorical_uniforms(seed, b, eng.A)
+        post = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64)
+        got = eng.get_posterior(b)
+        if not np.array_equal(np.nonzero(post["keep"])[0], got["anchor_index"]):
+            continue
+        assert rel_err(got["means"], post["means"][:, :, 0], 1.0) < REL_TOL
+        floor = np.abs(post["covs"]).reshape(len(post["covs"]), -1).max(axis=1)[:, None, None] * 1e-2
+        assert (np.abs(got["covs"] - post["covs"]) / (np.abs(post["covs"]) + floor)).max() < REL_TOL
+        corners = post["corners"].astype(np.float32)
+        idx, _ = nms.soft_nms(corners, post["ranking"].astype(np.float32), 100, 0.5, 0.5)
+        if not np.array_equal(idx, eng.get_nms(b)):
+            continue
+        iou = geometry.bbox_iou_vuvu(post["corners"], post["corners"])
+        s, mu, cv, cn, margins = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx,
+                                                                iou, 0.5, return_margins=True)
+        ok = margins > 1e-6
+        scores, means, covs, counts = dets[b]
+        assert rel_err(means[ok], mu[ok][:, :, 0], 1.0) < REL_TOL
+        floor = np.abs(cv).reshape(len(cv), -1).max(axis=1)[:, None, None] * 1e-2
+        assert (np.abs(covs - cv) / (np.abs(cv) + floor))[ok].max() < REL_TOL
+        assert rel_err(scores[ok], s[ok], 1e-6) < REL_TOL
+        checked += 1
+    assert checked >= 1
