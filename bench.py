@@ -29,6 +29,7 @@ BAYES_CFG = {"ranking_method": "score", "dirichlet_prior": {"type": "non_informa
 NMS_CFG = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TFLOPS = 157.3       # f32-in MFMA = fp32 vector rate (fp32 precision mode)
 # cls foreground bias calibrated so that 500 <= M <= 1500 anchors survive the background filter
 # at 512x512 with synthetic.make_weights() (python bench.py --calibrate)
 CALIBRATED_FG_BIAS = -3.2
@@ -103,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true", help="print the cls foreground bias for M~1000")
     ap.add_argument("--fg-bias", type=float, default=CALIBRATED_FG_BIAS)
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
+                    help="bf16 = throughput path (BASELINE.json north_star); fp32 = reference-exact arithmetic mode")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +131,7 @@ def main():
     weights = synthetic.make_weights(cls_fg_bias=args.fg_bias)
     anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
     eng = Engine(make_config(hw, batch=B, mc_samples=n, device=local_rank, bayes_od_config=BAYES_CFG,
-                             nms_config=NMS_CFG, use_full_covar=True))
+                             nms_config=NMS_CFG, use_full_covar=True, precision=args.precision))
     eng.load_weights(weights)
     eng.set_anchors(anchors)
     # this rank's shard of a (world*B)-frame synthetic clip, resident in HBM before timing starts
@@ -209,9 +212,21 @@ def main():
     algo_flops = head_flops_per_image(eng.P, n) * B * prof_steps
     assert abs(algo_flops - prof["head_conv_flops"]) / algo_flops < 1e-6
     achieved = algo_flops / (prof["head_conv_ms"] * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    # MI355X_MICROARCH.md prescribes) when they were taken on this exact configuration, else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_head_conv_pmc.json")) as fp:
+            pmc = json.load(fp)
+        c = pmc["config"]
+        if (c["height"], c["width"], c["mc_samples"], c["batch"]) == (hw[0], hw[1], n, B) and args.precision == "bf16":
+            traffic = pmc["avg_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (head 3x3 256->256 towers)",
-                "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(prof["head_conv_ms"] / launches, 4), "launches_per_step": launches // prof_steps,
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
     post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
@@ -219,7 +234,7 @@ def main():
     out = {"metric": "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency",
            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
            "data": "synthetic",
            "config": {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, full BayesOD "
                                   "pipeline (forward+posterior+soft-NMS+cluster-fuse)" % (n, hw[0], hw[1]),
