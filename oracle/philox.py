@@ -48,8 +48,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def drop_threshold(rate):
-    """keep iff word >= floor(rate * 2**32)  (P[keep] = 1 - rate to within 2**-32)."""
-    return np.uint32(int(np.floor(float(rate) * 4294967296.0)))
+    """keep iff word >= floor(float32(rate) * 2**32).  The rate is taken as float32, as tf.nn.dropout
+    compares its float32 uniforms with ``rate`` cast to the tensor dtype (0.3 -> 0.30000001192...)."""
+    return np.uint32(int(np.floor(float(np.float32(rate)) * 4294967296.0)))
 
 
 def dropout_keep_mask(seed, image_id, sample, layer_id, num_pixels, channels, rate):

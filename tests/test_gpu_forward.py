@@ -126,3 +126,33 @@ def test_fp32_mode_end_to_end(hw, batch, n):
             err = float(np.max(np.abs(got - t) / (np.abs(t) + rms)))
             assert err < 1e-3, (name, err)
             assert _rms(got - t) / rms < 1e-4, (name, _rms(got - t) / rms)
+
+
+@pytest.mark.parametrize("hw", [(192, 624), (360, 640)])
+def test_non_square_and_odd_pyramids(hw):
+    """Half-scale versions of BASELINE config 4 (KITTI 384x1248 -> 192x624: odd level widths 78/39/20/10/5)
+    and of the real BDD frame (720x1280 -> 360x640: 45->23->12->6->3, nearest up-sampling with a
+    non-integer ratio, stride-2 SAME on odd sizes).  fp32 mode against the float64 oracle, 1e-3."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    n, seed = 2, 17
+    w = synthetic.make_weights()
+    frames = synthetic.make_frames(1, hw[0], hw[1], seed=9)
+    eng = Engine(make_config(hw, batch=1, mc_samples=n, precision="fp32"))
+    eng.load_weights(w)
+    eng.forward(frames, seed=seed, first_image_id=0)
+    cls, box, cov = eng.get_raw()
+    _, f64 = _oracles(w, frames[0], n, seed, 0, eng.P)
+    assert [tuple(p.shape[1:3]) for p in f64["_pyramid"]] == eng.levels
+    for l in range(5):
+        t = f64["_pyramid"][l][0]
+        assert float(np.max(np.abs(eng.get_pyramid(l)[0] - t) / (np.abs(t) + _rms(t)))) < 1e-3, l
+    for got, key in ((cls[0], "anchors_class_predictions"), (box[0], "anchors_box_predictions"), (cov[0], "_covar_params")):
+        t = f64[key]
+        assert float(np.max(np.abs(got - t) / (np.abs(t) + _rms(t)))) < 1e-3, key
+    # and the bf16 path stays at its noise floor on the same geometry
+    eng16 = Engine(make_config(hw, batch=1, mc_samples=n))
+    eng16.load_weights(w)
+    eng16.forward(frames, seed=seed, first_image_id=0)
+    c16 = eng16.get_raw()[0][0]
+    assert _rms(c16 - f64["anchors_class_predictions"]) / _rms(f64["anchors_class_predictions"]) < 2e-2
