@@ -15,6 +15,7 @@ SOURCES = [
     ("aux_kernels.hip", []),
     # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
     ("post_kernels.hip", ["-ffp-contract=off"]),
+    ("loss_kernels.hip", ["-ffp-contract=off"]),
     ("engine.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

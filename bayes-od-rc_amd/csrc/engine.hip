@@ -1214,6 +1214,60 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     return done(run());
 }
 
+bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
+                            const float* box, const float* box_t, const float* cov, const float* anchors,
+                            const uint8_t* pos, const uint8_t* neg, int32_t do_cls, int32_t reg_kind,
+                            float label_smoothing, double* out4) {
+    bod_context ctx;
+    bod_context* h = &ctx;
+    auto done = [&](bod_status s) {
+        if (s != BOD_OK) g_create_error = h->err;
+        if (h->stream) hipStreamSynchronize(h->stream);
+        for (void* p : h->allocs) hipFree(p);
+        if (h->stream) hipStreamDestroy(h->stream);
+        h->allocs.clear(); h->stream = nullptr;
+        return s;
+    };
+    if (B < 1 || A < 1 || (C != 4 && C != 8) || !pos || !neg || !out4 || reg_kind < 0 || reg_kind > 3)
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_loss_forward: bad argument (C must be 4 or 8)"));
+    if ((do_cls && (!cls || !cls_t)) || (reg_kind && (!box || !box_t)) || (reg_kind >= 2 && (!cov || !anchors)))
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_loss_forward: a tensor required by the selected losses is NULL"));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return done(h->fail(BOD_ERR_NO_DEVICE, "no HIP device %d: libbayesod_hip has no CPU fallback", device));
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return done(h->fail(BOD_ERR_HIP, "cannot set up device %d", device));
+    auto run = [&]() -> bod_status {
+        const size_t n = (size_t)B * A;
+        LossArgs a{};
+        a.B = B; a.A = A; a.C = C; a.do_cls = do_cls; a.reg_kind = reg_kind; a.label_smoothing = label_smoothing;
+        auto up = [&](const void* src, size_t bytes, const void** dst) -> bod_status {
+            if (!src) { *dst = nullptr; return BOD_OK; }
+            char* d = nullptr;
+            BODCHK(h->dalloc(&d, bytes, false));
+            HIPCHK(h, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream));
+            *dst = d;
+            return BOD_OK;
+        };
+        BODCHK(up(cls, n * C * 4, (const void**)&a.cls)); BODCHK(up(cls_t, n * C * 4, (const void**)&a.cls_t));
+        BODCHK(up(box, n * 16, (const void**)&a.box)); BODCHK(up(box_t, n * 16, (const void**)&a.box_t));
+        BODCHK(up(cov, n * 40, (const void**)&a.cov)); BODCHK(up(anchors, (size_t)A * 16, (const void**)&a.anchors));
+        BODCHK(up(pos, n, (const void**)&a.pos)); BODCHK(up(neg, n, (const void**)&a.neg));
+        const int nblocks = (int)((n + 255) / 256);
+        float* partial = nullptr;
+        BODCHK(h->dalloc(&partial, (size_t)nblocks * 4));
+        HIPCHK(h, launch_loss(a, partial, nblocks, h->stream));
+        std::vector<float> hp((size_t)nblocks * 4);
+        HIPCHK(h, hipMemcpyAsync(hp.data(), partial, hp.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int q = 0; q < 4; ++q) out4[q] = 0.0;
+        for (int b = 0; b < nblocks; ++b)
+            for (int q = 0; q < 4; ++q) out4[q] += (double)hp[(size_t)b * 4 + q];
+        return BOD_OK;
+    };
+    return done(run());
+}
+
 bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters, double* mean_ms, double* flops) {
     if (!h || !mean_ms || iters < 1 || layer < 0 || layer > 3) return BOD_ERR_INVALID_ARG;
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");

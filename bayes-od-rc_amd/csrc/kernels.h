@@ -134,3 +134,19 @@ struct ClusterArgs {
 };
 hipError_t launch_cluster_fuse(const ClusterArgs& a, hipStream_t s);
 hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Loss forward (loss_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+struct LossArgs {
+    int32_t B, A, C;
+    int32_t do_cls;          // focal classification term
+    int32_t reg_kind;        // 0 none, 1 'regression', 2 'regression_var', 3 'regression_covar'
+    float label_smoothing;
+    const float* cls; const float* cls_t;       // [B,A,C]
+    const float* box; const float* box_t;       // [B,A,4]
+    const float* cov;                           // [B,A,10] fill_triangular parameters
+    const float* anchors;                       // [A,4]
+    const uint8_t* pos; const uint8_t* neg;     // [B,A]
+};
+hipError_t launch_loss(const LossArgs& a, float* partial, int nblocks, hipStream_t s);

@@ -128,6 +128,61 @@ class RetinaNetModel(object):
 
     call = __call__
 
+    _REG_KIND = {'regression': 1, 'regression_var': 2, 'regression_covar': 3}
+
     def get_loss(self, sample_dict, prediction_dict):
-        raise NotImplementedError("losses belong to the training step (SURVEY.md section 8f-1), "
-                                  "not to the inference hot path")
+        """Loss FORWARD with the reference's signature and return value ``(total_loss, loss_dict)``
+        (retinanet_model.py:151-328; keys src/core/constants.py:66-71), evaluated on the device.
+        The backward pass / optimizer belong to the training step."""
+        import ctypes as C
+        from . import _lib
+        losses = self.model_config['losses']
+        names, weights = list(losses['loss_names']), list(losses['loss_weights'])
+        for n in names:
+            if n != 'classification' and n not in self._REG_KIND:
+                raise ValueError('Invalid Loss! Not implemented yet.', n)
+        reg = [n for n in names if n in self._REG_KIND]
+        if len(reg) > 1:
+            raise ValueError("only one regression loss can be active")
+        cls = _lib.as_f32(prediction_dict[constants.ANCHORS_CLASS_PREDICTIONS_KEY])
+        box = _lib.as_f32(prediction_dict[constants.ANCHORS_BOX_PREDICTIONS_KEY])
+        b, a, c = cls.shape
+        cov = None
+        kind = self._REG_KIND[reg[0]] if reg else 0
+        if kind >= 2:
+            m = _lib.as_f32(prediction_dict[constants.ANCHORS_COVAR_PREDICTIONS_KEY])
+            if m.shape[-2:] == (4, 4):           # undo fill_triangular (retinanet_model.py:110)
+                idx = {4: (0, 0), 8: (1, 0), 9: (1, 1), 7: (2, 0), 6: (2, 1), 5: (2, 2), 3: (3, 0), 2: (3, 1), 1: (3, 2), 0: (3, 3)}
+                cov = np.stack([m[..., idx[k][0], idx[k][1]] for k in range(10)], axis=-1)
+            else:
+                cov = m
+            cov = np.ascontiguousarray(cov, dtype=np.float32)
+        anchors = _lib.as_f32(np.asarray(sample_dict[constants.ANCHORS_KEY]).reshape(-1, 4))
+        pos = np.ascontiguousarray(np.asarray(sample_dict[constants.POSITIVE_ANCHORS_MASK_KEY]).reshape(b, a), dtype=np.uint8)
+        neg = np.ascontiguousarray(np.asarray(sample_dict[constants.NEGATIVE_ANCHOR_MASK_KEY]).reshape(b, a), dtype=np.uint8)
+        cls_t = _lib.as_f32(sample_dict[constants.ANCHORS_CLASS_TARGETS_KEY]).reshape(b, a, c)
+        box_t = _lib.as_f32(sample_dict[constants.ANCHORS_BOX_TARGETS_KEY]).reshape(b, a, 4)
+        out = (C.c_double * 4)()
+        lib = _lib.load()
+        u8 = C.POINTER(C.c_uint8)
+        st = lib.bod_loss_forward(self.device, b, a, c, _lib.fptr(cls), _lib.fptr(cls_t), _lib.fptr(box), _lib.fptr(box_t),
+                                  _lib.fptr(cov), _lib.fptr(anchors), pos.ctypes.data_as(u8), neg.ctypes.data_as(u8),
+                                  int('classification' in names), kind,
+                                  float(losses.get('label_smoothing_epsilon', 0.001)), out)
+        _lib.check(lib, None, st)
+        s_cls, s_cmp, s_reg, n_pos = out[0], out[1], out[2], out[3]
+        denom = max(n_pos, 1.0)
+        total, loss_dict = 0.0, {}
+        for n in names:
+            w = float(weights[names.index(n)])
+            if n == 'classification':
+                loss_dict['cls_loss'] = s_cls / denom * w
+                total += loss_dict['cls_loss']
+            elif n == 'regression':
+                loss_dict['reg_loss'] = s_cmp / denom * w
+                total += loss_dict['reg_loss']
+            else:
+                loss_dict['reg_loss'] = s_cmp / denom
+                loss_dict['covariance_loss'] = s_reg / denom
+                total += w * (s_cmp + s_reg) / denom
+        return total, loss_dict

@@ -193,6 +193,19 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
                           int32_t round_output_bf16, int32_t precision, float* out);
 
+/* model.get_loss(sample_dict, prediction_dict) forward (retinanet_model.py:151-328, core/losses.py:30-61;
+ * BASELINE config 5's loss, forward only).  Host arrays: cls/cls_targets [B,A,C], box/box_targets [B,A,4],
+ * covar_params [B,A,10] (pre fill_triangular; may be NULL unless reg_kind >= 2), anchors [A,4],
+ * positive/negative masks [B,A] (bytes).  reg_kind: 0 none, 1 'regression', 2 'regression_var',
+ * 3 'regression_covar'.  out4 = {sum of masked focal terms, sum of positive regression terms,
+ * sum of positive 0.5*sum(log D) terms, number of positives}; the caller applies the
+ * /max(num_pos,1) normalisation and the yaml loss weights. Errors via bod_last_error(NULL). */
+bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls,
+                            const float* cls_targets, const float* box, const float* box_targets,
+                            const float* covar_params, const float* anchors, const uint8_t* positive_mask,
+                            const uint8_t* negative_mask, int32_t do_classification, int32_t reg_kind,
+                            float label_smoothing, double* out4);
+
 /* Kernel micro-benchmark (tests/tools): re-launches the handle's layer-`layer` head-tower conv
  * (0 = de-duplicated fan-out layer, 1..3 = per-sample layers) `iters` times on the handle's own
  * buffers and returns the mean duration; `variant` selects an ablation build of the kernel
