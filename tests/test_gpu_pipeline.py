@@ -197,3 +197,26 @@ def test_fp32_pipeline_matches_oracle_end_to_end():
         assert rel_err(scores[ok], s[ok], 1e-6) < REL_TOL
         checked += 1
     assert checked >= 1
+
+
+def test_run_inference_cli_writes_reference_layout(tmp_path, monkeypatch):
+    """run_inference with the reference's flags on synthetic frames: directory layout and per-frame
+    files of run_inference.py:90-115,174-251."""
+    import json
+    import os
+    monkeypatch.setenv("BAYESOD_DATA_DIR", str(tmp_path))
+    from bayes_od_rc_amd import run_inference
+    root = run_inference.main(["--gpu_device", "0", "--data_split", "test", "--synthetic", "4",
+                               "--image_size", "128", "128", "--batch", "2"])
+    assert root.endswith(os.path.join("predictions", "testing", "bdd", "101", "bayes_od_none"))
+    for i in range(4):
+        mean = np.load(os.path.join(root, "mean", "%06d.npy" % i))
+        cov = np.load(os.path.join(root, "cov", "%06d.npy" % i))
+        par = np.load(os.path.join(root, "cat_param", "%06d.npy" % i))
+        cnt = np.load(os.path.join(root, "cat_count", "%06d.npy" % i))
+        k = mean.shape[0]
+        assert mean.shape == (k, 4) and cov.shape == (k, 4, 4) and par.shape == (k, 8) and cnt.shape == (k, 8)
+    recs = json.load(open(os.path.join(root, "data", "predictions.json")))
+    assert isinstance(recs, list)
+    for r in recs[:5]:
+        assert set(r) == {"name", "timestep", "category", "bbox", "score"} and len(r["bbox"]) == 4
