@@ -67,7 +67,8 @@ struct ConvCfg {
     static constexpr int OFF_RES = OFF_OUT + BP * 4;     // int   [BP] residual pixel
     static constexpr int OFF_RNG = OFF_RES + BP * 4;     // int2  [BP] dropout counters
     static constexpr int OFF_BIAS = OFF_RNG + BP * 8;    // float [BC]
-    static constexpr int LDS = OFF_BIAS + BC * 4;
+    static constexpr int OFF_OUT2 = OFF_BIAS + BC * 4;   // int   [BP] dense row of the fused 1x1 output
+    static constexpr int LDS = OFF_OUT2 + BP * 4;
 };
 
 // ABL: 0 = production; 1 = no epilogue; 2 = no global->LDS traffic after the first tile;
@@ -94,6 +95,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
     int* s_res = reinterpret_cast<int*>(smem + Cfg::OFF_RES);
     int2* s_rng = reinterpret_cast<int2*>(smem + Cfg::OFF_RNG);
     float* s_bias = reinterpret_cast<float*>(smem + Cfg::OFF_BIAS);
+    int* s_off2 = reinterpret_cast<int*>(smem + Cfg::OFF_OUT2);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,6 +135,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         s_off[i] = m < a.M ? e0.z : -1;
         s_res[i] = e0.w;
         s_rng[i] = *(reinterpret_cast<const int2*>(&a.rows[mm]) + 2);
+        s_off2[i] = a.rows[mm].pad0;
     }
     for (int i = tid; i < BC; i += THREADS) s_bias[i] = G.bias[bc0 + i];
 
@@ -364,6 +367,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // fused 1x1 head conv: wave w owns cout2 fragment w/2 and pixel fragments (w&1)*HALFP.. of the tile;
+    // its 16 weight fragments (64 VGPRs) are fetched now and land while phase B (Philox, LDS writes) runs
+    constexpr bool CAN_FUSE = (BC == 256) && (BP % 64 == 0) && (WC * WP == 8);
+    constexpr int HALFP = BP / 64;               // pixel fragments per wave in the fused conv
+    const bool fuse = CAN_FUSE && G.w2 != nullptr;
+    const int f2 = wave >> 1;
+    const bool fuse_active = fuse && f2 * 32 < G.cout2;
+    bf16x8 w2f[16];
+    const uint16_t* wp2 = reinterpret_cast<const uint16_t*>(G.w2) + (size_t)(f2 * 32 + frow) * 256 + fhalf * 8;
+    if (fuse_active) {                          // first half now, second half after the barrier (register budget)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w2f[ks] = *reinterpret_cast<const bf16x8*>(wp2 + ks * 16);
+    }
     if (ABL == 31) {
 #pragma unroll
         for (int j = 0; j < FP; ++j)
@@ -412,6 +428,40 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         }
         __syncthreads();
         if (ABL == 52) continue;
+        if (fuse) {
+            if (fuse_active) {
+#pragma unroll
+                for (int ks = 8; ks < 16; ++ks) w2f[ks] = *reinterpret_cast<const bf16x8*>(wp2 + ks * 16);
+#pragma unroll 1
+                for (int pf = (wave & 1) * HALFP; pf < (wave & 1) * HALFP + HALFP; ++pf) {
+                    const int pixl = pf * 32 + frow;
+                    const char* prow = smem + pixl * (BC * 2);
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(prow + ((((ks * 2 + fhalf) ^ pixl) & (CPR - 1)) << 4));
+                        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ks], xb, y, 0, 0, 0);
+                    }
+                    if (s_off[pixl] < 0) continue;
+                    float* orow = G.out2 + (size_t)s_off2[pixl] * G.out2_cstride;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int co2 = f2 * 32 + g4 * 8 + fhalf * 4;
+                        if (co2 >= G.cout2) continue;
+                        const float4 b2 = *reinterpret_cast<const float4*>(G.bias2 + co2);
+                        const float v0 = y[g4 * 4 + 0] + b2.x, v1 = y[g4 * 4 + 1] + b2.y;
+                        const float v2 = y[g4 * 4 + 2] + b2.z, v3 = y[g4 * 4 + 3] + b2.w;
+                        if (co2 + 1 < G.cout2) *reinterpret_cast<float2*>(orow + co2) = make_float2(v0, v1);
+                        else orow[co2] = v0;
+                        if (co2 + 3 < G.cout2) *reinterpret_cast<float2*>(orow + co2 + 2) = make_float2(v2, v3);
+                        else if (co2 + 2 < G.cout2) orow[co2 + 2] = v2;
+                    }
+                }
+            }
+            continue;                                 // the tile itself has no other consumer
+        }
 #pragma unroll 4
         for (int q = tid; q < BP * CPR; q += THREADS) {
             const int pixl = q / CPR, cp = q % CPR;
@@ -498,9 +548,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
-    if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
+bool conv_igemm_uses_full_cout_tile(const ConvArgs& a) {
     // 256x256 tiles once there are enough pixel tiles to fill the chip; BOD_FORCE_CONV_TILE=256|128
     // overrides the size heuristic (tests exercise both configurations on small inputs)
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
@@ -510,6 +558,19 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.fan_count > 1) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
     if (forced == 128) big = false;
+    return big && a.cout_pad == 256;
+}
+
+hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
+    static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
+    bool big = a.cout_pad % 256 == 0 && a.M >= 16384 && !(a.flags & CONV_OUT_F32);
+    if (a.fan_count > 1) big = false;
+    if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
+    if (forced == 128) big = false;
+    for (int g = 0; g < a.groups; ++g)
+        if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
     // BOD_CONV_SCHEDULE=stag|persist|stag_persist selects the experimental schedules of the 256x256
     // configuration for every eligible launch (bit-identical results; tests/test_gpu_conv.py)
     static const int env_sched = [] {

@@ -275,7 +275,7 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     BODCHK(make_table(h, key, B, in, out, stride, oy, ox, res, &tbl));
     Op op; op.kind = Op::CONV;
     op.conv = base_args(pc, tbl, B * out.h * out.w, in.C, out.C);
-    op.conv.g[0] = ConvGroup{in.d, pc.w, pc.bias, out.d, res ? res->d : nullptr, out_relu, 0, 0};
+    op.conv.g[0] = ConvGroup{in.d, pc.w, pc.bias, out.d, res ? res->d : nullptr, out_relu, 0, 0, nullptr, nullptr, nullptr, 0, 0};
     op.conv.flags = relu ? CONV_RELU : 0;
     op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
     h->ops.push_back(op);
@@ -463,6 +463,7 @@ bod_status build_plan(bod_context* h) {
                             e.out_off = (int32_t)(plane0 + (int64_t)(y + 1) * pitch + (xq + 1));
                             e.rng_p = dense;
                             e.rng_zs = n | (b << 16);
+                            e.pad0 = (int32_t)(((int64_t)b * N + n) * h->P + dense);      // row of the fused 1x1 output
                             t2[r2] = e;
                             RowEnt f = e;
                             f.in_off = e.out_off;                 // 1x1 reads the centre pixel
@@ -486,6 +487,16 @@ bod_status build_plan(bod_context* h) {
     const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
     const int nheads = c.has_covar_head ? 3 : 2;
     // which heads are still running a tower conv at `layer`
+    // Fuse each head's 1x1 output conv into the epilogue of its last tower layer whenever that layer runs
+    // with the full 256-channel cout tile (bf16 mode, enough rows): the last tower activation then never
+    // goes to HBM and three launches disappear.  BOD_FUSE_HEAD_OUTPUT=0 keeps the separate launches.
+    bool fuse_out = h->es == 2;
+    if (const char* e = getenv("BOD_FUSE_HEAD_OUTPUT")) fuse_out = fuse_out && atoi(e) != 0;
+    {
+        ConvArgs probe{};
+        probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
+        fuse_out = fuse_out && conv_igemm_uses_full_cout_tile(probe);
+    }
     for (int layer = 0; layer < 4; ++layer) {
         Op op; op.kind = Op::CONV; op.is_head3x3 = true;
         int g = 0; PackedConv pc0{};
@@ -500,6 +511,14 @@ bod_status build_plan(bod_context* h) {
             cg.w = pc.w; cg.bias = pc.bias;
             cg.out = h->head_act[hd][layer & 1];
             cg.layer_id = hd * 4 + layer;
+            if (fuse_out && layer == kHeadConvs[hd] - 1) {
+                PackedConv po;
+                BODCHK(pack_conv(h, kHeadPrefix[hd], "", 32, &po));
+                if (po.cin != 256 || po.cout != out_ch[hd] || po.taps != 1)
+                    return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], po.cin, po.cout);
+                cg.w2 = po.w; cg.bias2 = po.bias; cg.out2 = h->raw[hd]; cg.cout2 = po.cout; cg.out2_cstride = out_ch[hd];
+                op.flops += 0;      // head-conv roofline accounting stays the 3x3 FLOPs only
+            }
             op.conv.g[g] = cg;
             if (g == 0) pc0 = pc;
             ++g;
@@ -516,14 +535,14 @@ bod_status build_plan(bod_context* h) {
         op.flops = 2.0 * M * 256.0 * 2304.0 * g;
         h->ops.push_back(op);
     }
-    for (int hd = 0; hd < nheads; ++hd) {
+    for (int hd = 0; hd < nheads && !fuse_out; ++hd) {
         PackedConv pc;
         BODCHK(pack_conv(h, kHeadPrefix[hd], "", 64, &pc));
         if (pc.cin != 256 || pc.cout != out_ch[hd] || pc.taps != 1)
             return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], pc.cin, pc.cout);
         Op op; op.kind = Op::CONV;
         ConvArgs a = base_args(pc, d3, B * N * h->P, 256, out_ch[hd]);
-        a.g[0] = ConvGroup{h->head_act[hd][(kHeadConvs[hd] - 1) & 1], pc.w, pc.bias, h->raw[hd], nullptr, nullptr, 0, 0};
+        a.g[0] = ConvGroup{h->head_act[hd][(kHeadConvs[hd] - 1) & 1], pc.w, pc.bias, h->raw[hd], nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0};
         a.flags = CONV_OUT_F32;
         op.conv = a;
         op.flops = 2.0 * a.M * pc.cout * 256.0;
@@ -1194,7 +1213,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         BODCHK(h->dalloc(&d_rows, rows.size(), false));
         HIPCHK(h, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
         ConvArgs a = base_args(pc, d_rows, B * OH * OW, Cin, Cout);
-        a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id};
+        a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id, nullptr, nullptr, nullptr, 0, 0};
         a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
         a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 4294967296.0);

@@ -18,7 +18,8 @@ struct RowEnt {            // 32 B per output pixel
     int32_t res_off;       // pixel index in the residual buffer (unused if no residual)
     int32_t rng_p;         // pixel index in the image's concatenated p3..p7 pyramid (dropout counter x)
     int32_t rng_zs;        // sample | image_in_batch << 16
-    int32_t pad0, pad1;
+    int32_t pad0;          // dense output row of the fused 1x1 head conv ((b*N+n)*P + p)
+    int32_t pad1;
 };
 
 struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (default) or fp32 (fp32 precision mode)
@@ -30,6 +31,13 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     void* out_relu;        // optional second output relu(out) (P6 -> P7 input) or nullptr
     int32_t in_coff;       // channel offset inside an input pixel
     int32_t layer_id;      // dropout stream id (head*4 + layer)
+    // Fused head output conv (1x1, 256 -> cout2) applied to this group's finished output tile while it
+    // is still in LDS; the tile itself is then not stored (nothing else reads the last tower layer).
+    const void* w2;        // bf16 [cout2 rounded up to 32][256] or nullptr
+    const float* bias2;    // fp32, padded like w2
+    float* out2;           // fp32 [rows][out2_cstride]; row index = RowEnt.pad0
+    int32_t cout2;         // real output channels (A*C, A*4, A*10)
+    int32_t out2_cstride;
 };
 
 enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4 };
@@ -57,6 +65,7 @@ struct ConvArgs {
 };
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
 
 // ------------------------------------------------------------------------------------------------

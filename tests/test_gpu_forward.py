@@ -156,3 +156,33 @@ def test_non_square_and_odd_pyramids(hw):
     eng16.forward(frames, seed=seed, first_image_id=0)
     c16 = eng16.get_raw()[0][0]
     assert _rms(c16 - f64["anchors_class_predictions"]) / _rms(f64["anchors_class_predictions"]) < 2e-2
+
+
+def test_fused_head_output_equals_separate_launches():
+    """The 1x1 head output convs fused into the last tower layer's epilogue (bf16 mode, 256-wide cout
+    tile) give the same raw head outputs as the separate 1x1 launches."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "eng = Engine(make_config((128, 160), batch=2, mc_samples=3))\n"
+            "eng.load_weights(synthetic.make_weights())\n"
+            "eng.forward(synthetic.make_frames(2, 128, 160, seed=6), seed=21, first_image_id=4)\n"
+            "c, b, v = eng.get_raw()\n"
+            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % root)
+    outs = []
+    for fuse in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_FUSE_HEAD_OUTPUT=fuse)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    for k in ("c", "b", "v"):
+        a, b = outs[0][k], outs[1][k]
+        assert a.shape == b.shape
+        assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max())), k
