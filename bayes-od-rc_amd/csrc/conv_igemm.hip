@@ -55,12 +55,15 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
     return lo | hi;
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int BC, int BP, int WC, int WP, bool XR = false>
 struct ConvCfg {
     static constexpr int THREADS = 64 * WC * WP;
     static constexpr int STAGE = (BC + BP) * 128;
     static constexpr int EP_BYTES = BP * BC * 2;
-    static constexpr int MAIN = (2 * STAGE > EP_BYTES) ? 2 * STAGE : EP_BYTES;
+    // row-reuse layout: 2 weight stages of BC rows + 2 extended-activation buffers of XR_EXT_ROWS rows
+    static constexpr int XR_BYTES = 2 * BC * 128 + 2 * XR_EXT_ROWS * 128;
+    static constexpr int STAGED = XR ? XR_BYTES : 2 * STAGE;
+    static constexpr int MAIN = (STAGED > EP_BYTES) ? STAGED : EP_BYTES;
     // after the staging / epilogue area: per-tile metadata read by the epilogue (kept out of registers
     // during the K loop and out of global memory in the epilogue)
     static constexpr int OFF_OUT = MAIN;                 // int   [BP] output pixel (-1 = invalid row)
@@ -77,9 +80,9 @@ struct ConvCfg {
 // SPLIT: only the upper half of the waves issues the global->LDS staging (2x the pieces each), so the
 //      lower half starts its MFMAs right after the barrier and the two waves of every SIMD run
 //      out of phase (the matrix pipe stays fed while the other wave issues loads / waits).
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG>
+template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, const int bx, const int by, char* smem) {
-    using Cfg = ConvCfg<BC, BP, WC, WP>;
+    using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = SPLIT ? THREADS / 2 : THREADS;   // threads that stage
     constexpr int RPI = LTHREADS / 8;            // tile rows covered by one staging instruction
@@ -183,7 +186,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
 
     int ky = 0, kx = 0, cc = 0;
     const int KH = a.taps / a.KW;
-    if (loader) issue(0, 0, 0, 0);
+    if (loader && !XR) issue(0, 0, 0, 0);
     int cur = 0;
     if constexpr (STAG) {
         // Staggered schedule (the two wave rows of the block run one barrier apart): every k-step is a
@@ -258,6 +261,79 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             }
         }
         if (!row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    } else if constexpr (XR) {
+        // Activation row reuse: per (channel chunk, ky) the tile's extended rows are staged ONCE and the
+        // three kx taps read them at row offsets 0/1/2; only the weights stream every K-tile.
+        static_assert(BC == 256 && BP == 256 && WC * WP == 8 && !SPLIT, "row reuse is written for the 256x256 8-wave tile");
+        constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
+        const char* xe[NXE];
+        int xep[NXE];
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int2 e = a.ext[(size_t)bx * XR_EXT_ROWS + i * (THREADS / 8) + (tid >> 3)];
+            xe[i] = reinterpret_cast<const char*>(G.in) + ((size_t)e.x * a.in_cstride + G.in_coff + ldchunk * 8) * 2;
+            xep[i] = e.y * a.in_cstride * 2;
+        }
+        int xrow[FP];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            int m = bp0 + wp * WTP + j * 32 + frow;
+            xrow[j] = a.rows[m].pad1;
+        }
+        auto issue_wx = [&](int stage, int ky_, int kx_, int cc_) {
+            const int woff = ((ky_ * 3 + kx_) * a.cin + cc_ * BK) * 2;
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wsrc[i] + woff), LDS_PTR(smem + stage * WST + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+        };
+        auto issue_xe = [&](int buf, int ky_, int cc_, int i0, int i1) {
+#pragma unroll
+            for (int i = 0; i < NXE; ++i)
+                if (i >= i0 && i < i1)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xe[i] + ky_ * xep[i] + cc_ * (BK * 2)),
+                                                     LDS_PTR(smem + 2 * WST + buf * XBUF + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weight / activation pieces issued by the generic prologue
+        __syncthreads();
+        issue_wx(0, 0, 0, 0);
+        issue_xe(0, 0, 0, 0, NXE);
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int g = cc * 3 + ky;
+            int nkx = kx + 1, nky = ky, ncc = cc;
+            if (nkx == 3) { nkx = 0; if (++nky == 3) { nky = 0; ++ncc; } }
+            if (kt + 1 < KT && ABL != 2) {
+                issue_wx((kt + 1) & 1, nky, nkx, ncc);
+                if (g + 1 < KT / 3) {                            // next (chunk, ky) group, a third per K-tile
+                    const int gky = ky + 1 < 3 ? ky + 1 : 0, gcc = ky + 1 < 3 ? cc : cc + 1;
+                    if (kx == 0) issue_xe((g + 1) & 1, gky, gcc, 0, 2);
+                    else if (kx == 1) issue_xe((g + 1) & 1, gky, gcc, 2, 4);
+                    else issue_xe((g + 1) & 1, gky, gcc, 4, NXE);
+                }
+            }
+            const char* wb = smem + (kt & 1) * WST + (wc * WTC + frow) * ROWB;
+            const char* xbase = smem + 2 * WST + (g & 1) * XBUF;
+            const char* xbj[FP];
+            int xsw[FP];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kx; xbj[j] = xbase + r * ROWB; xsw[j] = (r >> 1) & 7; }
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int ch = ((ks * 2 + fhalf) ^ fswz) << 4;
+                bf16x8 af[FC], bfr[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * ROWB + ch);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(xbj[j] + (((ks * 2 + fhalf) ^ xsw[j]) << 4));
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            kx = nkx; ky = nky; cc = ncc;
+        }
     } else
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,7 +560,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
 
 // One tile per workgroup.  XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous
 // range of pixel tiles so that neighbouring tiles (which share their 3x3 halo rows) share an L2.
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG>
+template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
 __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bx = blockIdx.x;
@@ -492,7 +568,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG>(a, blockIdx.z, bx, blockIdx.y, smem);
+    conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG, XR>(a, blockIdx.z, bx, blockIdx.y, smem);
 }
 
 // Persistent form: one workgroup per CU walks a contiguous range of (head, cout tile, pixel tile)
@@ -508,14 +584,14 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_persistent_kernel(con
     const int t0 = v * per, t1 = (t0 + per < total) ? t0 + per : total;
     for (int t = t0; t < t1; ++t) {
         const int z = t / (nx * ny), rem = t - z * (nx * ny);
-        conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG>(a, z, rem % nx, rem / nx, smem);
+        conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG, false>(a, z, rem % nx, rem / nx, smem);
         __syncthreads();                         // LDS (epilogue tile + metadata) is reused by the next tile
     }
 }
 
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT = false, bool STAG = false, bool PERSIST = false>
+template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT = false, bool STAG = false, bool PERSIST = false, bool XR = false>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-    using Cfg = ConvCfg<BC, BP, WC, WP>;
+    using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     static bool attr_set = false;
     const int nx = (a.M + BP - 1) / BP, ny = a.cout_pad / BC;
     if (PERSIST) {
@@ -536,7 +612,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::LDS, s, a, nx, ny, total);
         return hipGetLastError();
     }
-    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, SPLIT, STAG>;
+    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, SPLIT, STAG, XR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -581,6 +657,12 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     }();
     int variant = a.variant;
     if (variant == 0 && env_sched && big) variant = env_sched;
+    if (a.xreuse) {
+        if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
+        if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, false, false, false, true>(a, s);
+        if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);
+        return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
+    }
     switch (variant) {
         case 0: break;
         case 1: return launch_cfg<256, 256, 2, 4, 1>(a, s);

@@ -482,6 +482,46 @@ bod_status build_plan(bod_context* h) {
     HIPCHK(h, hipMemcpyAsync(d3, t3.data(), t3.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
+    // Activation row reuse for the per-sample 3x3 tower layers: re-pack the rows into 256-slot tiles made
+    // of runs of x-adjacent pixels and list each tile's extended input rows (kernels.h, ConvArgs::ext).
+    RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
+    bool xreuse = h->es == 2;
+    if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
+    {
+        ConvArgs probe{};
+        probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
+        xreuse = xreuse && conv_igemm_uses_full_cout_tile(probe);
+    }
+    if (xreuse) {
+        std::vector<RowEnt> tiled;
+        std::vector<int2> ext;
+        RowEnt invalid = t2[0];
+        invalid.out_off = -1; invalid.pad0 = 0; invalid.pad1 = 0;
+        size_t r = 0;
+        while (r < t2.size()) {
+            const size_t tile0 = tiled.size();
+            const size_t ext0 = ext.size();
+            int pix = 0, nx = 0;
+            while (r < t2.size() && pix < 256 && nx + 3 <= XR_EXT_ROWS) {
+                // maximal run of x-adjacent pixels starting at row r
+                size_t e = r + 1;
+                while (e < t2.size() && t2[e].in_off == t2[e - 1].in_off + 1 && t2[e].in_pitch == t2[r].in_pitch) ++e;
+                int take = (int)std::min<size_t>(e - r, (size_t)std::min(256 - pix, XR_EXT_ROWS - nx - 2));
+                for (int k = 0; k < take + 2; ++k) ext.push_back(int2{t2[r].in_off + k, t2[r].in_pitch});
+                for (int k = 0; k < take; ++k) { RowEnt q = t2[r + k]; q.pad1 = nx + k; tiled.push_back(q); }
+                nx += take + 2; pix += take; r += take;
+            }
+            while (tiled.size() < tile0 + 256) tiled.push_back(invalid);
+            while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(int2{0, 0});      // pixel 0 is a zero border pixel
+        }
+        m2x = (int)tiled.size();
+        BODCHK(h->dalloc(&d2x, tiled.size(), false));
+        BODCHK(h->dalloc(&dext, ext.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d2x, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+
     const bool mc = N > 1;                                  // mc_dropout_enabled (retinanet_model.py:74-77)
     const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 4294967296.0);
     const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
@@ -531,6 +571,7 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
+        if (xreuse && layer > 0) { a.rows = d2x; a.M = m2x; a.ext = dext; a.xreuse = 1; }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g;
         h->ops.push_back(op);

@@ -19,7 +19,7 @@ struct RowEnt {            // 32 B per output pixel
     int32_t rng_p;         // pixel index in the image's concatenated p3..p7 pyramid (dropout counter x)
     int32_t rng_zs;        // sample | image_in_batch << 16
     int32_t pad0;          // dense output row of the fused 1x1 head conv ((b*N+n)*P + p)
-    int32_t pad1;
+    int32_t pad1;          // extended-row index of this pixel inside its tile (activation row reuse)
 };
 
 struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (default) or fp32 (fp32 precision mode)
@@ -62,7 +62,15 @@ struct ConvArgs {
     uint32_t image_base;   // global id of image 0 of the batch
     int32_t groups;
     int32_t variant;       // 0 = production kernel; >0 = ablation / experimental builds (tests/tools)
+    // Activation row reuse (3x3 stride-1 convs, 256x256 tiles): `rows` is then organised in tiles of 256
+    // slots (invalid slots have out_off = -1) and `ext` lists, per tile, the XR_EXT_ROWS "extended" input
+    // pixels {pixel index for ky = 0, plane pitch}: every run of x-adjacent output pixels contributes its
+    // pixels plus one on either side, so the three kx taps read the SAME staged rows at offsets 0/1/2
+    // (RowEnt.pad1 = a pixel's extended-row index) and activations are staged once per (chunk, ky).
+    const int2* ext;
+    int32_t xreuse;
 };
+constexpr int XR_EXT_ROWS = 320;
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible

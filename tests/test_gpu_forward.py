@@ -186,3 +186,31 @@ def test_fused_head_output_equals_separate_launches():
         a, b = outs[0][k], outs[1][k]
         assert a.shape == b.shape
         assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max())), k
+
+
+def test_activation_row_reuse_is_bit_identical():
+    """Row-reuse staging of the 3x3 tower layers (extended rows shared by the three kx taps) changes
+    only how activations reach LDS, not a single bit of the result."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "eng = Engine(make_config((96, 160), batch=2, mc_samples=3))\n"
+            "eng.load_weights(synthetic.make_weights())\n"
+            "eng.forward(synthetic.make_frames(2, 96, 160, seed=8), seed=5, first_image_id=1)\n"
+            "c, b, v = eng.get_raw()\n"
+            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % root)
+    outs = []
+    for xr in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_CONV_XREUSE=xr)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    for k in ("c", "b", "v"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
