@@ -6,7 +6,7 @@
 //
 // Orientation: D[cout][pixel] = W[cout][k] * X[pixel][k].  Weights are the MFMA "A" operand and
 // pixels the "B" operand, so a lane's accumulator registers hold 4 CONSECUTIVE output channels of
-// one pixel and one Philox4x32 call yields exactly the 4 dropout decisions the lane needs.
+// one pixel; one Philox4x32 call yields the 8 dropout decisions of two such groups (contract v2).
 //
 // Both operands are K-contiguous (OHWI weights, NHWC activations), staged global->LDS with
 // 16-byte LDS-DMA (global_load_lds_dwordx4) into 128-byte rows, double-buffered, one barrier per
@@ -176,14 +176,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
     const int frow = lane & 31;
     const int fswz = (frow >> 1) & 7;
     const int fhalf = lane >> 5;
-    // Dropout decisions computed in the shadow of the matrix pipe: one Philox call per K-tile inside
-    // the memory segment of the staggered schedule (VALU is otherwise idle there), 4 keep-bits per
-    // (fragment, channel-group) packed into 4 registers and consumed by the epilogue.
-    constexpr int NGROUPS = FC * FP * 4;
-    uint32_t dmask[4] = {0u, 0u, 0u, 0u};
-    const bool rng_in_loop = STAG && NGROUPS <= 32 && (a.flags & CONV_DROPOUT) && a.fan_count <= 1 &&
-                             a.taps * (a.cin / BK) >= NGROUPS && ABL != 4;
-
     int ky = 0, kx = 0, cc = 0;
     const int KH = a.taps / a.KW;
     if (loader && !XR) issue(0, 0, 0, 0);
@@ -200,10 +192,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         const bool row1 = wc == 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int2 lrng[FP];
-#pragma unroll
-        for (int j = 0; j < FP; ++j) lrng[j] = s_rng[wp * WTP + j * 32 + frow];
-        PhiloxState pst{0u, 0u, 0u, 0u, 0u, 0u};
         if (row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         for (int kt = 0; kt < KT; ++kt) {
             const int st = kt & 1;
@@ -221,28 +209,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
                 for (int i = 0; i < FC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * ROWB + ch);
 #pragma unroll
                 for (int j = 0; j < FP; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(xb + j * 32 * ROWB + ch);
-                if (rng_in_loop && kt < NGROUPS) {
-                    // one Philox call per K-tile, its 10 rounds spread 3/2/3/2 over the four memory segments
-                    const int g = kt;
-                    if (ks == 0) {
-                        const int gi = g / (FP * 4), gj = (g >> 2) % FP, g4 = g & 3;
-                        const int col = wc * WTC + gi * 32 + g4 * 8 + fhalf * 4;
-                        int2 rj = lrng[0];
-#pragma unroll
-                        for (int j = 1; j < FP; ++j) rj = (gj == j) ? lrng[j] : rj;
-                        pst = PhiloxState{(uint32_t)rj.x, (uint32_t)(bc0 + col) >> 2,
-                                          ((uint32_t)rj.y & 0xFFFFu) | ((uint32_t)G.layer_id << 16),
-                                          a.image_base + ((uint32_t)rj.y >> 16), a.seed_lo, a.seed_hi};
-                    }
-                    philox_rounds(pst, (ks & 1) ? 2 : 3);
-                    if (ks == 3) {
-                        const uint32_t bits = (pst.c0 >= a.drop_threshold ? 1u : 0u) | (pst.c1 >= a.drop_threshold ? 2u : 0u) |
-                                              (pst.c2 >= a.drop_threshold ? 4u : 0u) | (pst.c3 >= a.drop_threshold ? 8u : 0u);
-                        const uint32_t sh = bits << ((g & 7) * 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) dmask[q] |= ((g >> 3) == q) ? sh : 0u;
-                    }
-                }
                 if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -479,24 +445,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             const uint32_t sample = a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rng[j].y & 0xFFFFu);
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
+                Philox4 rr{0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
                     uint2 o = pk[i][j][g4];
-                    if (drop && rng_in_loop) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int g = (i * FP + j) * 4 + g4;
-                        const uint32_t bits = dmask[g >> 3] >> ((g & 7) * 4);
-                        o.x &= ((bits & 1u) ? 0x0000FFFFu : 0u) | ((bits & 2u) ? 0xFFFF0000u : 0u);
-                        o.y &= ((bits & 4u) ? 0x0000FFFFu : 0u) | ((bits & 8u) ? 0xFFFF0000u : 0u);
-                    } else if (drop) {
-                        Philox4 r;
-                        if (ABL == 4 || ABL == 51 || ABL == 52) r = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
-                        else r = philox4x32_10((uint32_t)rng[j].x, (uint32_t)(bc0 + col) >> 2,
-                                               sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
-                        o.x &= (r.x >= a.drop_threshold ? 0x0000FFFFu : 0u) | (r.y >= a.drop_threshold ? 0xFFFF0000u : 0u);
-                        o.y &= (r.z >= a.drop_threshold ? 0x0000FFFFu : 0u) | (r.w >= a.drop_threshold ? 0xFFFF0000u : 0u);
-                        __builtin_amdgcn_sched_barrier(0);       // keep the Philox chains from interleaving (registers)
+                    if (drop) {
+                        // dropout contract v2: one Philox call decides 8 channels with 16-bit words -- the lane's
+                        // channel groups g4 = 2p and 2p+1 share the call keyed by (col>>5, p, fhalf)
+                        if ((g4 & 1) == 0) {
+                            if (ABL == 4 || ABL == 51 || ABL == 52) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
+                            else rr = philox4x32_10((uint32_t)rng[j].x, dropout_group8(bc0 + col),
+                                                    sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
+                        }
+                        const uint32_t w0 = (g4 & 1) ? rr.z : rr.x, w1 = (g4 & 1) ? rr.w : rr.y;
+                        o.x &= ((w0 & 0xFFFFu) >= a.drop_threshold ? 0x0000FFFFu : 0u) | ((w0 >> 16) >= a.drop_threshold ? 0xFFFF0000u : 0u);
+                        o.y &= ((w1 & 0xFFFFu) >= a.drop_threshold ? 0x0000FFFFu : 0u) | ((w1 >> 16) >= a.drop_threshold ? 0xFFFF0000u : 0u);
+                        if (g4 & 1) __builtin_amdgcn_sched_barrier(0);   // keep the Philox chains from interleaving (registers)
                     }
                     *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = o;
                 }

@@ -152,12 +152,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
                     if (drop) {
                         const uint32_t img = a.image_base + ((uint32_t)e1.y >> 16);
                         const uint32_t sample = a.fan_count > 1 ? (uint32_t)n : ((uint32_t)e1.y & 0xFFFFu);
-                        const Philox4 r = philox4x32_10((uint32_t)e1.x, (uint32_t)co >> 2,
+                        const Philox4 r = philox4x32_10((uint32_t)e1.x, dropout_group8((uint32_t)co),
                                                         sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
-                        w[0] = r.x >= a.drop_threshold ? v[0] * a.drop_scale : 0.f;
-                        w[1] = r.y >= a.drop_threshold ? v[1] * a.drop_scale : 0.f;
-                        w[2] = r.z >= a.drop_threshold ? v[2] * a.drop_scale : 0.f;
-                        w[3] = r.w >= a.drop_threshold ? v[3] * a.drop_scale : 0.f;
+                        const uint32_t w0 = (g4 & 1) ? r.z : r.x, w1 = (g4 & 1) ? r.w : r.y;   // decisions d = (g4&1)*4 + q
+                        w[0] = (w0 & 0xFFFFu) >= a.drop_threshold ? v[0] * a.drop_scale : 0.f;
+                        w[1] = (w0 >> 16) >= a.drop_threshold ? v[1] * a.drop_scale : 0.f;
+                        w[2] = (w1 & 0xFFFFu) >= a.drop_threshold ? v[2] * a.drop_scale : 0.f;
+                        w[3] = (w1 >> 16) >= a.drop_threshold ? v[3] * a.drop_scale : 0.f;
                     }
                     const size_t o = ((size_t)e0.z + (size_t)n * a.fan_stride) * a.out_cstride + co;
                     if (vec_ok) {

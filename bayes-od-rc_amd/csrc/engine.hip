@@ -523,7 +523,7 @@ bod_status build_plan(bod_context* h) {
     }
 
     const bool mc = N > 1;                                  // mc_dropout_enabled (retinanet_model.py:74-77)
-    const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 4294967296.0);
+    const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 65536.0);
     const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
     const int nheads = c.has_covar_head ? 3 : 2;
     // which heads are still running a tower conv at `layer`
@@ -1257,7 +1257,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id, nullptr, nullptr, nullptr, 0, 0};
         a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
-        a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 4294967296.0);
+        a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 65536.0);
         a.drop_scale = (float)(1.0 / (1.0 - (double)dropout_rate));
         HIPCHK(h, f32 ? launch_conv_igemm_f32(a, h->stream) : launch_conv_igemm(a, h->stream));
         if (f32_out) {

@@ -45,4 +45,10 @@ BOD_HD void philox_rounds(PhiloxState& s, int n) {
     }
 }
 
+// Dropout contract v2 (DESIGN.md "RNG contract"): a Philox call decides 8 channels with 16-bit words.
+// Channel c belongs to call group  (c>>5)*4 + ((c>>4)&1)*2 + ((c>>2)&1)  and uses decision
+// d = ((c>>3)&1)*4 + (c&3): 16-bit half (d&1) of word (d>>1).  (The 8 channels of a group are the two
+// 4-channel runs one MFMA lane holds in adjacent accumulator groups.)
+BOD_HD uint32_t dropout_group8(uint32_t c) { return (c >> 5) * 4u + ((c >> 4) & 1u) * 2u + ((c >> 2) & 1u); }
+
 #define BOD_CAT_TAG 0x00CA7E60u

@@ -9,11 +9,12 @@ experiments/inference_utils.py:37-46), which cannot be reproduced.  The build th
 identical random numbers:
 
 dropout   counter = (pixel p in the image's p3..p7 concatenated pyramid,
-                     channel group c//4,
+                     call group dropout_group8(c)   (8 channels per Philox call),
                      sample n | layer_id << 16,      layer_id = head*4 + layer, head cls/reg/cov = 0/1/2
                      image id)
           key     = (seed_lo, seed_hi)
-          word j of the result decides channel 4*(c//4)+j: keep iff word >= DROP_THRESHOLD(rate)
+          16-bit half d&1 of word d>>1 decides channel c (d = ((c>>3)&1)*4 + (c&3)):
+          keep iff u16 >= DROP_THRESHOLD(rate)
 
 categorical  counter = (anchor a, draw group g, CAT_TAG, image id); draw d = 4*g + j uses word j,
           u = (word >> 8) * 2**-24 in [0, 1)
@@ -48,20 +49,34 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def drop_threshold(rate):
-    """keep iff word >= floor(float32(rate) * 2**32).  The rate is taken as float32, as tf.nn.dropout
-    compares its float32 uniforms with ``rate`` cast to the tensor dtype (0.3 -> 0.30000001192...)."""
-    return np.uint32(int(np.floor(float(np.float32(rate)) * 4294967296.0)))
+    """keep iff u16 >= floor(float32(rate) * 2**16).  The rate is taken as float32, as tf.nn.dropout
+    compares its uniforms with ``rate`` cast to the tensor dtype; decisions use 16-bit words (contract v2),
+    so P[drop] = 19660/65536 = 0.29999 for rate 0.3."""
+    return np.uint32(int(np.floor(float(np.float32(rate)) * 65536.0)))
+
+
+def dropout_group8(c):
+    """Philox call group of channel c (contract v2; twin of csrc/philox.h)."""
+    c = np.asarray(c, dtype=np.uint64)
+    return (c >> np.uint64(5)) * np.uint64(4) + ((c >> np.uint64(4)) & np.uint64(1)) * np.uint64(2) + ((c >> np.uint64(2)) & np.uint64(1))
 
 
 def dropout_keep_mask(seed, image_id, sample, layer_id, num_pixels, channels, rate):
-    """bool [num_pixels, channels]: True where the activation is kept."""
-    assert channels % 4 == 0
+    """bool [num_pixels, channels]: True where the activation is kept.
+    Channel c uses decision d = ((c>>3)&1)*4 + (c&3) of call group dropout_group8(c): the 16-bit half (d&1)
+    of word (d>>1)."""
+    assert channels % 32 == 0
     p = np.arange(num_pixels, dtype=np.uint64)[:, None]
-    g = np.arange(channels // 4, dtype=np.uint64)[None, :]
+    c = np.arange(channels, dtype=np.uint64)
+    groups = np.arange(channels // 8, dtype=np.uint64)[None, :]
     z = np.uint64((int(sample) & 0xFFFF) | (int(layer_id) << 16))
-    words = philox4x32_10(p, g, z, np.uint64(image_id), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    keep = np.stack([w >= drop_threshold(rate) for w in words], axis=-1)  # [P, C/4, 4]
-    return keep.reshape(num_pixels, channels)
+    words = philox4x32_10(p, groups, z, np.uint64(image_id), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(words, axis=-1)                                              # [P, C/8, 4]
+    halves = np.stack([w & np.uint32(0xFFFF), w >> np.uint32(16)], axis=-1).reshape(num_pixels, channels // 8, 8)
+    keep8 = halves >= drop_threshold(rate)                                    # decision index d = word*2 + half
+    g = dropout_group8(c).astype(np.int64)
+    d = (((c >> np.uint64(3)) & np.uint64(1)) * np.uint64(4) + (c & np.uint64(3))).astype(np.int64)
+    return keep8[:, g, d]
 
 
 def categorical_uniforms(seed, image_id, num_anchors, num_draws=NUM_CAT_DRAWS):

@@ -28,15 +28,22 @@ def test_dropout_mask_contract():
                                  channels=256, rate=0.3)
     assert m.shape == (500, 256) and m.dtype == bool
     assert abs(m.mean() - 0.7) < 0.01
-    # element (p, c) uses word c%4 of philox(p, c//4, sample|layer<<16, image; seed)
-    w = philox.philox4x32_10(17, 33, 2 | (5 << 16), 3, 9, 7)
+    # channel c: decision d = ((c>>3)&1)*4 + (c&3) of call group (c>>5)*4 + ((c>>4)&1)*2 + ((c>>2)&1)
     thr = philox.drop_threshold(0.3)
-    assert thr == 1288490240            # floor(float32(0.3) * 2**32)
-    for j in range(4):
-        assert m[17, 33 * 4 + j] == (int(w[j]) >= int(thr))
+    assert thr == 19660                    # floor(float32(0.3) * 2**16)
+    for c in (0, 5, 13, 77, 200, 255):
+        g = (c >> 5) * 4 + ((c >> 4) & 1) * 2 + ((c >> 2) & 1)
+        d = ((c >> 3) & 1) * 4 + (c & 3)
+        w = philox.philox4x32_10(17, g, 2 | (5 << 16), 3, 9, 7)
+        u16 = (int(w[d >> 1]) >> (16 * (d & 1))) & 0xFFFF
+        assert m[17, c] == (u16 >= int(thr))
+    # every channel is decided by exactly one (group, decision) pair
+    cs = np.arange(256)
+    pairs = set(zip(((cs >> 5) * 4 + ((cs >> 4) & 1) * 2 + ((cs >> 2) & 1)).tolist(), (((cs >> 3) & 1) * 4 + (cs & 3)).tolist()))
+    assert len(pairs) == 256
     other = philox.dropout_keep_mask((7 << 32) | 9, 3, 3, 5, 500, 256, 0.3)
     assert (other != m).mean() > 0.3
-    assert philox.dropout_keep_mask(1, 0, 0, 0, 10, 8, 0.0).all()
+    assert philox.dropout_keep_mask(1, 0, 0, 0, 10, 32, 0.0).all()
 
 
 def test_categorical_uniforms_contract():

@@ -15,5 +15,5 @@ for prec in ("fp32", "bf16"):
         if mism.sum():
             y, xx, c = np.argwhere(mism)[0]
             p = y * 50 + xx
-            wd = philox.philox4x32_10(p, c // 4, s | (11 << 16), 0, 17, 0)
+            wd = philox.philox4x32_10(p, int(philox.dropout_group8(c)), s | (11 << 16), 0, 17, 0)
             print("  pixel", p, "channel", c, "words", [hex(int(v)) for v in wd], "thr", hex(int(philox.drop_threshold(0.3))))
