@@ -609,8 +609,9 @@ bod_status alloc_post(bod_context* h) {
     BODCHK(h->dalloc(&p.corners, BA * 4));
     BODCHK(h->dalloc(&p.anchor_index, BA));
     BODCHK(h->dalloc(&h->d_anchors, (size_t)h->A * 4));
-    BODCHK(h->dalloc(&h->nms_scores, BA));
-    BODCHK(h->dalloc(&h->nms_begin, BA));
+    const size_t BApad = (size_t)h->cfg.batch * ((h->A + 511) & ~(size_t)511);   // nms_kernel pads its queue to 512
+    BODCHK(h->dalloc(&h->nms_scores, BApad));
+    BODCHK(h->dalloc(&h->nms_begin, BApad));
     const size_t BK = (size_t)c.batch * c.nms_max_output_size;
     for (int sidx = 0; sidx < 2; ++sidx) {
         BODCHK(h->dalloc(&h->nms_sel_s[sidx], BK));

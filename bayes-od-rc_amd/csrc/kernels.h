@@ -126,8 +126,8 @@ struct NmsArgs {
     const int32_t* num_kept;      // [B]
     const float* corners;         // [B,A,4]
     const float* ranking;         // [B,A]
-    float* work_scores;           // [B,A] scratch
-    int32_t* work_begin;          // [B,A] scratch
+    float* work_scores;           // [B, A rounded up to 512] scratch (used when M exceeds the LDS capacity)
+    int32_t* work_begin;          // same shape
     int32_t* selected;            // [B,max_out]
     int32_t* num_selected;        // [B]
     int32_t max_out;

@@ -462,73 +462,118 @@ __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
     return inter / ((area_i + area_j) - inter);
 }
 
+// Wave-wide arg-max of (score desc, index asc) without LDS traffic: 4 DPP steps reduce each row of 16
+// lanes (quad xor 1, xor 2, half-row mirror, row mirror), then the four row results are read out through
+// SGPRs.  idx < 0 marks "no candidate".
+__device__ __forceinline__ bool nms_better(float os, int oi, float bs, int bi) {
+    return (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi < bi));
+}
+template <int CTRL>
+__device__ __forceinline__ void nms_dpp_step(float& bs, int& bi) {
+    const float os = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bs), CTRL, 0xF, 0xF, false));
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, false);
+    if (nms_better(os, oi, bs, bi)) { bs = os; bi = oi; }
+}
+__device__ __forceinline__ void nms_wave_argmax(float& bs, int& bi) {
+    nms_dpp_step<0xB1>(bs, bi);     // quad_perm [1,0,3,2]
+    nms_dpp_step<0x4E>(bs, bi);     // quad_perm [2,3,0,1]
+    nms_dpp_step<0x141>(bs, bi);    // row_half_mirror
+    nms_dpp_step<0x140>(bs, bi);    // row_mirror
+    float rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), 0));
+    int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float os = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), r));
+        const int oi = __builtin_amdgcn_readlane(bi, r);
+        if (nms_better(os, oi, rs, ri)) { rs = os; ri = oi; }
+    }
+    bs = rs; bi = ri;
+}
+
+#define NMS_BOX_CAP 4096
 __global__ __launch_bounds__(64) void nms_kernel(NmsArgs a) {
-    __shared__ float s_score[NMS_LDS_CAP];
-    __shared__ int s_begin[NMS_LDS_CAP];
-    __shared__ float4 s_selbox[NMS_MAX_OUT];
-    __shared__ float s_w[NMS_MAX_OUT];
+    extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    float4* s_box = reinterpret_cast<float4*>(nms_smem);                                  // [NMS_BOX_CAP]
+    float4* s_selbox = s_box + NMS_BOX_CAP;                                               // [NMS_MAX_OUT]
+    float* s_score = reinterpret_cast<float*>(s_selbox + NMS_MAX_OUT);                    // [NMS_LDS_CAP]
+    int* s_begin = reinterpret_cast<int*>(s_score + NMS_LDS_CAP);                         // [NMS_LDS_CAP]
     const int b = blockIdx.x, lane = threadIdx.x;
     const int M = a.num_kept[b];
-    const float4* boxes = reinterpret_cast<const float4*>(a.corners) + (size_t)b * a.A;
-    float* score = (M <= NMS_LDS_CAP) ? s_score : a.work_scores + (size_t)b * a.A;
-    int* begin = (M <= NMS_LDS_CAP) ? s_begin : a.work_begin + (size_t)b * a.A;
+    const float4* gboxes = reinterpret_cast<const float4*>(a.corners) + (size_t)b * a.A;
+    float* score = (M <= NMS_LDS_CAP) ? s_score : a.work_scores + (size_t)b * ((a.A + 511) & ~511);
+    int* begin = (M <= NMS_LDS_CAP) ? s_begin : a.work_begin + (size_t)b * ((a.A + 511) & ~511);
+    const bool box_lds = M <= NMS_BOX_CAP;
     int* sel = a.selected + (size_t)b * a.max_out;
     const float scale = a.sigma > 0.f ? -0.5f / a.sigma : 0.f;
     const bool soft = a.sigma > 0.f;
+    const bool always_soft = a.variant == 1 && soft;
     const float NEG_INF = -INFINITY;
 
-    for (int i = lane; i < M; i += 64) { score[i] = a.ranking[(size_t)b * a.A + i]; begin[i] = 0; }
+    // score[] is padded to a multiple of 64*8 with -inf; a candidate that leaves the queue is marked by
+    // score = -inf as well (the op never queues a -inf score: it only admits score > score_threshold = -inf),
+    // so the lane-local rescan is a branch-free strided max with 8 independent LDS reads in flight.
+    const int Mpad = (M + 511) & ~511;
+    for (int i = lane; i < Mpad; i += 64) {
+        score[i] = i < M ? a.ranking[(size_t)b * a.A + i] : NEG_INF;
+        if (i < M) {
+            begin[i] = 0;
+            if (box_lds) s_box[i] = gboxes[i];
+        }
+    }
     __syncthreads();
 
     // lane-local best over its strided slice
     float lbest = NEG_INF; int lidx = -1;
     auto rescan = [&]() {
         lbest = NEG_INF; lidx = -1;
-        for (int i = lane; i < M; i += 64) {
-            if (begin[i] < 0) continue;
-            const float s = score[i];
-            if (lidx < 0 || s > lbest) { lbest = s; lidx = i; }    // ascending i => lowest index wins ties
+        for (int i0 = lane; i0 < Mpad; i0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = score[i0 + q * 64];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (v[q] > lbest) { lbest = v[q]; lidx = i0 + q * 64; }    // ascending i => lowest index wins ties
         }
     };
     rescan();
     int nsel = 0;
     while (nsel < a.max_out) {
-        // wave arg-max: (score desc, index asc)
         float bs = lbest; int bi = lidx;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float os = __shfl_xor(bs, off);
-            const int oi = __shfl_xor(bi, off);
-            const bool take = (oi >= 0) && (bi < 0 || os > bs || (os == bs && oi < bi));
-            if (take) { bs = os; bi = oi; }
-        }
+        nms_wave_argmax(bs, bi);
         if (bi < 0) break;
         const int idx = bi;
         const float original = bs;
         const int beg = begin[idx];
-        const float4 cb = boxes[idx];
-        // weights against selected[beg .. nsel), computed lane-parallel, multiplied newest-first
-        for (int j = beg + lane; j < nsel; j += 64) {
-            const float sim = nms_iou(cb, s_selbox[j]);
-            float w = (float)exp((double)(scale * (sim * sim)));
-            if (!(a.variant == 1 && soft) && !(sim <= a.iou_thr)) w = 0.f;
-            s_w[j] = w;
-        }
-        __syncthreads();
+        const float4 cb = box_lds ? s_box[idx] : gboxes[idx];
+        // Decay by every box selected since the candidate was last examined, newest first (the TF op's
+        // loop order; fp32 products do not commute in rounding).  Weights are evaluated lane-parallel, 64
+        // selected boxes at a time with lane l <-> j = hi-1-l; a factor of exactly 1.0f (no overlap) leaves
+        // the product bit-identical, so only the lanes with w != 1 enter the serial chain.
         float s = original;
-        if (lane == 0)
-            for (int j = nsel - 1; j >= beg; --j) s = s * s_w[j];
-        s = __shfl(s, 0);
-        __syncthreads();
+        for (int hi = nsel; hi > beg; hi -= 64) {
+            const int j = hi - 1 - lane;
+            float w = 1.0f;
+            if (j >= beg) {
+                const float sim = nms_iou(cb, s_selbox[j]);
+                if (sim != 0.f) w = (float)exp((double)(scale * (sim * sim)));
+                if (!always_soft && !(sim <= a.iou_thr)) w = 0.f;
+            }
+            unsigned long long m = __ballot(w != 1.0f);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                s = s * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), l));
+            }
+        }
         const bool owner = (idx & 63) == lane;
         if (s == original) {
             if (lane == 0) { sel[nsel] = idx; s_selbox[nsel] = cb; }
-            if (owner) begin[idx] = -1;
+            if (owner) score[idx] = NEG_INF;
             ++nsel;
         } else if (s > NEG_INF) {
             if (owner) { score[idx] = s; begin[idx] = nsel; }
         } else {
-            if (owner) begin[idx] = -1;
+            if (owner) score[idx] = NEG_INF;
         }
         __syncthreads();
         if (owner) rescan();
@@ -538,7 +583,15 @@ __global__ __launch_bounds__(64) void nms_kernel(NmsArgs a) {
 
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
     if (a.max_out > NMS_MAX_OUT) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(64), 0, s, a);
+    constexpr int LDS = (NMS_BOX_CAP + NMS_MAX_OUT) * 16 + NMS_LDS_CAP * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(64), LDS, s, a);
     return hipGetLastError();
 }
 

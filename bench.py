@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true", help="print the cls foreground bias for M~1000")
     ap.add_argument("--fg-bias", type=float, default=CALIBRATED_FG_BIAS)
+    ap.add_argument("--forward-only", action="store_true",
+                    help="time RetinaNetModel.call only (BASELINE config 2: raw head outputs); implied by --mc 1, "
+                         "where the Bayesian stages are undefined (sample covariance divides by N-1)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="bf16 = throughput path (BASELINE.json north_star); fp32 = reference-exact arithmetic mode")
     args = ap.parse_args()
@@ -128,6 +131,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     hw, n, B = (args.height, args.width), args.mc, args.batch
+    fwd_only = args.forward_only or n < 2
     weights = synthetic.make_weights(cls_fg_bias=args.fg_bias)
     anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
     eng = Engine(make_config(hw, batch=B, mc_samples=n, device=local_rank, bayes_od_config=BAYES_CFG,
@@ -165,6 +169,9 @@ def main():
     pending = []
 
     def step(i):
+        if fwd_only:
+            eng.forward(None, seed=0, first_image_id=lo + i * world * B)   # asynchronous on the engine stream
+            return
         # software pipeline of depth 2: batch i's NMS/cluster-fuse (side stream) and its collection
         # overlap batch i+1's convolutions; every enqueued batch is collected inside the timed region
         pending.append(eng.infer_async(None, seed=0, first_image_id=lo + i * world * B))
@@ -199,13 +206,16 @@ def main():
         elapsed = float(t.item())
     total_images = world * B * args.steps
     value = total_images / elapsed
-    kept = eng.num_kept()
+    kept = [] if fwd_only else eng.num_kept()
 
     # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM), HIP events on the engine's stream
     prof_steps = max(1, min(3, args.steps))
     eng.profile_begin()
     for i in range(prof_steps):
-        eng.infer(None, seed=0, first_image_id=lo + i * world * B)
+        if fwd_only:
+            eng.forward(None, seed=0, first_image_id=lo + i * world * B)
+        else:
+            eng.infer(None, seed=0, first_image_id=lo + i * world * B)
     prof = eng.profile_end()
     launches = max(1, prof["head_conv_launches"])
     # algorithmic FLOPs: de-duplicated head convs = exactly what the 4 launches/step issue
@@ -236,8 +246,9 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
            "data": "synthetic",
-           "config": {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, full BayesOD "
-                                  "pipeline (forward+posterior+soft-NMS+cluster-fuse)" % (n, hw[0], hw[1]),
+           "config": {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, %s"
+                                  % (n, hw[0], hw[1], "forward only (raw head outputs, BASELINE config 2)" if fwd_only else
+                                     "full BayesOD pipeline (forward+posterior+soft-NMS+cluster-fuse)"),
                       "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
                       "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
                       "parallelism": "image-sharded x%d, one RCCL gather/step" % world,

@@ -133,7 +133,7 @@ def _posterior_like(rng, m, n_obj):
 
 
 @pytest.mark.parametrize("variant", ["A", "B"])
-@pytest.mark.parametrize("m,n_obj", [(1, 1), (37, 3), (400, 25), (1500, 60), (7000, 300)])
+@pytest.mark.parametrize("m,n_obj", [(1, 1), (37, 3), (400, 25), (1500, 60), (5000, 200), (7000, 300)])
 def test_soft_nms_bit_exact(variant, m, n_obj):
     """Index list identical to the restated NonMaxSuppressionV5 (oracle/nms.py)."""
     from oracle import nms, geometry
