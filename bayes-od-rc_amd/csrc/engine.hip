@@ -37,6 +37,7 @@ struct Op {
     ConvArgs conv;
     bool is_head3x3 = false;
     double flops = 0;
+    std::string name;
 };
 
 uint16_t f2bf(float f) {
@@ -96,6 +97,7 @@ struct bod_context {
     hipStream_t side = nullptr;
     hipEvent_t ev_posterior = nullptr; hipEvent_t ev_done[2] = {nullptr, nullptr};
     bool side_pending[2] = {false, false};
+    char* host_stage[2] = {nullptr, nullptr};     // pinned host copy of a slot's records (filled on the side stream)
     void select_slot(int sidx) {
         slot = sidx;
         nms_sel = nms_sel_s[sidx]; nms_nsel = nms_nsel_s[sidx];
@@ -278,6 +280,7 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     op.conv.g[0] = ConvGroup{in.d, pc.w, pc.bias, out.d, res ? res->d : nullptr, out_relu, 0, 0, nullptr, nullptr, nullptr, 0, 0};
     op.conv.flags = relu ? CONV_RELU : 0;
     op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
+    op.name = name;
     h->ops.push_back(op);
     return BOD_OK;
 }
@@ -345,8 +348,8 @@ bod_status build_plan(bod_context* h) {
         HIPCHK(h, hipMemcpyAsync(h->stem_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         BODCHK(h->dalloc(&h->stem_out, (size_t)B * h->sh * h->sw * 64 * h->es));
-        Op s; s.kind = Op::STEM; h->ops.push_back(s);
-        Op p; p.kind = Op::POOL; h->ops.push_back(p);
+        Op s; s.kind = Op::STEM; s.name = "conv1(stem)"; s.flops = 2.0 * B * h->sh * h->sw * 64.0 * 147.0; h->ops.push_back(s);
+        Op p; p.kind = Op::POOL; p.name = "pool1"; h->ops.push_back(p);
     }
     // ---------------- ResNet-50 stages (feature_extractor.py:104-139)
     Plane x;
@@ -574,6 +577,7 @@ bod_status build_plan(bod_context* h) {
         if (xreuse && layer > 0) { a.rows = d2x; a.M = m2x; a.ext = dext; a.xreuse = 1; }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g;
+        op.name = "head_tower_layer_" + std::to_string(layer);
         h->ops.push_back(op);
     }
     for (int hd = 0; hd < nheads && !fuse_out; ++hd) {
@@ -587,6 +591,7 @@ bod_status build_plan(bod_context* h) {
         a.flags = CONV_OUT_F32;
         op.conv = a;
         op.flops = 2.0 * a.M * pc.cout * 256.0;
+        op.name = kHeadPrefix[hd];
         h->ops.push_back(op);
     }
     return BOD_OK;
@@ -620,6 +625,9 @@ bod_status alloc_post(bod_context* h) {
         BODCHK(h->dalloc(&h->out_means_s[sidx], BK * 4));
         BODCHK(h->dalloc(&h->out_covs_s[sidx], BK * 16));
         BODCHK(h->dalloc(&h->out_counts_s[sidx], BK * c.num_classes));
+        const size_t stage_bytes = ((size_t)c.batch + BK * (2 * (size_t)c.num_classes + 20)) * 4;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_stage[sidx]), stage_bytes, hipHostMallocDefault) != hipSuccess)
+            return h->fail(BOD_ERR_OOM, "pinned host staging buffer (%zu bytes)", stage_bytes);
     }
     h->select_slot(0);
     BODCHK(h->dalloc(&h->d_images, (size_t)c.batch * c.image_h * c.image_w * 3));
@@ -639,7 +647,21 @@ PostCfg post_cfg(bod_context* h, uint64_t seed, uint32_t first_image) {
 
 bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image) {
     const bod_config& c = h->cfg;
+    // BOD_TRACE_OPS=k: the k-th forward call is traced op by op (HIP events on the engine stream) and a table
+    // is printed to stderr -- a development aid (tests/tools), off by default.
+    static const int trace_call = getenv("BOD_TRACE_OPS") ? atoi(getenv("BOD_TRACE_OPS")) : 0;
+    static int call_no = 0;
+    const bool trace = trace_call > 0 && ++call_no == trace_call;
+    std::vector<hipEvent_t> tev;
+    if (trace) {
+        tev.resize(h->ops.size() + 1);
+        for (hipEvent_t& e : tev) HIPCHK(h, hipEventCreate(&e));
+        HIPCHK(h, hipEventRecord(tev[0], h->stream));
+    }
+    size_t op_i = 0;
     for (Op& op : h->ops) {
+        if (trace && op_i > 0) HIPCHK(h, hipEventRecord(tev[op_i], h->stream));
+        ++op_i;
         switch (op.kind) {
             case Op::STEM:
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
@@ -667,6 +689,19 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 break;
             }
         }
+    }
+    if (trace) {
+        HIPCHK(h, hipEventRecord(tev[h->ops.size()], h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        fprintf(stderr, "# op trace: name kind M taps cin cout_pad groups fan ms TFLOP/s\n");
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            float ms = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&ms, tev[i], tev[i + 1]));
+            const Op& o = h->ops[i];
+            fprintf(stderr, "%-28s %d %8d %2d %5d %5d %d %2d %9.4f %8.1f\n", o.name.c_str(), (int)o.kind, o.conv.M, o.conv.taps,
+                    o.conv.cin, o.conv.cout_pad, o.conv.groups, o.conv.fan_count, ms, o.flops / (ms * 1e-3) / 1e12);
+        }
+        for (hipEvent_t& e : tev) hipEventDestroy(e);
     }
     h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
     return BOD_OK;
@@ -792,6 +827,7 @@ bod_status bod_destroy(bod_handle h) {
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
     if (h->ev_posterior) hipEventDestroy(h->ev_posterior);
     for (int sidx = 0; sidx < 2; ++sidx) if (h->ev_done[sidx]) hipEventDestroy(h->ev_done[sidx]);
+    for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1132,6 +1168,18 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
     HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
     BODCHK(run_nms(h, h->side));
     BODCHK(run_cluster(h, h->side));
+    // The records follow the kernels on the side stream into pinned host memory, so bod_collect only waits for
+    // this slot's event: it must never queue work behind the NEXT batch's side-stream kernels (that would
+    // stall the host until the next batch has finished and drain the pipeline).
+    {
+        const size_t B = (size_t)h->cfg.batch, BK = B * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
+        char* hs = h->host_stage[sidx];
+        HIPCHK(h, hipMemcpyAsync(hs, h->nms_nsel_s[sidx], B * 4, hipMemcpyDeviceToHost, h->side)); hs += B * 4;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_scores_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, h->side)); hs += BK * C * 4;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_means_s[sidx], BK * 16, hipMemcpyDeviceToHost, h->side)); hs += BK * 16;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_covs_s[sidx], BK * 64, hipMemcpyDeviceToHost, h->side)); hs += BK * 64;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_counts_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, h->side));
+    }
     HIPCHK(h, hipEventRecord(h->ev_done[sidx], h->side));
     h->side_pending[sidx] = true;
     *slot_out = sidx;
@@ -1141,17 +1189,18 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
 bod_status bod_collect(bod_handle h, int32_t sidx, int32_t* num, float* scores, float* means, float* covs, float* counts) {
     if (!h) return BOD_ERR_INVALID_ARG;
     if (sidx < 0 || sidx > 1 || !h->side_pending[sidx]) return h->fail(BOD_ERR_NOT_READY, "slot %d has no pending batch", sidx);
-    const size_t BK = (size_t)h->cfg.batch * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
-    hipStream_t st = h->side;
-    auto cp = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
-    };
-    HIPCHK(h, cp(num, h->nms_nsel_s[sidx], (size_t)h->cfg.batch * 4));
-    HIPCHK(h, cp(scores, h->out_scores_s[sidx], BK * C * 4));
-    HIPCHK(h, cp(means, h->out_means_s[sidx], BK * 16));
-    HIPCHK(h, cp(covs, h->out_covs_s[sidx], BK * 64));
-    HIPCHK(h, cp(counts, h->out_counts_s[sidx], BK * C * 4));
-    HIPCHK(h, hipStreamSynchronize(st));
+    const size_t B = (size_t)h->cfg.batch, BK = B * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
+    HIPCHK(h, hipEventSynchronize(h->ev_done[sidx]));
+    const char* hs = h->host_stage[sidx];
+    if (num) std::memcpy(num, hs, B * 4);
+    hs += B * 4;
+    if (scores) std::memcpy(scores, hs, BK * C * 4);
+    hs += BK * C * 4;
+    if (means) std::memcpy(means, hs, BK * 16);
+    hs += BK * 16;
+    if (covs) std::memcpy(covs, hs, BK * 64);
+    hs += BK * 64;
+    if (counts) std::memcpy(counts, hs, BK * C * 4);
     h->side_pending[sidx] = false;
     return BOD_OK;
 }
