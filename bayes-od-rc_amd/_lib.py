@@ -22,7 +22,9 @@ class BodConfig(C.Structure):
         ("nms_iou_threshold", C.c_float), ("nms_soft_sigma", C.c_float), ("nms_variant", C.c_int32),
         ("num_categorical_draws", C.c_int32), ("has_covar_head", C.c_int32),
         ("kitti_scale_h", C.c_float), ("kitti_scale_w", C.c_float), ("precision", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("mc_sample_base", C.c_int32),
+        ("mc_ensemble_size", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -65,6 +67,7 @@ SIGNATURES = {
     "bod_get_detections": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
     "bod_get_detections_batch": (C.c_int, [_H, _I, _F, _F, _F, _F]),
     "bod_device_detections": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bod_device_raw": (C.c_int, [_H, C.POINTER(C.c_void_p), C.c_int32]),
     "bod_infer": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32]),
     "bod_infer_async": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32, _I]),
     "bod_collect": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),

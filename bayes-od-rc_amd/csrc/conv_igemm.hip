@@ -442,7 +442,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             const int pixl = wp * WTP + j * 32 + frow;
             char* prow = smem + pixl * (BC * 2);
             const uint32_t img = a.image_base + ((uint32_t)rng[j].y >> 16);
-            const uint32_t sample = a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rng[j].y & 0xFFFFu);
+            const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rng[j].y & 0xFFFFu));
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 Philox4 rr{0u, 0u, 0u, 0u};

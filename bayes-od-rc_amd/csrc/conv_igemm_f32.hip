@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
                     float w[4] = {v[0], v[1], v[2], v[3]};
                     if (drop) {
                         const uint32_t img = a.image_base + ((uint32_t)e1.y >> 16);
-                        const uint32_t sample = a.fan_count > 1 ? (uint32_t)n : ((uint32_t)e1.y & 0xFFFFu);
+                        const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)e1.y & 0xFFFFu));
                         const Philox4 r = philox4x32_10((uint32_t)e1.x, dropout_group8((uint32_t)co),
                                                         sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
                         const uint32_t w0 = (g4 & 1) ? r.z : r.x, w1 = (g4 & 1) ? r.w : r.y;   // decisions d = (g4&1)*4 + q

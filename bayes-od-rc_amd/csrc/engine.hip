@@ -324,6 +324,18 @@ Plane level_view(bod_context* h, int l) {
     return v;
 }
 
+// Raw head outputs [B,N,A,.] fp32.  Allocated with the plan, or on first use by a handle that never loads
+// weights (a "post-only" handle whose raw buffers are filled by bod_set_raw / through bod_device_raw).
+bod_status ensure_raw(bod_context* h) {
+    const bod_config& c = h->cfg;
+    const int out_ch[3] = {c.anchors_per_location * c.num_classes, c.anchors_per_location * 4, c.anchors_per_location * 10};
+    for (int hd = 0; hd < 3; ++hd) {
+        if ((hd == 2 && !c.has_covar_head) || h->raw[hd]) continue;
+        BODCHK(h->dalloc(&h->raw[hd], (size_t)c.batch * c.mc_samples * h->P * out_ch[hd]));
+    }
+    return BOD_OK;
+}
+
 bod_status build_plan(bod_context* h) {
     const bod_config& c = h->cfg;
     const int B = c.batch, N = c.mc_samples;
@@ -432,10 +444,7 @@ bod_status build_plan(bod_context* h) {
         BODCHK(h->dalloc(&h->head_act[hd][1], act_elems));
     }
     const int out_ch[3] = {c.anchors_per_location * c.num_classes, c.anchors_per_location * 4, c.anchors_per_location * 10};
-    for (int hd = 0; hd < 3; ++hd) {
-        if (hd == 2 && !c.has_covar_head) continue;
-        BODCHK(h->dalloc(&h->raw[hd], (size_t)B * N * h->P * out_ch[hd]));
-    }
+    BODCHK(ensure_raw(h));
     // row tables: layer 1 (pyramid -> N dropout variants), layers 2.. (per sample), output 1x1
     std::vector<RowEnt> t1((size_t)B * h->P), t2((size_t)B * N * h->P), t3((size_t)B * N * h->P);
     {
@@ -525,7 +534,7 @@ bod_status build_plan(bod_context* h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
 
-    const bool mc = N > 1;                                  // mc_dropout_enabled (retinanet_model.py:74-77)
+    const bool mc = std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77)
     const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 65536.0);
     const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
     const int nheads = c.has_covar_head ? 3 : 2;
@@ -674,6 +683,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
             case Op::CONV: {
                 op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
                 op.conv.image_base = first_image;
+                op.conv.sample_base = (uint32_t)c.mc_sample_base;
                 const bool timed = h->profiling && op.is_head3x3;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {
@@ -793,6 +803,10 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (c.device < 0 || c.device >= ndev) return bail(h->fail(BOD_ERR_INVALID_ARG, "device %d out of range [0,%d)", c.device, ndev));
     if (c.batch < 1 || c.batch > 4096 || c.mc_samples < 1 || c.mc_samples > 4096)
         return bail(h->fail(BOD_ERR_INVALID_ARG, "batch=%d / mc_samples=%d out of range", c.batch, c.mc_samples));
+    if (c.mc_sample_base < 0 || c.mc_sample_base + c.mc_samples > 65535 || c.mc_ensemble_size < 0 ||
+        (c.mc_ensemble_size > 0 && c.mc_sample_base + c.mc_samples > c.mc_ensemble_size))
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "mc_sample_base=%d / mc_samples=%d / mc_ensemble_size=%d inconsistent",
+                            c.mc_sample_base, c.mc_samples, c.mc_ensemble_size));
     if (c.num_classes != 4 && c.num_classes != 8)
         return bail(h->fail(BOD_ERR_INVALID_ARG, "num_classes (incl. background) must be 4 or 8, got %d", c.num_classes));
     if (c.anchors_per_location < 1 || (c.anchors_per_location * c.num_classes) % 4 != 0)
@@ -854,12 +868,14 @@ bod_status bod_update_config(bod_handle h, const bod_config* cfg) {
         cfg->mc_samples != o.mc_samples || cfg->num_classes != o.num_classes ||
         cfg->anchors_per_location != o.anchors_per_location || cfg->min_level != o.min_level ||
         cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate ||
-        cfg->precision != o.precision)
+        cfg->precision != o.precision || (std::max(cfg->mc_ensemble_size, cfg->mc_samples) > 1) != (std::max(o.mc_ensemble_size, o.mc_samples) > 1))
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: geometry / model fields cannot change on a live handle");
     if (cfg->nms_max_output_size != o.nms_max_output_size)
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: nms_max_output_size sizes device buffers and cannot change");
     if (cfg->num_categorical_draws < 1 || cfg->num_categorical_draws > 1024)
         return h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range");
+    if (cfg->mc_sample_base < 0 || cfg->mc_sample_base + cfg->mc_samples > 65535)
+        return h->fail(BOD_ERR_INVALID_ARG, "mc_sample_base + mc_samples must stay below 65536 (16-bit sample field of the RNG counter)");
     h->cfg = *cfg;
     return BOD_OK;
 }
@@ -944,7 +960,8 @@ bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* cov) {
 
 bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const float* cov) {
     if (!h) return BOD_ERR_INVALID_ARG;
-    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized (raw buffers are allocated with the plan)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    BODCHK(ensure_raw(h));
     const bod_config& c = h->cfg;
     const size_t n = (size_t)c.batch * c.mc_samples * h->A;
     if (cls) HIPCHK(h, hipMemcpyAsync(h->raw[0], cls, n * c.num_classes * 4, hipMemcpyHostToDevice, h->stream));
@@ -1128,6 +1145,15 @@ bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, f
     BODCHK(d2h(h, covs, h->out_covs, BK * 16));
     BODCHK(d2h(h, counts, h->out_counts, BK * C));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_device_raw(bod_handle h, void** p, int32_t mark_ready) {
+    if (!h || !p) return BOD_ERR_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    BODCHK(ensure_raw(h));
+    p[0] = h->raw[0]; p[1] = h->raw[1]; p[2] = h->cfg.has_covar_head ? h->raw[2] : nullptr;
+    if (mark_ready) { h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; }
     return BOD_OK;
 }
 

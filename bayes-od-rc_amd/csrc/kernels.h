@@ -69,6 +69,7 @@ struct ConvArgs {
     // (RowEnt.pad1 = a pixel's extended-row index) and activations are staged once per (chunk, ky).
     const int2* ext;
     int32_t xreuse;
+    uint32_t sample_base;  // added to every MC sample index before it enters the dropout counter (sample sharding)
 };
 constexpr int XR_EXT_ROWS = 320;
 

@@ -75,3 +75,86 @@ def torch_views(engine, slot=0):
     for name, (ptr, shape) in p.items():
         views[name] = torch.as_tensor(DeviceArray(ptr, shape, "<i4" if name == "num" else "<f4"), device=dev)
     return views
+
+
+# ---------------------------------------------------------------------------------------------------
+# Second mode: MC-sample sharding for single-frame latency.  Every rank runs the
+# backbone/FPN of the SAME frame(s) and n = N/world of the N dropout samples (its handle has
+# mc_sample_base = rank*n, so the Philox streams are those of samples rank*n .. rank*n+n-1 of the N-sample
+# ensemble); ONE all-gather of the raw head outputs rebuilds the [B,N,A,.] tensors RetinaNetModel.call
+# returns on every rank, bit-identical to a single-GPU run, and the (cheap) Bayesian stages run replicated.
+# The exchange carries 22 floats per anchor and sample ((C + 4 + 10) * 4 B * A * n per rank; 2.6 MB per
+# sample at 512x512) over xGMI -- direct all-gather, no reduction, nothing to re-associate.
+# ---------------------------------------------------------------------------------------------------
+def sample_shard(total_samples, world_size, rank):
+    """(first sample, count) of this rank; the ensemble must split evenly (fixed-size all-gather)."""
+    if total_samples % world_size != 0:
+        raise ValueError("mc_dropout_samples=%d is not divisible by the %d ranks of the sample-sharded mode"
+                         % (total_samples, world_size))
+    n = total_samples // world_size
+    return rank * n, n
+
+
+def raw_views(engine, mark_ready=False):
+    """torch tensors aliasing the engine's raw head-output buffers: cls [B,N,A,C], box [B,N,A,4], cov [B,N,A,10]."""
+    ptrs = engine.device_raw_pointers(mark_ready)
+    dev = torch.device("cuda", engine.cfg.device)
+    b, n, a = engine.B, engine.N, engine.A
+    shapes = {"cls": (b, n, a, engine.Ccls), "box": (b, n, a, 4), "cov": (b, n, a, 10)}
+    return {k: torch.as_tensor(DeviceArray(p, shapes[k], "<f4"), device=dev)
+            for k, p in zip(("cls", "box", "cov"), ptrs) if p}
+
+
+def all_gather_samples(local, full, group=None):
+    """local [B,n,A,c] of every rank -> full [B,world*n,A,c] on every rank, rank r's samples at r*n.. .
+    B == 1 gathers straight into ``full`` (zero copy); B > 1 goes through one staging tensor."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    b, n = local.shape[0], local.shape[1]
+    if tuple(full.shape) != (b, world * n) + tuple(local.shape[2:]):
+        raise ValueError("full %s does not hold %d x local %s" % (tuple(full.shape), world, tuple(local.shape)))
+    if world == 1:
+        full.copy_(local)
+        return full
+    local = local.contiguous()
+    if b == 1:
+        dist.all_gather_into_tensor(full.view((world * n,) + tuple(local.shape[2:])),
+                                    local.view((n,) + tuple(local.shape[2:])), group=group)
+    else:
+        tmp = torch.empty((world * b,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(tmp, local, group=group)           # concatenation along dim 0: [world*B, n, A, c]
+        full.view((b, world, n) + tuple(local.shape[2:])).copy_(tmp.view((world,) + tuple(local.shape)).transpose(0, 1))
+    return full
+
+
+class SampleShardedEngine(object):
+    """Pair of handles for the sample-sharded mode on this rank's GPU: ``fwd`` computes this rank's n samples,
+    ``post`` (no weights: raw buffers only) receives the gathered ensemble and runs posterior / soft-NMS /
+    cluster-fuse.  ``make_config_kwargs`` are those of engine.make_config for the FULL ensemble."""
+
+    def __init__(self, image_hw, weights, anchors, mc_samples, device=0, batch=1, group=None, **make_config_kwargs):
+        from .engine import Engine, make_config
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        base, n = sample_shard(mc_samples, self.world, self.rank)
+        self.fwd = Engine(make_config(image_hw, batch=batch, mc_samples=n, device=device, mc_sample_base=base,
+                                      mc_ensemble_size=mc_samples, **make_config_kwargs))
+        self.fwd.load_weights(weights)
+        self.post = Engine(make_config(image_hw, batch=batch, mc_samples=mc_samples, device=device, **make_config_kwargs))
+        self.post.set_anchors(anchors)
+        self._local = raw_views(self.fwd)
+        self._full = raw_views(self.post, mark_ready=False)
+
+    def infer(self, images, seed=0, first_image_id=0):
+        """images: [B,H,W,3] float32 (the same on every rank).  Returns this rank's copy of the detections
+        (list over images of (scores, means, covs, counts)); identical on all ranks."""
+        self.fwd.forward(images, seed=seed, first_image_id=first_image_id)
+        self.fwd.synchronize()                    # the collective runs on torch's stream, not the engine's
+        for k, loc in self._local.items():
+            all_gather_samples(loc, self._full[k], self.group)
+        torch.cuda.synchronize(self._full["cls"].device)
+        self.post.device_raw_pointers(mark_ready=True)
+        self.post.posterior(seed=seed, first_image_id=first_image_id)
+        self.post.nms()
+        self.post.cluster_fuse()
+        return [self.post.get_detections(i) for i in range(self.post.B)]

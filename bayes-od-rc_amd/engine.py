@@ -15,7 +15,8 @@ _KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
 def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
                 dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
                 has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
-                num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16'):
+                num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16', mc_sample_base=0,
+                mc_ensemble_size=0):
     """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
     into a ``bod_config``."""
     bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
@@ -45,6 +46,7 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
     if precision not in ('bf16', 'fp32'):
         raise ValueError("precision must be 'bf16' or 'fp32'")
     cfg.precision = int(precision == 'fp32')
+    cfg.mc_sample_base, cfg.mc_ensemble_size = int(mc_sample_base), int(mc_ensemble_size)
     if dataset_name == 'kitti':
         if orig_size is None:
             raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")
@@ -259,6 +261,12 @@ class Engine(object):
     def wait_slot(self, slot):
         """Block until the batch in ``slot`` is complete without copying anything."""
         self._chk(self.lib.bod_collect(self.h, slot, None, None, None, None, None))
+
+    def device_raw_pointers(self, mark_ready=False):
+        """Device addresses (cls, box, cov-or-None) of the raw head outputs [B,N,A,.] fp32."""
+        ptrs = (C.c_void_p * 3)()
+        self._chk(self.lib.bod_device_raw(self.h, ptrs, int(mark_ready)))
+        return [ptrs[i] for i in range(3)]
 
     def device_detection_pointers(self, slot=0):
         ptrs = (C.c_void_p * 5)()

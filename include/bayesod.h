@@ -63,7 +63,15 @@ typedef struct {
     int32_t precision;           /* BOD_PRECISION_BF16 (default, throughput path: bf16 storage + bf16 MFMA)
                                     or BOD_PRECISION_FP32 (fp32 storage + exact-fp32 MFMA: matches the
                                     reference's fp32 arithmetic end to end; ~1/10 of the speed)          */
-    int32_t reserved[7];
+    int32_t mc_sample_base;      /* index of this handle's first MC sample in the dropout RNG streams (default 0).
+                                    A handle with mc_samples = n and base = r*n computes samples r*n .. r*n+n-1 of
+                                    a larger ensemble bit-identically: the MC-sample-sharded multi-GPU mode
+                                    (second mode).  May change on a live handle.        */
+    int32_t mc_ensemble_size;    /* total MC samples of the ensemble this handle contributes to; 0 = mc_samples.
+                                    MC dropout is on iff max(mc_ensemble_size, mc_samples) > 1
+                                    (retinanet_model.py:74-77 decides on the ensemble size), so a rank holding a
+                                    single sample of a sharded ensemble still applies its dropout masks.       */
+    int32_t reserved[5];
 } bod_config;
 
 /* Sizes the caller needs to allocate host buffers. */
@@ -155,6 +163,13 @@ bod_status bod_get_detections_batch(bod_handle h, int32_t* num_detections, float
  * completed (bod_synchronize, or bod_collect with NULL destinations). Synchronous calls use slot 0
  * until the first bod_infer_async. */
 bod_status bod_device_detections(bod_handle h, int32_t slot, void** ptrs5);
+/* Device addresses of the raw head outputs of bod_forward (order: cls [B,N,A,C], box [B,N,A,4],
+ * cov [B,N,A,10] or NULL), fp32 -- the tensors RetinaNetModel.call returns (retinanet_model.py:99-112) --
+ * for zero-copy exchange between handles / GPUs (MC-sample sharding gathers every rank's [1,n,A,.] slices
+ * into one handle's buffers).  mark_ready != 0 declares the buffers filled by the caller (like bod_set_raw),
+ * so bod_posterior may run on them; the caller orders its writes before that call (bod_synchronize or
+ * its own stream/event ordering). */
+bod_status bod_device_raw(bod_handle h, void** ptrs3, int32_t mark_ready);
 
 /* The whole per-image body of run_inference.test_model's loop (:137-149) for `batch` images:
  * forward -> posterior -> nms -> cluster_fuse, one stream, no host round trip. */

@@ -73,3 +73,52 @@ def test_gather_records_world2_gloo():
     assert got.shape == (2, 3, 5, bd.record_width(8))
     for r in range(2):
         assert np.array_equal(got[r], bd.pack_records(*_fake(r)).numpy())
+
+
+# ---- second mode: MC-sample sharding (one all-gather of the raw head outputs) -------------------------------
+def test_sample_shard_split():
+    from bayes_od_rc_amd.distributed import sample_shard
+    assert [sample_shard(30, 2, r) for r in range(2)] == [(0, 15), (15, 15)]
+    assert [sample_shard(8, 8, r) for r in range(8)] == [(r, 1) for r in range(8)]
+    with pytest.raises(ValueError):
+        sample_shard(10, 4, 0)
+
+
+def _sample_block(b, n_total, a, c):
+    """value encodes (image, sample, anchor, channel) so a misplaced slice is visible"""
+    i = np.arange(b)[:, None, None, None] * 1e6 + np.arange(n_total)[None, :, None, None] * 1e3
+    return (i + np.arange(a)[None, None, :, None] * 10 + np.arange(c)[None, None, None, :]).astype(np.float32)
+
+
+def _sample_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayes_od_rc_amd import distributed as bd
+    out = {}
+    for b in (1, 2):
+        full_ref = _sample_block(b, 6, 7, 4)
+        base, n = bd.sample_shard(6, world, rank)
+        local = torch.from_numpy(full_ref[:, base:base + n].copy())
+        full = torch.zeros(b, 6, 7, 4)
+        bd.all_gather_samples(local, full)
+        out[b] = np.array_equal(full.numpy(), full_ref)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_samples_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == {0: {1: True, 2: True}, 1: {1: True, 2: True}}

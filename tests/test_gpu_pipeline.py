@@ -220,3 +220,71 @@ def test_run_inference_cli_writes_reference_layout(tmp_path, monkeypatch):
     assert isinstance(recs, list)
     for r in recs[:5]:
         assert set(r) == {"name", "timestep", "category", "bbox", "score"} and len(r["bbox"]) == 4
+
+
+@pytest.mark.parametrize("parts,batch", [(2, 1), (3, 2), (6, 1)])
+def test_sample_sharded_ensemble_is_bit_identical(parts, batch):
+    """SURVEY 8e second mode on one GPU: `parts` handles, each computing n = N/parts MC samples with
+    mc_sample_base = r*n, reproduce the N-sample handle's raw head outputs bit for bit (the RNG is keyed by the
+    absolute sample index), and a post-only handle fed the re-assembled ensemble returns the same detections."""
+    import torch
+    from bayes_od_rc_amd import synthetic, distributed as bd
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, n_total, seed, first = (160, 160), 6, 5, 40
+    kw = dict(bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True)
+    weights = synthetic.make_weights(cls_fg_bias=-1.0)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
+
+    full = Engine(make_config(hw, batch=batch, mc_samples=n_total, **kw))
+    full.load_weights(weights)
+    full.set_anchors(anchors)
+    full.infer(frames, seed=seed, first_image_id=first)
+    ref_raw = full.get_raw()
+    ref_det = [full.get_detections(i) for i in range(batch)]
+
+    post = Engine(make_config(hw, batch=batch, mc_samples=n_total, **kw))          # no weights: post-only
+    post.set_anchors(anchors)
+    dst = bd.raw_views(post)
+    for r in range(parts):
+        base, n = bd.sample_shard(n_total, parts, r)
+        part = Engine(make_config(hw, batch=batch, mc_samples=n, mc_sample_base=base, mc_ensemble_size=n_total, **kw))
+        part.load_weights(weights)
+        part.forward(frames, seed=seed, first_image_id=first)
+        part.synchronize()
+        for k, v in bd.raw_views(part).items():
+            dst[k][:, base:base + n].copy_(v)
+        torch.cuda.synchronize()
+        part.close()
+    post.device_raw_pointers(mark_ready=True)
+    got_raw = post.get_raw()
+    for a, b in zip(got_raw, ref_raw):
+        assert np.array_equal(a, b)
+    post.posterior(seed=seed, first_image_id=first)
+    post.nms()
+    post.cluster_fuse()
+    for i in range(batch):
+        for a, b in zip(post.get_detections(i), ref_det[i]):
+            assert np.array_equal(a, b)
+    assert ref_det[0][0].shape[0] > 0
+
+
+def test_sample_sharded_engine_world1():
+    """distributed.SampleShardedEngine without a process group (world 1) == the plain pipeline."""
+    from bayes_od_rc_amd import synthetic, distributed as bd
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, n_total = (160, 160), 4
+    kw = dict(bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True)
+    weights = synthetic.make_weights(cls_fg_bias=-1.0)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(1, hw[0], hw[1], seed=9)
+    sse = bd.SampleShardedEngine(hw, weights, anchors, n_total, **kw)
+    got = sse.infer(frames, seed=1, first_image_id=7)
+    ref = Engine(make_config(hw, batch=1, mc_samples=n_total, **kw))
+    ref.load_weights(weights)
+    ref.set_anchors(anchors)
+    ref.infer(frames, seed=1, first_image_id=7)
+    for a, b in zip(got[0], ref.get_detections(0)):
+        assert np.array_equal(a, b)
