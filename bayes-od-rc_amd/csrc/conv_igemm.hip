@@ -227,6 +227,114 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             }
         }
         if (!row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    } else if constexpr (XR && ABL == 80) {
+        // Row-reuse loop, second generation: (a) compact staging state -- one weight pointer plus scalar
+        // row strides, 32-bit activation offsets against the group's base pointer, advanced incrementally
+        // per (chunk, ky) group -- frees the registers for (b) a software-pipelined fragment schedule: per
+        // k-step the A fragments are double-buffered in pairs (i = 0,1 | 2,3) and the B fragments across
+        // k-steps, every ds_read_b128 is issued >= 4 MFMAs before its first use, and the only exposed LDS
+        // wait is the first fragment set after each block barrier (covered by issuing the LDS-DMA there).
+        static_assert(BC == 256 && BP == 256 && WC == 2 && WP == 4 && !SPLIT, "written for the 256x256 8-wave tile");
+        constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
+        const char* in_base = reinterpret_cast<const char*>(G.in) + G.in_coff * 2;
+        const char* wbase = wsrc[0];
+        const int wrs = RPI * KT * BK * 2;                                  // bytes between the rows of two weight pieces
+        uint32_t xo[NXE];
+        int xp[NXE];
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int2 e = a.ext[(size_t)bx * XR_EXT_ROWS + i * (THREADS / 8) + (tid >> 3)];
+            xo[i] = ((uint32_t)e.x * (uint32_t)a.in_cstride + ldchunk * 8) * 2u;
+            xp[i] = e.y * a.in_cstride * 2;
+        }
+        int xrow[FP];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) xrow[j] = a.rows[bp0 + wp * WTP + j * 32 + frow].pad1;
+        auto issue_wx = [&](int stage, int ky_, int kx_, int cc_) {
+            const int woff = ((ky_ * 3 + kx_) * a.cin + cc_ * BK) * 2;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                int off = woff + i * wrs;
+                asm volatile("" : "+s"(off));                               // keep the sum scalar, do not hoist 4 pointers
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + stage * WST + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+            }
+        };
+        // pieces [i0, i1) of the NEXT group: advance the running offset, then stage
+        auto issue_xe = [&](int buf, bool next_row, int i0, int i1) {
+#pragma unroll
+            for (int i = 0; i < NXE; ++i)
+                if (i >= i0 && i < i1) {
+                    xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]),
+                                                     LDS_PTR(smem + 2 * WST + buf * XBUF + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue_wx(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NXE; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]), LDS_PTR(smem + 2 * WST + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+        const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0 (k-step ks: ^ (ks << 5))
+        const int a_row = (wc * WTC + frow) * ROWB + a_c0;
+        const int NG = KT / 3;
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int g = cc * 3 + ky;
+            int nkx = kx + 1, nky = ky, ncc = cc;
+            if (nkx == 3) { nkx = 0; if (++nky == 3) { nky = 0; ++ncc; } }
+            // fragment addresses: every row base is a multiple of 128 B, so the k-step only flips address bits 5..6
+            const int wa = (kt & 1) * WST + a_row;                         // LDS byte offsets
+            const int xbase = 2 * WST + (g & 1) * XBUF;
+            int xb[FP];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kx; xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
+            auto ldA = [&](int i, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((wa ^ (ks << 5)) + i * 32 * ROWB)); };
+            auto ldB = [&](int j, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (xb[j] ^ (ks << 5))); };
+            bf16x8 A01[2], A23[2], Bc[2], Bn[2];
+            A01[0] = ldA(0, 0); Bc[0] = ldB(0, 0); Bc[1] = ldB(1, 0); A01[1] = ldA(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < KT) {
+                issue_wx((kt + 1) & 1, nky, nkx, ncc);
+                if (g + 1 < NG) {
+                    if (kx == 0) issue_xe((g + 1) & 1, ky + 1 < 3, 0, 2);
+                    else if (kx == 1) issue_xe((g + 1) & 1, ky + 1 < 3, 2, 4);
+                    else issue_xe((g + 1) & 1, ky + 1 < 3, 4, NXE);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define MFMA_ROW(I, AF) \
+    acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[0], acc[I][0], 0, 0, 0); \
+    acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[1], acc[I][1], 0, 0, 0);
+#define SGB_MFMA_DS() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16 - 1; ++ks) {
+                // phase P: MFMAs of A0,A1 | loads A2,A3 (this k-step), B0,B1 (next k-step)
+                A23[0] = ldA(2, ks); A23[1] = ldA(3, ks);
+                Bn[0] = ldB(0, ks + 1); Bn[1] = ldB(1, ks + 1);
+                MFMA_ROW(0, A01[0]) MFMA_ROW(1, A01[1])
+                SGB_MFMA_DS() SGB_MFMA_DS() SGB_MFMA_DS() SGB_MFMA_DS()
+                // phase Q: MFMAs of A2,A3 | loads A0,A1 (next k-step)
+                A01[0] = ldA(0, ks + 1); A01[1] = ldA(1, ks + 1);
+                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+                SGB_MFMA_DS() SGB_MFMA_DS()
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                Bc[0] = Bn[0]; Bc[1] = Bn[1];
+            }
+            {
+                constexpr int ks = BK / 16 - 1;
+                A23[0] = ldA(2, ks); A23[1] = ldA(3, ks);
+                MFMA_ROW(0, A01[0]) MFMA_ROW(1, A01[1])
+                SGB_MFMA_DS() SGB_MFMA_DS()
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+#undef MFMA_ROW
+#undef SGB_MFMA_DS
+            kx = nkx; ky = nky; cc = ncc;
+        }
     } else if constexpr (XR) {
         // Activation row reuse: per (channel chunk, ky) the tile's extended rows are staged ONCE and the
         // three kx taps read them at row offsets 0/1/2; only the weights stream every K-tile.
@@ -626,6 +734,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
         if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, false, false, false, true>(a, s);
         if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);
+        // xreuse == 2: every activation byte offset fits 32 bits -> compact-state, software-pipelined loop
+        if (a.variant == 80 || (a.variant == 0 && a.xreuse == 2)) return launch_cfg<256, 256, 2, 4, 80, false, false, false, true>(a, s);
+        if (a.variant == 81) return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);   // first-generation loop (A/B timing)
         return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
     }
     switch (variant) {

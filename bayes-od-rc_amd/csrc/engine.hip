@@ -583,7 +583,10 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
-        if (xreuse && layer > 0) { a.rows = d2x; a.M = m2x; a.ext = dext; a.xreuse = 1; }
+        if (xreuse && layer > 0) {
+            a.rows = d2x; a.M = m2x; a.ext = dext;
+            a.xreuse = act_elems < ((size_t)1 << 32) ? 2 : 1;       // 2: 32-bit activation offsets are safe
+        }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g;
         op.name = "head_tower_layer_" + std::to_string(layer);

@@ -68,7 +68,7 @@ struct ConvArgs {
     // pixels plus one on either side, so the three kx taps read the SAME staged rows at offsets 0/1/2
     // (RowEnt.pad1 = a pixel's extended-row index) and activations are staged once per (chunk, ky).
     const int2* ext;
-    int32_t xreuse;
+    int32_t xreuse;        // 0 off; 1 on; 2 on and the group's activation buffer is < 4 GiB (32-bit byte offsets)
     uint32_t sample_base;  // added to every MC sample index before it enters the dropout counter (sample sharding)
 };
 constexpr int XR_EXT_ROWS = 320;
