@@ -80,6 +80,85 @@ struct ConvCfg {
 // SPLIT: only the upper half of the waves issues the global->LDS staging (2x the pieces each), so the
 //      lower half starts its MFMAs right after the barrier and the two waves of every SIMD run
 //      out of phase (the matrix pipe stays fed while the other wave issues loads / waits).
+// One K-tile (BK = 64, four k-steps of 16) of MFMAs for a wave tile of FC x FP 32x32 fragments, software-
+// pipelined in registers.  `wa` / `xb[j]` are LDS byte offsets of the lane's A / B fragment rows INCLUDING the
+// swizzled chunk of k-step 0; every row base is a multiple of 128 B, so k-step ks only flips offset bits 5..6.
+// A fragment i lives at wa + i*32 rows.  Every ds_read_b128 is issued >= 2-4 MFMAs before its first use and
+// one read is slotted per MFMA, so the only exposed LDS wait is the first fragment set after the block barrier.
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SGB_DSRD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+template <int FC, int FP, int ROWB>
+struct KTilePipe {
+    const char* smem; int wa; int xb[FP];
+    bf16x8 Ac[FC == 4 ? 2 : FC], Bc[FP];            // fragments of k-step 0, loaded by first_loads()
+    __device__ __forceinline__ bf16x8 ldA(int i, int ks) const { return *reinterpret_cast<const bf16x8*>(smem + ((wa ^ (ks << 5)) + i * 32 * ROWB)); }
+    __device__ __forceinline__ bf16x8 ldB(int j, int ks) const { return *reinterpret_cast<const bf16x8*>(smem + (xb[j] ^ (ks << 5))); }
+
+    // Issue the first fragment set right after the block barrier; the caller then issues the next tile's
+    // LDS-DMA (between two sched_barriers) under this one exposed LDS wait, and calls run().
+    __device__ __forceinline__ void first_loads() {
+        Ac[0] = ldA(0, 0);
+#pragma unroll
+        for (int j = 0; j < FP; ++j) Bc[j] = ldB(j, 0);
+#pragma unroll
+        for (int i = 1; i < (FC == 4 ? 2 : FC); ++i) Ac[i] = ldA(i, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    __device__ __forceinline__ void run(f32x16 (&acc)[FC][FP]) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FC == 4 && FP == 2) {
+            // A fragments double-buffered in pairs (i = 0,1 | 2,3), B fragments across k-steps: 32 fragment registers
+            bf16x8 A23[2], Bn[2];
+#define MFMA_ROW(I, AF) \
+    acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[0], acc[I][0], 0, 0, 0); \
+    acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[1], acc[I][1], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                A23[0] = ldA(2, ks); A23[1] = ldA(3, ks);          // phase P: MFMAs of A0,A1 | loads A2,A3, next B0,B1
+                Bn[0] = ldB(0, ks + 1); Bn[1] = ldB(1, ks + 1);
+                MFMA_ROW(0, Ac[0]) MFMA_ROW(1, Ac[1])
+                SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1);
+                Ac[0] = ldA(0, ks + 1); Ac[1] = ldA(1, ks + 1);    // phase Q: MFMAs of A2,A3 | loads next A0,A1
+                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+                SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
+                Bc[0] = Bn[0]; Bc[1] = Bn[1];
+            }
+            A23[0] = ldA(2, 3); A23[1] = ldA(3, 3);
+            MFMA_ROW(0, Ac[0]) MFMA_ROW(1, Ac[1])
+            SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
+            MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+            SGB_MFMA(4);
+#undef MFMA_ROW
+        } else {
+            // other wave tiles (FC = 2, FP = 1 or 2 in production): all fragments of the next k-step in a second register set
+            bf16x8 An[FC], Bn[FP];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) An[i] = ldA(i, ks + 1);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) Bn[j] = ldB(j, ks + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac[i], Bc[j], acc[i][j], 0, 0, 0);
+                if (ks < 3) {
+                    if constexpr (FC == 2 && FP == 2) { SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); }
+                    else if constexpr (FC == 2 && FP == 1) { SGB_MFMA(1); SGB_DSRD(2); SGB_MFMA(1); SGB_DSRD(1); }
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) Ac[i] = An[i];
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) Bc[j] = Bn[j];
+                }
+            }
+        }
+    }
+};
+
 template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, const int bx, const int by, char* smem) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
@@ -227,7 +306,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             }
         }
         if (!row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    } else if constexpr (XR && ABL == 80) {
+    } else if constexpr (XR && ABL != 81) {
         // Row-reuse loop, second generation: (a) compact staging state -- one weight pointer plus scalar
         // row strides, 32-bit activation offsets against the group's base pointer, advanced incrementally
         // per (chunk, ky) group -- frees the registers for (b) a software-pipelined fragment schedule: per
@@ -284,18 +363,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             const int g = cc * 3 + ky;
             int nkx = kx + 1, nky = ky, ncc = cc;
             if (nkx == 3) { nkx = 0; if (++nky == 3) { nky = 0; ++ncc; } }
-            // fragment addresses: every row base is a multiple of 128 B, so the k-step only flips address bits 5..6
-            const int wa = (kt & 1) * WST + a_row;                         // LDS byte offsets
+            KTilePipe<FC, FP, ROWB> pipe;
+            pipe.smem = smem;
+            pipe.wa = (kt & 1) * WST + a_row;
             const int xbase = 2 * WST + (g & 1) * XBUF;
-            int xb[FP];
 #pragma unroll
-            for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kx; xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
-            auto ldA = [&](int i, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((wa ^ (ks << 5)) + i * 32 * ROWB)); };
-            auto ldB = [&](int j, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (xb[j] ^ (ks << 5))); };
-            bf16x8 A01[2], A23[2], Bc[2], Bn[2];
-            A01[0] = ldA(0, 0); Bc[0] = ldB(0, 0); Bc[1] = ldB(1, 0); A01[1] = ldA(1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < KT) {
+            for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kx; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
+            pipe.first_loads();
+            if (kt + 1 < KT && ABL != 2) {
                 issue_wx((kt + 1) & 1, nky, nkx, ncc);
                 if (g + 1 < NG) {
                     if (kx == 0) issue_xe((g + 1) & 1, ky + 1 < 3, 0, 2);
@@ -303,36 +378,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
                     else issue_xe((g + 1) & 1, ky + 1 < 3, 4, NXE);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#define MFMA_ROW(I, AF) \
-    acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[0], acc[I][0], 0, 0, 0); \
-    acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, Bc[1], acc[I][1], 0, 0, 0);
-#define SGB_MFMA_DS() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-            for (int ks = 0; ks < BK / 16 - 1; ++ks) {
-                // phase P: MFMAs of A0,A1 | loads A2,A3 (this k-step), B0,B1 (next k-step)
-                A23[0] = ldA(2, ks); A23[1] = ldA(3, ks);
-                Bn[0] = ldB(0, ks + 1); Bn[1] = ldB(1, ks + 1);
-                MFMA_ROW(0, A01[0]) MFMA_ROW(1, A01[1])
-                SGB_MFMA_DS() SGB_MFMA_DS() SGB_MFMA_DS() SGB_MFMA_DS()
-                // phase Q: MFMAs of A2,A3 | loads A0,A1 (next k-step)
-                A01[0] = ldA(0, ks + 1); A01[1] = ldA(1, ks + 1);
-                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
-                SGB_MFMA_DS() SGB_MFMA_DS()
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                Bc[0] = Bn[0]; Bc[1] = Bn[1];
-            }
-            {
-                constexpr int ks = BK / 16 - 1;
-                A23[0] = ldA(2, ks); A23[1] = ldA(3, ks);
-                MFMA_ROW(0, A01[0]) MFMA_ROW(1, A01[1])
-                SGB_MFMA_DS() SGB_MFMA_DS()
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-#undef MFMA_ROW
-#undef SGB_MFMA_DS
+            pipe.run(acc);
             kx = nkx; ky = nky; cc = ncc;
         }
     } else if constexpr (XR) {
@@ -408,32 +454,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             }
             kx = nkx; ky = nky; cc = ncc;
         }
-    } else
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < KT) {
-            if (++kx == a.KW) { kx = 0; if (++ky == KH) { ky = 0; ++cc; } }
-            if (ABL != 2 && loader) issue(cur ^ 1, ky, kx, cc);
+    } else {
+        const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = kt + 1 < KT;
+            if (more) { if (++kx == a.KW) { kx = 0; if (++ky == KH) { ky = 0; ++cc; } } }
+            if (ABL == 3) { if (more && loader) issue(cur ^ 1, ky, kx, cc); cur ^= 1; continue; }
+            KTilePipe<FC, FP, ROWB> pipe;
+            pipe.smem = smem;
+            pipe.wa = cur * STAGE + (wc * WTC + frow) * ROWB + a_c0;
+#pragma unroll
+            for (int j = 0; j < FP; ++j) pipe.xb[j] = cur * STAGE + W_BYTES + (wp * WTP + j * 32 + frow) * ROWB + a_c0;
+            pipe.first_loads();
+            if (more && ABL != 2 && loader) issue(cur ^ 1, ky, kx, cc);
+            pipe.run(acc);
+            cur ^= 1;
         }
-        if (ABL == 3) { cur ^= 1; continue; }
-        const char* wb = smem + cur * STAGE + (wc * WTC + frow) * ROWB;
-        const char* xb = smem + cur * STAGE + W_BYTES + (wp * WTP + frow) * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int ch = ((ks * 2 + fhalf) ^ fswz) << 4;
-            bf16x8 af[FC], bfr[FP];
-#pragma unroll
-            for (int i = 0; i < FC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * ROWB + ch);
-#pragma unroll
-            for (int j = 0; j < FP; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(xb + j * 32 * ROWB + ch);
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        cur ^= 1;
     }
 
     if (ABL == 1) {
@@ -732,11 +770,14 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (variant == 0 && env_sched && big) variant = env_sched;
     if (a.xreuse) {
         if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
-        if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, false, false, false, true>(a, s);
-        if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);
-        // xreuse == 2: every activation byte offset fits 32 bits -> compact-state, software-pipelined loop
-        if (a.variant == 80 || (a.variant == 0 && a.xreuse == 2)) return launch_cfg<256, 256, 2, 4, 80, false, false, false, true>(a, s);
-        if (a.variant == 81) return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);   // first-generation loop (A/B timing)
+        // xreuse == 2: every activation byte offset fits 32 bits -> compact-state, software-pipelined loop;
+        // otherwise (or variant 81, for A/B timing) the first-generation loop with 64-bit pointers
+        if (a.xreuse != 2 || a.variant == 81) return launch_cfg<256, 256, 2, 4, 81, false, false, false, true>(a, s);
+        if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, false, false, false, true>(a, s);     // no epilogue
+        if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);     // no staging after tile 0
+        if (a.variant == 4) return launch_cfg<256, 256, 2, 4, 4, false, false, false, true>(a, s);     // cheap hash instead of Philox
+        if (a.variant == 30) return launch_cfg<256, 256, 2, 4, 30, false, false, false, true>(a, s);   // no global stores
+        if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, false, false, false, true>(a, s);   // epilogue ends after bias/ReLU/pack
         return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
     }
     switch (variant) {
