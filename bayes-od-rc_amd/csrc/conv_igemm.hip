@@ -80,6 +80,24 @@ struct ConvCfg {
 // SPLIT: only the upper half of the waves issues the global->LDS staging (2x the pieces each), so the
 //      lower half starts its MFMAs right after the barrier and the two waves of every SIMD run
 //      out of phase (the matrix pipe stays fed while the other wave issues loads / waits).
+// Phase clock of the instrumented build (variant 90, tests/tools/bench_head_conv.py): wave 0 of every
+// workgroup adds the shader-clock cycles it spent between consecutive stamps; slot 15 counts tiles.
+__device__ unsigned long long g_phase_cycles[16];
+template <int ABL>
+__device__ __forceinline__ void phase_stamp(unsigned long long& t, int slot) {
+    if constexpr (ABL == 90) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[slot], now - t);
+        t = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+void conv_igemm_phase_cycles(unsigned long long* out16, bool reset) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+}
+
 // One K-tile (BK = 64, four k-steps of 16) of MFMAs for a wave tile of FC x FP 32x32 fragments, software-
 // pipelined in registers.  `wa` / `xb[j]` are LDS byte offsets of the lane's A / B fragment rows INCLUDING the
 // swizzled chunk of k-step 0; every row base is a multiple of 128 B, so k-step ks only flips offset bits 5..6.
@@ -179,6 +197,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
     float* s_bias = reinterpret_cast<float*>(smem + Cfg::OFF_BIAS);
     int* s_off2 = reinterpret_cast<int*>(smem + Cfg::OFF_OUT2);
 
+    unsigned long long tstamp = 0;
+    if constexpr (ABL == 90) { tstamp = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[15], 1ull); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
@@ -257,6 +277,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
     const int fhalf = lane >> 5;
     int ky = 0, kx = 0, cc = 0;
     const int KH = a.taps / a.KW;
+    phase_stamp<ABL>(tstamp, 0);            // tile set-up (row table, bias, pointers)
     if (loader && !XR) issue(0, 0, 0, 0);
     int cur = 0;
     if constexpr (STAG) {
@@ -357,29 +378,67 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0 (k-step ks: ^ (ks << 5))
         const int a_row = (wc * WTC + frow) * ROWB + a_c0;
         const int NG = KT / 3;
-        for (int kt = 0; kt < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int g = cc * 3 + ky;
-            int nkx = kx + 1, nky = ky, ncc = cc;
-            if (nkx == 3) { nkx = 0; if (++nky == 3) { nky = 0; ++ncc; } }
-            KTilePipe<FC, FP, ROWB> pipe;
-            pipe.smem = smem;
-            pipe.wa = (kt & 1) * WST + a_row;
-            const int xbase = 2 * WST + (g & 1) * XBUF;
+        // One (chunk, ky) group = three K-tiles (kx = 0,1,2, unrolled so the staged piece indices are compile-time).
+        // The next tile's LDS-DMA pieces are NOT issued in a burst after the barrier (both waves of a SIMD would
+        // sit in that burst together with the matrix pipe idle) but one at a time in MFMA shadows: W pieces after
+        // MFMAs 4, 8, 12, 16 and the (at most two) activation pieces after MFMAs 20 and 24 of the 32.
+        for (int g = 0; g < NG; ++g) {
+            const bool xnext = g + 1 < NG;
+            const bool next_row = ky + 1 < 3;
+            const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
 #pragma unroll
-            for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kx; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
-            pipe.first_loads();
-            if (kt + 1 < KT && ABL != 2) {
-                issue_wx((kt + 1) & 1, nky, nkx, ncc);
-                if (g + 1 < NG) {
-                    if (kx == 0) issue_xe((g + 1) & 1, ky + 1 < 3, 0, 2);
-                    else if (kx == 1) issue_xe((g + 1) & 1, ky + 1 < 3, 2, 4);
-                    else issue_xe((g + 1) & 1, ky + 1 < 3, 4, NXE);
+            for (int kxc = 0; kxc < 3; ++kxc) {
+                const int kt = g * 3 + kxc;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const bool wnext = kt + 1 < KT && ABL != 2;
+                // weight tile kt+1 = tap (ky, kxc+1) of this chunk, or tap (ky+1 | 0, 0) of the next group's chunk
+                int woff;
+                if (kxc < 2) woff = ((ky * 3 + kxc + 1) * a.cin + cc * BK) * 2;
+                else woff = next_row ? (((ky + 1) * 3) * a.cin + cc * BK) * 2 : ((cc + 1) * BK) * 2;
+                const int wdst = ((kt + 1) & 1) * WST;
+                KTilePipe<FC, FP, ROWB> pipe;
+                pipe.smem = smem;
+                pipe.wa = (kt & 1) * WST + a_row;
+                const int xbase = 2 * WST + (g & 1) * XBUF;
+#pragma unroll
+                for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
+                pipe.first_loads();
+                bf16x8 A23[2], Bn[2];
+#define MFMA_ROW(I, AF) \
+    acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, pipe.Bc[0], acc[I][0], 0, 0, 0); \
+    acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, pipe.Bc[1], acc[I][1], 0, 0, 0);
+#define DMA_W(I) if (wnext) { int off = woff + (I) * wrs; asm volatile("" : "+s"(off)); \
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + wdst + ((I) * THREADS + wave * 64) * 16), 16, 0, 0); }
+#define DMA_X(I) if ((I) < NXE && xnext && ABL != 2) { xo[(I) < NXE ? (I) : 0] += next_row ? (uint32_t)xp[(I) < NXE ? (I) : 0] : (uint32_t)(BK * 2 - 2 * xp[(I) < NXE ? (I) : 0]); \
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[(I) < NXE ? (I) : 0]), LDS_PTR(smem + xdst + (((I) < NXE ? (I) : 0) * THREADS + wave * 64) * 16), 16, 0, 0); }
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    A23[0] = pipe.ldA(2, ks); A23[1] = pipe.ldA(3, ks);
+                    Bn[0] = pipe.ldB(0, ks + 1); Bn[1] = pipe.ldB(1, ks + 1);
+                    MFMA_ROW(0, pipe.Ac[0]) MFMA_ROW(1, pipe.Ac[1])
+                    SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 0) { DMA_W(0) } else if (ks == 1) { DMA_W(2) } else { DMA_X(2 * kxc) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pipe.Ac[0] = pipe.ldA(0, ks + 1); pipe.Ac[1] = pipe.ldA(1, ks + 1);
+                    MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+                    SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 0) { DMA_W(1) } else if (ks == 1) { DMA_W(3) } else { DMA_X(2 * kxc + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pipe.Bc[0] = Bn[0]; pipe.Bc[1] = Bn[1];
                 }
+                A23[0] = pipe.ldA(2, 3); A23[1] = pipe.ldA(3, 3);
+                MFMA_ROW(0, pipe.Ac[0]) MFMA_ROW(1, pipe.Ac[1])
+                SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
+                MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
+                SGB_MFMA(4);
+#undef MFMA_ROW
+#undef DMA_W
+#undef DMA_X
             }
-            pipe.run(acc);
-            kx = nkx; ky = nky; cc = ncc;
+            if (++ky == 3) { ky = 0; ++cc; }
         }
     } else if constexpr (XR) {
         // Activation row reuse: per (channel chunk, ky) the tile's extended rows are staged ONCE and the
@@ -474,6 +533,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         }
     }
 
+    phase_stamp<ABL>(tstamp, 1);            // main loop
     if (ABL == 1) {
 #pragma unroll
         for (int i = 0; i < FC; ++i)
@@ -554,6 +614,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
             }
         }
     }
+    phase_stamp<ABL>(tstamp, 2);            // barrier + bias/ReLU/scale/pack
     __builtin_amdgcn_sched_barrier(0);
     // fused 1x1 head conv: wave w owns cout2 fragment w/2 and pixel fragments (w&1)*HALFP.. of the tile;
     // its 16 weight fragments (64 VGPRs) are fetched now and land while phase B (Philox, LDS writes) runs
@@ -613,7 +674,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
                 }
             }
         }
+        phase_stamp<ABL>(tstamp, 3);        // Philox mask + LDS tile writes
         __syncthreads();
+        phase_stamp<ABL>(tstamp, 4);        // barrier
         if (ABL == 52) continue;
         if (fuse) {
             if (fuse_active) {
@@ -665,6 +728,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
                 *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out_relu) + e) = r;
             }
         }
+        phase_stamp<ABL>(tstamp, 5);        // store loop (issue)
         if (n + 1 < fan) __syncthreads();
     }
 }
@@ -777,6 +841,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);     // no staging after tile 0
         if (a.variant == 4) return launch_cfg<256, 256, 2, 4, 4, false, false, false, true>(a, s);     // cheap hash instead of Philox
         if (a.variant == 30) return launch_cfg<256, 256, 2, 4, 30, false, false, false, true>(a, s);   // no global stores
+        if (a.variant == 90) return launch_cfg<256, 256, 2, 4, 90, false, false, false, true>(a, s);   // phase clock
         if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, false, false, false, true>(a, s);   // epilogue ends after bias/ReLU/pack
         return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
     }

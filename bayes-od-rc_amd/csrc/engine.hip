@@ -1425,6 +1425,15 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (variant == 90) {
+        unsigned long long c[16];
+        conv_igemm_phase_cycles(c, true);
+        const double tiles = (double)c[15];
+        static const char* names[6] = {"set-up", "main loop", "barrier+bias/relu/pack", "philox+lds writes", "barrier", "store loop"};
+        fprintf(stderr, "# phase clock, wave 0, cycles per tile (%.0f tiles):", tiles);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "  %s %.0f", names[k], (double)c[k] / tiles);
+        fprintf(stderr, "\n");
+    }
     *mean_ms = ms / iters;
     if (flops) *flops = op->flops;
     return BOD_OK;

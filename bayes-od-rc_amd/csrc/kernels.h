@@ -75,6 +75,7 @@ constexpr int XR_EXT_ROWS = 320;
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible
+void conv_igemm_phase_cycles(unsigned long long* out16, bool reset);   // instrumented build (variant 90)
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
 
 // ------------------------------------------------------------------------------------------------
