@@ -95,9 +95,9 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--mc", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
