@@ -73,6 +73,7 @@ struct bod_context {
 
     // activations
     float* d_images = nullptr;
+    uint8_t* d_frames_u8 = nullptr; size_t frames_u8_cap = 0;     // staging for bod_upload_frames_u8 (plain hipMalloc, grows)
     char* stem_out = nullptr;
     int es = 2;                                          // bytes per activation / weight element (2 = bf16, 4 = fp32)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
@@ -847,6 +848,7 @@ bod_status bod_destroy(bod_handle h) {
     for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
+    if (h->d_frames_u8) hipFree(h->d_frames_u8);
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (h->stream) hipStreamDestroy(h->stream);
@@ -924,6 +926,46 @@ bod_status bod_upload_images(bod_handle h, const float* host_images) {
     const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
     HIPCHK(h, hipMemcpyAsync(h->d_images, host_images, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
+                                int32_t aspect_resize) {
+    if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
+    const bod_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    PreprocArgs a{};
+    a.B = c.batch; a.sh = src_h; a.sw = src_w; a.H = c.image_h; a.W = c.image_w; a.resize = aspect_resize ? 1 : 0;
+    a.rh = src_h; a.rw = src_w;
+    if (aspect_resize) {
+        // tf.image.resize(..., preserve_aspect_ratio=True): scale = min(H/sh, W/sw) in float32, size = round(s * in)
+        const float fh = (float)c.image_h / (float)src_h, fw = (float)c.image_w / (float)src_w;
+        const float sc = fh < fw ? fh : fw;
+        a.rh = (int32_t)std::nearbyint(sc * (float)src_h);
+        a.rw = (int32_t)std::nearbyint(sc * (float)src_w);
+        if (a.rh < 1 || a.rw < 1) return h->fail(BOD_ERR_INVALID_ARG, "bod_upload_frames_u8: degenerate resize %dx%d", a.rh, a.rw);
+    } else if (src_h != c.image_h || src_w != c.image_w) {
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_upload_frames_u8: frames are %dx%d but the handle expects %dx%d (pass aspect_resize=1 for "
+                       "the KITTI-style resize + crop/pad)", src_h, src_w, c.image_h, c.image_w);
+    }
+    a.scale_y = (float)src_h / (float)a.rh; a.scale_x = (float)src_w / (float)a.rw;
+    const int dh = c.image_h - a.rh, dw = c.image_w - a.rw;                 // resize_with_crop_or_pad (floor division like Python)
+    auto fdiv2 = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
+    a.crop_y = std::max(fdiv2(-dh), 0); a.crop_x = std::max(fdiv2(-dw), 0);
+    a.pad_y = std::max(fdiv2(dh), 0); a.pad_x = std::max(fdiv2(dw), 0);
+    a.vis_h = std::min(a.rh, c.image_h); a.vis_w = std::min(a.rw, c.image_w);
+    for (int k = 0; k < 3; ++k) a.mean[k] = rgb_means[k];
+    const size_t bytes = (size_t)c.batch * src_h * src_w * 3;
+    if (bytes > h->frames_u8_cap) {
+        if (h->d_frames_u8) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_frames_u8); h->d_frames_u8 = nullptr; h->frames_u8_cap = 0; }
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_frames_u8), bytes) != hipSuccess)
+            return h->fail(BOD_ERR_OOM, "bod_upload_frames_u8: %zu bytes of staging", bytes);
+        h->frames_u8_cap = bytes;
+    }
+    a.src = h->d_frames_u8; a.dst = h->d_images;
+    HIPCHK(h, hipMemcpyAsync(h->d_frames_u8, rgb, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_preprocess(a, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // the caller may reuse `rgb` on return
     return BOD_OK;
 }
 

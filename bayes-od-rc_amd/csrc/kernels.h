@@ -154,6 +154,19 @@ struct ClusterArgs {
 hipError_t launch_cluster_fuse(const ClusterArgs& a, hipStream_t s);
 hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s);
 
+struct PreprocArgs {
+    const uint8_t* src;        // [B, sh, sw, 3] uint8 RGB
+    float* dst;                // [B, H, W, 3] fp32 BGR, mean-subtracted
+    int32_t B, sh, sw;         // source size
+    int32_t rh, rw;            // size after the (optional) aspect-preserving bilinear resize (= sh, sw without)
+    int32_t H, W;              // network input size
+    int32_t crop_y, crop_x, pad_y, pad_x, vis_h, vis_w;   // tf.image.resize_with_crop_or_pad geometry
+    int32_t resize;
+    float scale_y, scale_x;    // sh/rh, sw/rw as float32
+    float mean[3];             // RGB order
+};
+hipError_t launch_preprocess(const PreprocArgs& a, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // Loss forward (loss_kernels.hip)
 // ------------------------------------------------------------------------------------------------

@@ -800,3 +800,52 @@ hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_
                        reinterpret_cast<const float4*>(corners), M, out);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Frame preprocessing on the device (the dataset handlers' work between image decode and
+// sample_dict['image_normalized']): uint8 RGB -> [optional KITTI bilinear resize + centred crop / zero pad]
+// -> float32, mean subtraction, RGB -> BGR  (bdd_dataset_handler.py:128-139, kitti_dataset_handler.py:120-148).
+// One thread per output pixel; fp32 operation order identical to oracle/preprocess.py (this file is built
+// with -ffp-contract=off), so results are bit-exact.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= a.W) return;
+    const int ry = y - a.pad_y + a.crop_y, rx = x - a.pad_x + a.crop_x;     // coordinates in the (resized) source
+    float v[3] = {0.f, 0.f, 0.f};                                            // zero padding (before mean subtraction)
+    const bool inside = y >= a.pad_y && x >= a.pad_x && ry < a.rh && rx < a.rw && ry >= 0 && rx >= 0 &&
+                        y - a.pad_y < a.vis_h && x - a.pad_x < a.vis_w;
+    if (inside) {
+        const uint8_t* src = a.src + (size_t)b * a.sh * a.sw * 3;
+        if (!a.resize) {
+            const uint8_t* p = src + ((size_t)ry * a.sw + rx) * 3;
+            v[0] = (float)p[0]; v[1] = (float)p[1]; v[2] = (float)p[2];
+        } else {
+            const float fy = ((float)ry + 0.5f) * a.scale_y - 0.5f;
+            const float fx = ((float)rx + 0.5f) * a.scale_x - 0.5f;
+            const float fy0 = floorf(fy), fx0 = floorf(fx);
+            const float ly = fy - fy0, lx = fx - fx0;
+            const int y0 = min(max((int)fy0, 0), a.sh - 1), y1 = min(max((int)ceilf(fy), 0), a.sh - 1);
+            const int x0 = min(max((int)fx0, 0), a.sw - 1), x1 = min(max((int)ceilf(fx), 0), a.sw - 1);
+            const uint8_t* p00 = src + ((size_t)y0 * a.sw + x0) * 3;
+            const uint8_t* p01 = src + ((size_t)y0 * a.sw + x1) * 3;
+            const uint8_t* p10 = src + ((size_t)y1 * a.sw + x0) * 3;
+            const uint8_t* p11 = src + ((size_t)y1 * a.sw + x1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float tl = (float)p00[c], tr = (float)p01[c], bl = (float)p10[c], br = (float)p11[c];
+                const float top = tl + (tr - tl) * lx;
+                const float bot = bl + (br - bl) * lx;
+                v[c] = top + (bot - top) * ly;
+            }
+        }
+    }
+    float* o = a.dst + (((size_t)b * a.H + y) * a.W + x) * 3;
+    o[0] = v[2] - a.mean[2]; o[1] = v[1] - a.mean[1]; o[2] = v[0] - a.mean[0];
+}
+
+hipError_t launch_preprocess(const PreprocArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3((a.W + 255) / 256, a.H, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

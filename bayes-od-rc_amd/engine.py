@@ -122,6 +122,27 @@ class Engine(object):
         a = self._img(images)
         self._chk(self.lib.bod_upload_images(self.h, fptr(a)))
 
+    def upload_frames_u8(self, frames_rgb_u8, means=None, aspect_resize=False):
+        """Decoded uint8 RGB frames [B,h,w,3] -> the device image buffer, preprocessed on the device like the
+        reference's dataset handlers (mean subtraction, BGR flip; aspect_resize=True adds KITTI's bilinear
+        aspect-preserving resize + centred crop/pad).  Then call forward()/infer() with images=None."""
+        from . import constants
+        a = np.ascontiguousarray(frames_rgb_u8, dtype=np.uint8)
+        if a.ndim != 4 or a.shape[0] != self.B or a.shape[3] != 3:
+            raise ValueError("expected uint8 frames of shape (%d, h, w, 3), got %s" % (self.B, a.shape))
+        m = np.ascontiguousarray(constants.MEANS_DICT['ImageNet'] if means is None else means, dtype=np.float32)
+        self._chk(self.lib.bod_upload_frames_u8(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[2],
+                                                fptr(m), int(bool(aspect_resize))))
+
+    def get_images(self):
+        """The device image buffer [B,H,W,3] float32 (normalised BGR) copied to the host."""
+        import torch
+        from .distributed import DeviceArray
+        ptr = self.lib.bod_device_images(self.h)
+        t = torch.as_tensor(DeviceArray(ptr, (self.B, self.cfg.image_h, self.cfg.image_w, 3), "<f4"),
+                            device=torch.device("cuda", self.cfg.device))
+        return t.cpu().numpy()
+
     def forward(self, images=None, seed=0, first_image_id=0):
         """images=None => use the device-resident buffer filled by upload_images()."""
         if images is None:

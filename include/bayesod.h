@@ -189,6 +189,13 @@ bod_status bod_collect(bod_handle h, int32_t slot, int32_t* num_detections, floa
 /* Device buffer of [batch,H,W,3] fp32 owned by the handle (fill with bod_upload_images, then
  * pass to bod_forward/bod_infer with images_on_device=1). */
 bod_status bod_upload_images(bod_handle h, const float* host_images);
+/* Same destination, filled from decoded uint8 RGB frames [batch, src_h, src_w, 3]: the dataset handlers'
+ * preprocessing runs on the device -- float conversion, mean subtraction (rgb_means[3], constants.py:12),
+ * RGB->BGR (bdd_dataset_handler.py:128-139) and, with aspect_resize != 0, KITTI's
+ * tf.image.resize(BILINEAR, preserve_aspect_ratio=True) + resize_with_crop_or_pad to the network size
+ * (kitti_dataset_handler.py:120-148).  A quarter of the PCIe bytes of bod_upload_images. */
+bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w,
+                                const float* rgb_means, int32_t aspect_resize);
 const float* bod_device_images(bod_handle h);
 bod_status bod_synchronize(bod_handle h);
 

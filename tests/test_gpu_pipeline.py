@@ -288,3 +288,38 @@ def test_sample_sharded_engine_world1():
     ref.infer(frames, seed=1, first_image_id=7)
     for a, b in zip(got[0], ref.get_detections(0)):
         assert np.array_equal(a, b)
+
+
+def test_run_inference_on_a_kitti_tree(tmp_path, monkeypatch):
+    """--dataset: KITTI frames on disk -> dataset handler -> uint8 upload -> device resize/normalise ->
+    BayesOD -> KITTI txt rows + .npy files (BASELINE config 4's route, BDD-trained classes mapped to KITTI)."""
+    import os
+    import yaml
+    from PIL import Image
+    from bayes_od_rc_amd import config_utils, run_inference
+    monkeypatch.setenv("BAYESOD_DATA_DIR", str(tmp_path / "data"))
+    root = tmp_path / "object"
+    (root / "training" / "image_2").mkdir(parents=True)
+    (root / "training" / "label_2").mkdir()
+    ids = ["000000", "000001", "000002"]
+    (root / "test.txt").write_text("\n".join(ids) + "\n")
+    rng = np.random.default_rng(5)
+    for i, sid in enumerate(ids):
+        hw = (94, 310) if i < 2 else (92, 306)            # a size change forces a second batch / engine
+        Image.fromarray(rng.integers(0, 256, size=hw + (3,), dtype=np.uint8)).save(str(root / "training" / "image_2" / (sid + ".png")))
+        (root / "training" / "label_2" / (sid + ".txt")).write_text(
+            "Car 0.00 0 -1.57 100.00 20.00 200.00 80.00 1.5 1.6 3.9 1.0 1.5 10.0 -1.5\n")
+    here = os.path.dirname(os.path.abspath(run_inference.__file__))
+    cfg = config_utils.load_yaml(os.path.join(here, "configs", "retinanet_bdd_covar.yaml"))
+    cfg["dataset_config"]["kitti"]["paths_config"]["dataset_dir"] = str(root)
+    cfg["dataset_config"]["kitti"]["resize_shape"] = [128, 416]
+    cfg["testing_config"]["test_dataset"] = "kitti"
+    ypath = tmp_path / "retinanet_bdd_covar.yaml"          # the file name must equal checkpoint_name (config_utils.py, like the reference)
+    ypath.write_text(yaml.safe_dump(cfg))
+    out = run_inference.main(["--gpu_device", "0", "--yaml_path", str(ypath), "--data_split", "test", "--dataset", "--batch", "2"])
+    assert os.path.join("predictions", "testing", "kitti") in out
+    for sid in ids:
+        mean = np.load(os.path.join(out, "mean", sid + ".npy"))
+        par = np.load(os.path.join(out, "cat_param", sid + ".npy"))
+        assert mean.shape[1:] == (4,) and par.shape == (mean.shape[0], 8)
+        assert os.path.exists(os.path.join(out, "data", sid + ".txt"))
