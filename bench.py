@@ -125,10 +125,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # BOD_BENCH_BACKEND=gloo + BOD_BENCH_SHARE_GPU=1: exercise the N>1 code path on a ONE-GPU box (all ranks on
+    # device 0, records gathered through host memory) -- tests/test_gpu_pipeline.py; the driver's runs use RCCL.
+    backend = os.environ.get("BOD_BENCH_BACKEND", "nccl")
+    if os.environ.get("BOD_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     hw, n, B = (args.height, args.width), args.mc, args.batch
     fwd_only = args.forward_only or n < 2
@@ -160,7 +168,7 @@ def main():
             eng.wait_slot(slot)
             v = views[slot]
             rec = bdist.pack_records(v["num"], v["scores"], v["means"], v["covs"], v["counts"])
-            allrec = bdist.gather_records(rec, dst=0)
+            allrec = bdist.gather_records(rec if backend == "nccl" else rec.cpu(), dst=0)
             if rank == 0:
                 gathered = allrec.cpu()
         else:
@@ -201,7 +209,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_images = world * B * args.steps

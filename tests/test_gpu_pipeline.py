@@ -323,3 +323,28 @@ def test_run_inference_on_a_kitti_tree(tmp_path, monkeypatch):
         par = np.load(os.path.join(out, "cat_param", sid + ".npy"))
         assert mean.shape[1:] == (4,) and par.shape == (mean.shape[0], 8)
         assert os.path.exists(os.path.join(out, "data", sid + ".txt"))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 path of bench.py (sharding, slot views, pack, gather, max-over-ranks timing) launched exactly as the
+    driver does, but with both ranks on this box's single GPU and the gather through gloo."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BOD_BENCH_BACKEND="gloo", BOD_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    rec = json.loads(line[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert "cpu_baseline" not in rec
