@@ -799,11 +799,22 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// 256x256 tiles (one 8-wave workgroup per CU) pay once there are at least ~1.5 workgroups per CU; below that
+// half the chip idles and the 128x128 configuration (two workgroups per CU, 4x the tiles) is 20-25 % faster
+// (measured on the stage-4 / FPN layers: 128 big tiles for 256 CUs).
+static bool conv_big_tile_pays(const ConvArgs& a) {
+    if (a.cout_pad % 256 != 0 || (a.flags & CONV_OUT_F32)) return false;
+    static const bool old_rule = getenv("BOD_TILE_RULE_OLD") != nullptr;          // A/B aid
+    if (old_rule) return a.M >= 16384;
+    const long tiles = (long)((a.M + 255) / 256) * (a.cout_pad / 256) * (a.groups > 0 ? a.groups : 1);
+    return tiles >= 384;
+}
+
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a) {
     // 256x256 tiles once there are enough pixel tiles to fill the chip; BOD_FORCE_CONV_TILE=256|128
     // overrides the size heuristic (tests exercise both configurations on small inputs)
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
-    bool big = a.cout_pad % 256 == 0 && a.M >= 16384 && !(a.flags & CONV_OUT_F32);
+    bool big = conv_big_tile_pays(a);
     // the N-way dropout fan-out epilogue is VALU-bound (N Philox rounds per tile): run it with two
     // resident blocks per CU (128x128 tiles) so one block's epilogue overlaps the other's MFMA loop
     if (a.fan_count > 1) big = false;
@@ -816,7 +827,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
-    bool big = a.cout_pad % 256 == 0 && a.M >= 16384 && !(a.flags & CONV_OUT_F32);
+    bool big = conv_big_tile_pays(a);
     if (a.fan_count > 1) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
     if (forced == 128) big = false;
