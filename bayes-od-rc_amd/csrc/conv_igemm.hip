@@ -178,7 +178,7 @@ struct KTilePipe {
 };
 
 template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
-__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, const int bx, const int by, char* smem) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = SPLIT ? THREADS / 2 : THREADS;   // threads that stage
@@ -202,10 +202,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
+    const int nsplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int grp = gz / nsplit, kpart = gz - grp * nsplit;          // split-K: this workgroup reduces chunks [c_begin, c_begin + cpt)
     const ConvGroup& G = a.g[grp];
     const int bp0 = bx * BP, bc0 = by * BC;
-    const int cpt = a.cin / BK;                  // K-tiles per tap
+    const int cpt = a.cin / BK / nsplit;         // K-tiles per tap (of this split)
+    const int c_begin = kpart * cpt;
     const int KT = (ABL >= 50 && ABL <= 53) ? 1 : a.taps * cpt;   // 50..53: epilogue-only timing probes
+    const int wrow = a.taps * a.cin;             // elements per weight row [cout][taps][cin]
 
     // ---- per-thread staging descriptors
     const bool loader = !SPLIT || tid >= THREADS / 2;
@@ -221,14 +225,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         m = m < a.M ? m : a.M - 1;
         const int2 e = *reinterpret_cast<const int2*>(&a.rows[m]);
         xsrc[i] = reinterpret_cast<const char*>(G.in) +
-                  ((size_t)e.x * a.in_cstride + G.in_coff + ldchunk * 8) * 2;
+                  ((size_t)e.x * a.in_cstride + G.in_coff + c_begin * BK + ldchunk * 8) * 2;
         xpitch[i] = e.y * a.in_cstride * 2;
     }
     const char* wsrc[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int co = bc0 + i * RPI + ldrow;
-        wsrc[i] = reinterpret_cast<const char*>(G.w) + ((size_t)co * KT * BK + ldchunk * 8) * 2;
+        wsrc[i] = reinterpret_cast<const char*>(G.w) + ((size_t)co * wrow + c_begin * BK + ldchunk * 8) * 2;
     }
     for (int i = tid; i < BP; i += THREADS) {
         const int m = bp0 + i;
@@ -338,7 +342,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
         const char* in_base = reinterpret_cast<const char*>(G.in) + G.in_coff * 2;
         const char* wbase = wsrc[0];
-        const int wrs = RPI * KT * BK * 2;                                  // bytes between the rows of two weight pieces
+        const int wrs = RPI * wrow * 2;                                     // bytes between the rows of two weight pieces
         uint32_t xo[NXE];
         int xp[NXE];
 #pragma unroll
@@ -546,6 +550,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int grp, cons
         return;
     }
 
+    if (nsplit > 1) {
+        // ---- split-K: raw fp32 accumulators of this split; conv_splitk_reduce_kernel finishes the layer
+        float* part = a.partial + (size_t)gz * a.M * a.cout_pad;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = bp0 + wp * WTP + j * 32 + frow;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = bc0 + wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
+                    *reinterpret_cast<float4*>(part + (size_t)m * a.cout_pad + co) =
+                        make_float4(acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]);
+                }
+        }
+        return;
+    }
     const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT, of32 = a.flags & CONV_OUT_F32;
     if (of32) {
         // ---- fp32 outputs (head 1x1 convs): direct stores, per-channel validity
@@ -794,9 +816,51 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(nx, ny, a.groups);
+    dim3 grid(nx, ny, a.groups * (a.ksplit > 1 ? a.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::LDS, s, a);
     return hipGetLastError();
+}
+
+// Split-K reduce: out[m][co] = act(sum_s partial[s][m][co] + bias[co] (+ residual)) -> bf16 through the row table.
+// One thread per 8 output channels (16-byte stores); the same fp32 operation order for every split count.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
+    const int c8 = a.cout_pad / 8;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int grp = blockIdx.y;
+    if (q >= (long)a.M * c8) return;
+    const int m = (int)(q / c8), co = (int)(q % c8) * 8;
+    if (co >= a.cout_valid) return;
+    const ConvGroup& G = a.g[grp];
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    for (int s = 0; s < a.ksplit; ++s) {
+        const float* p = a.partial + ((size_t)(grp * a.ksplit + s) * a.M + m) * a.cout_pad + co;
+        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+    }
+    const RowEnt e = a.rows[m];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += G.bias[co + k];
+    if (G.res) {
+        const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)e.res_off * a.res_cstride + co);
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32(rw[k] & 0xFFFFu); v[2 * k + 1] += bf16_to_f32(rw[k] >> 16); }
+    }
+    if (a.flags & CONV_RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    const size_t off = (size_t)e.out_off * a.out_cstride + co;
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + off) = o;
+    if (G.out_relu) {
+        uint4 r;
+        r.x = relu_bf16x2(o.x); r.y = relu_bf16x2(o.y); r.z = relu_bf16x2(o.z); r.w = relu_bf16x2(o.w);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out_relu) + off) = r;
+    }
 }
 
 // 256x256 tiles (one 8-wave workgroup per CU) pay once there are at least ~1.5 workgroups per CU; below that
@@ -833,6 +897,16 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (forced == 128) big = false;
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
+    if (a.ksplit > 1) {
+        if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & (CONV_DROPOUT | CONV_OUT_F32)) || a.variant != 0)
+            return hipErrorInvalidValue;
+        for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
+        hipError_t e = a.cout_pad % 128 == 0 ? launch_cfg<128, 128, 2, 2, 0>(a, s) : launch_cfg<64, 128, 1, 4, 0>(a, s);
+        if (e != hipSuccess) return e;
+        const long q = (long)a.M * (a.cout_pad / 8);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((q + 255) / 256), a.groups), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     // BOD_CONV_SCHEDULE=stag|persist|stag_persist selects the experimental schedules of the 256x256
     // configuration for every eligible launch (bit-identical results; tests/test_gpu_conv.py)
     static const int env_sched = [] {

@@ -73,6 +73,7 @@ struct bod_context {
 
     // activations
     float* d_images = nullptr;
+    float* splitk_partial = nullptr; size_t splitk_elems = 0;        // fp32 partial sums of the split-K layers
     uint8_t* d_frames_u8 = nullptr; size_t frames_u8_cap = 0;     // staging for bod_upload_frames_u8 (plain hipMalloc, grows)
     char* stem_out = nullptr;
     int es = 2;                                          // bytes per activation / weight element (2 = bf16, 4 = fp32)
@@ -282,6 +283,19 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     op.conv.flags = relu ? CONV_RELU : 0;
     op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
     op.name = name;
+    // Split-K for layers with too few output tiles to fill the chip and a long reduction (P6 always; most of
+    // stage 3-5 at batch 1): enough splits for >= ~256 workgroups, each keeping >= 4 K-tiles.
+    static const bool splitk_on = [] { const char* e = getenv("BOD_CONV_SPLITK"); return !e || atoi(e) != 0; }();
+    if (splitk_on && h->es == 2) {
+        const long tiles = (long)((op.conv.M + 127) / 128) * (pc.cout_pad % 128 == 0 ? pc.cout_pad / 128 : pc.cout_pad / 64);
+        const int chunks = pc.cin / 64;
+        int S = 1;
+        while (tiles * S < 256 && S * 2 <= 16 && chunks % (S * 2) == 0 && (long)pc.taps * (chunks / (S * 2)) >= 4) S *= 2;
+        if (S > 1) {
+            op.conv.ksplit = S;
+            h->splitk_elems = std::max(h->splitk_elems, (size_t)S * op.conv.M * pc.cout_pad);
+        }
+    }
     h->ops.push_back(op);
     return BOD_OK;
 }
@@ -606,6 +620,10 @@ bod_status build_plan(bod_context* h) {
         op.flops = 2.0 * a.M * pc.cout * 256.0;
         op.name = kHeadPrefix[hd];
         h->ops.push_back(op);
+    }
+    if (h->splitk_elems) {
+        BODCHK(h->dalloc(&h->splitk_partial, h->splitk_elems));
+        for (Op& o : h->ops) if (o.kind == Op::CONV && o.conv.ksplit > 1) o.conv.partial = h->splitk_partial;
     }
     return BOD_OK;
 }
@@ -1380,6 +1398,13 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
         a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 65536.0);
         a.drop_scale = (float)(1.0 / (1.0 - (double)dropout_rate));
+        if (const char* ks = getenv("BOD_STAGE_KSPLIT")) {        // test hook: run this stage through the split-K path
+            const int S = atoi(ks);
+            if (S > 1 && !f32_out && !drop && (Cin / 64) % S == 0 && Cin % 64 == 0) {
+                a.ksplit = S;
+                BODCHK(h->dalloc(&a.partial, (size_t)S * a.M * a.cout_pad));
+            }
+        }
         HIPCHK(h, f32 ? launch_conv_igemm_f32(a, h->stream) : launch_conv_igemm(a, h->stream));
         if (f32_out) {
             HIPCHK(h, hipMemcpyAsync(out, d_out32, n_out * 4, hipMemcpyDeviceToHost, h->stream));

@@ -69,6 +69,12 @@ struct ConvArgs {
     // (RowEnt.pad1 = a pixel's extended-row index) and activations are staged once per (chunk, ky).
     const int2* ext;
     int32_t xreuse;        // 0 off; 1 on; 2 on and the group's activation buffer is < 4 GiB (32-bit byte offsets)
+    // Split-K (small-M layers: P6, the stage-4/5 layers at batch 1): ksplit > 1 splits the input-channel chunks over
+    // ksplit workgroups per tile (blockIdx.z = group * ksplit + split); every split writes its raw fp32 accumulators to
+    // partial[(z * M + m) * cout_pad + co] and launch_conv_igemm runs the reduce kernel (sum, bias, residual, ReLU,
+    // bf16 store through the row table) behind it.  cin / 64 must be divisible by ksplit.
+    int32_t ksplit;
+    float* partial;
     uint32_t sample_base;  // added to every MC sample index before it enters the dropout counter (sample sharding)
 };
 constexpr int XR_EXT_ROWS = 320;

@@ -172,3 +172,33 @@ def test_fp32_conv_residual_relu_dropout():
     ref = ref * np.float64(np.float32(1.0 / 0.7)) * keep
     assert np.all(got[~keep] == 0)
     assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 2e-5
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,padding,split,res", [
+    (2, 16, 16, 2048, 256, 3, 2, "same", 8, False),      # P6: 16x16x2048 -> 8x8x256, K = 18432
+    (1, 8, 8, 1024, 512, 1, 1, "valid", 4, True),        # stage-5 1x1 at batch 1, with shortcut + ReLU
+    (1, 11, 9, 512, 192, 3, 1, "same", 2, False),        # ragged M, 64-wide cout tile
+])
+def test_split_k_matches_oracle_and_unsplit(monkeypatch, b, h, w, cin, cout, k, stride, padding, split, res):
+    """Split-K (small-M layers): partial fp32 sums over channel-chunk ranges + the reduce kernel give the oracle's
+    result within the conv tolerance and the un-split kernel's bf16 output up to rare 1-ulp flips."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(cin + cout + split)
+    x, wt, bias = _case(rng, b, h, w, cin, cout, k)
+    oh = -(-h // stride) if padding == "same" else (h - k) // stride + 1
+    ow = -(-w // stride) if padding == "same" else (w - k) // stride + 1
+    residual = rng.normal(0, 1, (b, oh, ow, cout)).astype(np.float32) if res else None
+    kw = dict(stride=stride, padding=padding, relu=res, residual=residual, round_output_bf16=True)
+    plain = stage_conv(x, wt, bias, **kw)
+    monkeypatch.setenv("BOD_STAGE_KSPLIT", str(split))
+    got = stage_conv(x, wt, bias, **kw)
+    monkeypatch.delenv("BOD_STAGE_KSPLIT")
+    ref = _oracle(x, wt, bias, stride, padding, relu=res, residual=residual)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert rel_err(got, ref, floor=rms) < 6e-3                    # bf16-stored output: half an ulp of 2^-8
+    mism = got != plain
+    assert mism.mean() < 5e-3
+    # one bf16 ulp, plus the fp32 re-association error of the K-long sum where the result nearly cancels
+    assert np.all(np.abs(got - plain)[mism] <= np.abs(plain[mism]) * 2.0 ** -7 + 1e-4 * rms)
+    assert np.array_equal(got, network.bf16_round(got))
