@@ -202,7 +202,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
-    const int nsplit = a.ksplit > 1 ? a.ksplit : 1;
+    // split-K exists only in the 4-wave configurations (the 256x256 tile has no registers to spare for it)
+    constexpr bool CAN_SPLITK = (BC <= 128) && !XR && !STAG;
+    const int nsplit = (CAN_SPLITK && a.ksplit > 1) ? a.ksplit : 1;
     const int grp = gz / nsplit, kpart = gz - grp * nsplit;          // split-K: this workgroup reduces chunks [c_begin, c_begin + cpt)
     const ConvGroup& G = a.g[grp];
     const int bp0 = bx * BP, bc0 = by * BC;
@@ -550,7 +552,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         return;
     }
 
-    if (nsplit > 1) {
+    if (CAN_SPLITK && nsplit > 1) {
         // ---- split-K: raw fp32 accumulators of this split; conv_splitk_reduce_kernel finishes the layer
         float* part = a.partial + (size_t)gz * a.M * a.cout_pad;
 #pragma unroll

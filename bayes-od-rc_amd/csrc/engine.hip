@@ -1483,6 +1483,14 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
     if (!op) return h->fail(BOD_ERR_INVALID_ARG, "no head layer %d", layer);
     ConvArgs a = op->conv;
     a.variant = variant;
+    // BOD_BENCH_ZERO=1: time the identical launch on zero-filled activations (DVFS / power-limit probe: the matrix
+    // pipe toggles far less on zeros, so any speed-up is clock, not work).  Destroys the head buffers' contents.
+    if (const char* z = getenv("BOD_BENCH_ZERO")) {
+        if (atoi(z) != 0 && layer > 0) {
+            const size_t bytes = (size_t)h->cfg.batch * h->cfg.mc_samples * h->Ppad * 256 * h->es;
+            for (int g = 0; g < a.groups; ++g) HIPCHK(h, hipMemsetAsync(const_cast<void*>(a.g[g].in), 0, bytes, h->stream));
+        }
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, launch_conv_igemm(a, h->stream));            // warm-up
