@@ -952,6 +952,11 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         case 40: return launch_cfg<256, 256, 2, 4, 0, false, false, true>(a, s);
         case 41: return launch_cfg<256, 256, 2, 4, 0, false, true, true>(a, s);
         case 42: return launch_cfg<256, 256, 2, 4, 1, false, true, true>(a, s);
+        case 91: return launch_cfg<128, 128, 2, 2, 90>(a, s);      // 128x128: phase clock
+        case 92: return launch_cfg<128, 128, 2, 2, 1>(a, s);       // 128x128: no epilogue
+        case 93: return launch_cfg<128, 128, 2, 2, 4>(a, s);       // 128x128: cheap hash instead of Philox
+        case 94: return launch_cfg<256, 256, 2, 4, 0>(a, s);       // fan-out layer on the 256x256 tile
+        case 95: return launch_cfg<128, 128, 2, 2, 30>(a, s);      // 128x128: no global stores
         case 11: return launch_cfg<256, 256, 2, 4, 11>(a, s);
         case 12: return launch_cfg<256, 256, 2, 4, 12>(a, s);
         case 7: return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
