@@ -56,6 +56,7 @@ SIGNATURES = {
     "bod_set_raw": (C.c_int, [_H, _F, _F, _F]),
     "bod_get_pyramid": (C.c_int, [_H, C.c_int32, _F]),
     "bod_posterior": (C.c_int, [_H, C.c_uint64, C.c_uint32]),
+    "bod_validation_post": (C.c_int, [_H]),
     "bod_get_num_kept": (C.c_int, [_H, _I]),
     "bod_get_posterior": (C.c_int, [_H, C.c_int32, _F, _F, _F, _F, _F, _I]),
     "bod_set_posterior": (C.c_int, [_H, C.c_int32, C.c_int32, _F, _F, _F, _F]),

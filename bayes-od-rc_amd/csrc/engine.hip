@@ -1066,6 +1066,21 @@ bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id) {
     return run_posterior(h, seed, first_image_id);
 }
 
+bod_status bod_validation_post(bod_handle h) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward / bod_set_raw has not run");
+    if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (int sidx = 0; sidx < 2; ++sidx)
+        if (h->side_pending[sidx]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[sidx], 0));
+    PostCfg pc = post_cfg(h, 0, 0);
+    PostBuffers pb = h->pb;
+    pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
+    HIPCHK(h, launch_validation_post(pc, pb, h->stream));
+    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    return BOD_OK;
+}
+
 bod_status bod_get_num_kept(bod_handle h, int32_t* out) {
     if (!h || !out) return BOD_ERR_INVALID_ARG;
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");

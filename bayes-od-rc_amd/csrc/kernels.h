@@ -128,6 +128,7 @@ struct PostBuffers {
 
 hipError_t launch_posterior(const PostCfg& c, const PostBuffers& b, hipStream_t s);
 hipError_t launch_joint_entropy_rank(const PostCfg& c, const PostBuffers& b, hipStream_t s);
+hipError_t launch_validation_post(const PostCfg& c, const PostBuffers& b, hipStream_t s);   // validation_utils.py:10-77
 
 struct NmsArgs {
     int32_t B, A;                 // per-image capacity A

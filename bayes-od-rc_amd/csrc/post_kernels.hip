@@ -380,6 +380,96 @@ hipError_t launch_posterior(const PostCfg& c, const PostBuffers& b, hipStream_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Validation post-processing (src/retina_net/experiments/validation_utils.py:10-77): deterministic single
+// forward pass -> softmax -> drop anchors whose arg-max class is background -> rank by the top score -> the
+// same soft-NMS kernel.  The compacted candidates land in the posterior buffers (score = counts = softmax row,
+// means = decoded box, covs = 0), so bod_nms and the getters serve both paths.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(POST_BLOCK) void val_flag_kernel(PostCfg c, PostBuffers pb, int nblocks) {
+    const int a = blockIdx.x * POST_BLOCK + threadIdx.x;
+    const int b = blockIdx.y;
+    bool keep = false;
+    if (a < c.A) {
+        const float* l = pb.cls + (((size_t)b * c.N) * c.A + a) * C;        // sample 0
+        float v[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) v[j] = l[j];
+        float mx = v[0];
+#pragma unroll
+        for (int j = 1; j < C; ++j) mx = fmaxf(mx, v[j]);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) { v[j] = expf(v[j] - mx); s += v[j]; }
+        int best = 0; float bestp = v[0] / s;
+        float* dc = pb.d_counts + ((size_t)b * c.A + a) * C;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float pj = v[j] / s;
+            dc[j] = pj;
+            if (j > 0 && pj > bestp) { bestp = pj; best = j; }                // tf.argmax: first maximum
+        }
+        keep = best != C - 1;
+        pb.keep[(size_t)b * c.A + a] = keep ? 1 : 0;
+    }
+    const int n = __syncthreads_count(keep ? 1 : 0);
+    if (threadIdx.x == 0) pb.block_counts[(size_t)b * nblocks + blockIdx.x] = n;
+}
+
+template <int C>
+__global__ __launch_bounds__(POST_BLOCK) void val_fuse_kernel(PostCfg c, PostBuffers pb, int nblocks) {
+    __shared__ int wave_off[POST_BLOCK / 64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = blockIdx.x * POST_BLOCK + tid;
+    const int b = blockIdx.y;
+    const bool keep = (a < c.A) && pb.keep[(size_t)b * c.A + a];
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_off[wave + 1] = __popcll(bal);
+    if (tid == 0) wave_off[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int w = 1; w <= POST_BLOCK / 64; ++w) wave_off[w] += wave_off[w - 1];
+    __syncthreads();
+    if (!keep) return;
+    const int slot = pb.block_counts[(size_t)b * nblocks + blockIdx.x] + wave_off[wave] + before;
+    const size_t o = (size_t)b * c.A + slot;
+    const float4 anc = reinterpret_cast<const float4*>(pb.anchors)[a];
+    const float4 t = reinterpret_cast<const float4*>(pb.box)[((size_t)b * c.N) * c.A + a];
+    float bx[4];
+    decode_box(anc, t, bx);                                                   // box_utils.box_from_anchor_and_target (:149-168)
+    const float* dc = pb.d_counts + ((size_t)b * c.A + a) * C;
+    float top = dc[0];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { pb.counts[o * C + j] = dc[j]; pb.score[o * C + j] = dc[j]; top = fmaxf(top, dc[j]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb.means[o * 4 + i] = bx[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pb.covs[o * 16 + i] = 0.f;
+    pb.ranking[o] = top;
+    // vuhw_to_vuvu (box_utils.py:5-23)
+    reinterpret_cast<float4*>(pb.corners)[o] = make_float4(bx[0] - bx[2] / 2.0f, bx[1] - bx[3] / 2.0f, bx[0] + bx[2] / 2.0f, bx[1] + bx[3] / 2.0f);
+    pb.anchor_index[o] = a;
+}
+
+hipError_t launch_validation_post(const PostCfg& c, const PostBuffers& b, hipStream_t s) {
+    const int nblocks = (c.A + POST_BLOCK - 1) / POST_BLOCK;
+    dim3 grid(nblocks, c.B);
+    if (c.C == 8) {
+        hipLaunchKernelGGL(val_flag_kernel<8>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+        hipLaunchKernelGGL(post_scan_kernel, dim3(c.B), dim3(POST_BLOCK), 0, s, b, nblocks);
+        hipLaunchKernelGGL(val_fuse_kernel<8>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+    } else if (c.C == 4) {
+        hipLaunchKernelGGL(val_flag_kernel<4>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+        hipLaunchKernelGGL(post_scan_kernel, dim3(c.B), dim3(POST_BLOCK), 0, s, b, nblocks);
+        hipLaunchKernelGGL(val_fuse_kernel<4>, grid, dim3(POST_BLOCK), 0, s, c, b, nblocks);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // joint-entropy ranking (:169-200): min-max normalised information gains, one block per image
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float det4(const float* m) {

@@ -209,6 +209,10 @@ class Engine(object):
     def posterior(self, seed=0, first_image_id=0):
         self._chk(self.lib.bod_posterior(self.h, seed, first_image_id))
 
+    def validation_post(self):
+        """validation_utils.post_process_predictions up to the NMS input (softmax, background filter, ranking)."""
+        self._chk(self.lib.bod_validation_post(self.h))
+
     def num_kept(self):
         out = np.zeros(self.B, np.int32)
         self._chk(self.lib.bod_get_num_kept(self.h, iptr(out)))

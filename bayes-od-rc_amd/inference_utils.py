@@ -6,7 +6,7 @@ pipeline through the C ABI.  Nothing here computes on the host except array resh
 """
 import numpy as np
 
-from . import constants
+from . import _lib, box_utils, constants
 
 
 def _bayes_testing_kwargs(bayes_od_config, nms_config, use_full_covar, dataset_name, sample_dict,
@@ -147,3 +147,37 @@ class BayesOdPipeline(object):
         (output_classes [K,C], output_boxes_vuhw [K,4], output_covs [K,4,4], output_counts [K,C])."""
         self.engine.infer(images, seed=seed, first_image_id=first_image_id)
         return [self.engine.get_detections(b) for b in range(self.engine.B)]
+
+
+def post_process_predictions(sample_dict, prediction_dict, dataset_name='bdd', engine=None, nms_config=None):
+    """Validation post-processing with the reference's signature and return value
+    (src/retina_net/experiments/validation_utils.py:10-77): ``(predicted_boxes_classes [K,C],
+    predicted_boxes_corners [K,4])`` of the first image of the batch -- softmax, background filter, soft-NMS on the
+    top score -- computed on the device (``bod_validation_post`` + ``bod_nms``).  ``engine``: the handle that produced
+    ``prediction_dict`` (default: a post-only handle of the right geometry is created)."""
+    from .engine import Engine, make_config
+    anchors = _lib.as_f32(np.asarray(sample_dict[constants.ANCHORS_KEY]))
+    if anchors.ndim == 3:
+        anchors = anchors[0]
+    cls = _lib.as_f32(np.asarray(prediction_dict[constants.ANCHORS_CLASS_PREDICTIONS_KEY]))[0:1]
+    box = _lib.as_f32(np.asarray(prediction_dict[constants.ANCHORS_BOX_PREDICTIONS_KEY]))[0:1]
+    image = np.asarray(sample_dict[constants.IMAGE_NORMALIZED_KEY])
+    hw = image.shape[1:3] if image.ndim == 4 else image.shape[0:2]
+    if engine is None:
+        engine = Engine(make_config(hw, batch=1, mc_samples=1, num_classes=cls.shape[-1], nms_config=nms_config,
+                                    has_covar_head=False))
+        engine.set_anchors(anchors)
+    if (engine.B, engine.N) != (1, 1):
+        raise ValueError("post_process_predictions works on a batch-1, single-sample handle")
+    engine.set_raw(cls.reshape(1, 1, -1, cls.shape[-1]), box.reshape(1, 1, -1, 4), None)
+    engine.validation_post()
+    engine.nms()
+    post = engine.get_posterior(0)
+    idx = engine.get_nms(0)
+    corners = box_utils.vuhw_to_vuvu_np(post["means"]) if post["means"].size else np.zeros((0, 4), np.float32)
+    if dataset_name == 'kitti':
+        orig = np.asarray(sample_dict[constants.ORIGINAL_IM_SIZE_KEY]).reshape(-1)[-3:]
+        n = np.asarray([hw[0], hw[1]] * 2, np.float32)
+        s = np.asarray([orig[0], orig[1]] * 2, np.float32)
+        corners = (corners / n) * s
+    return post["score"][idx], corners[idx]

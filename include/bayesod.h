@@ -127,6 +127,11 @@ bod_status bod_get_pyramid(bod_handle h, int32_t level_index, float* out);
  * decode, softmax, mean over MC, categorical sampling, filter, per-anchor mean / 4x4 covariance,
  * aleatoric L D L^T, mixing, Dirichlet + Gaussian prior fusion, ranking; compacted in anchor order. */
 bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id);
+/* validation_utils.post_process_predictions (:10-77), the deterministic validation path: softmax of MC sample 0
+ * of the raw class outputs, anchors whose arg-max class is background dropped, candidates ranked by their top
+ * score.  Fills the same compacted buffers as bod_posterior (score = counts = softmax row, means = decoded
+ * box, covs = 0), so bod_nms / bod_get_posterior / bod_get_nms follow as usual. */
+bod_status bod_validation_post(bod_handle h);
 /* Per image results of bod_posterior. num_kept[batch]; the arrays are [M,...] for image_index.
  * counts/score [M,C], means [M,4], covs [M,16], ranking [M], anchor_index [M]. NULLs skipped. */
 bod_status bod_get_num_kept(bod_handle h, int32_t* num_kept);

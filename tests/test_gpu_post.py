@@ -207,3 +207,30 @@ def test_iou_matrix_matches_reference_formula(golden_dir):
     eng.set_posterior(0, counts, means[:, :, 0], covs, np.zeros(len(counts), np.float32))
     iou = eng.get_iou_matrix(0)
     assert rel_err(iou, g[t + "_iou"], 1e-4) < 1e-5
+
+
+@pytest.mark.parametrize("dataset", ["bdd", "kitti"])
+def test_validation_post_process_matches_oracle(dataset):
+    """validation_utils.post_process_predictions (:10-77) on the device: kept set and soft-NMS order exact,
+    class rows / corners within 1e-5."""
+    from bayes_od_rc_amd import constants, inference_utils
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from conftest import ANCHOR_CFG
+    from oracle import validation
+    hw = (128, 160)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    a = anchors.shape[0]
+    rng = np.random.default_rng(3)
+    logits = rng.normal(0, 1.5, (1, a, 8)).astype(np.float32)
+    logits[..., 7] += 1.0                                         # background wins for most anchors
+    box_t = rng.normal(0, 0.6, (1, a, 4)).astype(np.float32)
+    sample = {constants.ANCHORS_KEY: anchors[None], constants.IMAGE_NORMALIZED_KEY: np.zeros((1,) + hw + (3,), np.float32),
+              constants.ORIGINAL_IM_SIZE_KEY: np.asarray([[375, 1242, 3]], np.int32)}
+    pred = {constants.ANCHORS_CLASS_PREDICTIONS_KEY: logits, constants.ANCHORS_BOX_PREDICTIONS_KEY: box_t}
+    classes, corners = inference_utils.post_process_predictions(sample, pred, dataset_name=dataset)
+    ref_c, ref_b, info = validation.post_process_predictions(anchors, box_t[0], logits[0], dataset_name=dataset, net_hw=hw,
+                                                             orig_hw=(375, 1242), dtype=np.float32)
+    assert 50 < info["keep"].sum() < a and len(info["nms"]) == 100
+    assert classes.shape == ref_c.shape and corners.shape == ref_b.shape
+    assert np.abs(classes - ref_c).max() < 1e-5
+    assert np.abs(corners - ref_b).max() < 1e-3 * max(1.0, float(np.abs(ref_b).max()))
