@@ -155,6 +155,44 @@ def main():
                         box=box, boxes=boxes, two_d_iou=iou, recalls=rec, precisions=prec,
                         ap=np.float64(ap))
 
+    # ------------------------------------------------------------------ AP / minimum uncertainty error (f4)
+    def _records(rng, n_img, n_gt, n_pred):
+        cats = ["car", "person", "truck"]
+        gt, pred = [], []
+        for i in range(n_img):
+            for _ in range(int(rng.integers(0, n_gt + 1))):
+                x, y = rng.uniform(0, 300, 2)
+                w, h = rng.uniform(20, 120, 2)
+                gt.append({"name": "im%03d" % i, "category": cats[int(rng.integers(0, 3))],
+                           "bbox": [float(x), float(y), float(x + w), float(y + h)]})
+        for g in gt:                                   # detections: jittered copies of the ground truth + clutter
+            if rng.uniform() < 0.8:
+                j = rng.normal(0, 6, 4)
+                pred.append({"name": g["name"], "category": g["category"] if rng.uniform() < 0.9 else cats[int(rng.integers(0, 3))],
+                             "bbox": [float(v) for v in (np.asarray(g["bbox"]) + j)],
+                             "score": float(rng.uniform(0.3, 1.0)), "entropy_score": float(rng.uniform(0, 3))})
+        for _ in range(n_pred):
+            x, y = rng.uniform(0, 300, 2)
+            w, h = rng.uniform(20, 120, 2)
+            pred.append({"name": "im%03d" % int(rng.integers(0, n_img + 2)), "category": cats[int(rng.integers(0, 3))],
+                         "bbox": [float(x), float(y), float(x + w), float(y + h)],
+                         "score": float(rng.uniform(0.0, 0.7)), "entropy_score": float(rng.uniform(1, 5))})
+        return gt, pred
+    import copy
+    eval_cases = []
+    for seed, (n_img, n_gt, n_pred) in enumerate(((4, 3, 5), (12, 5, 30), (30, 4, 80))):
+        gt, pred = _records(np.random.default_rng(100 + seed), n_img, n_gt, n_pred)
+        thr = [0.5] if seed != 1 else [0.7]     # one threshold per call, as every script of the reference does
+        # (cat_pc indexes the prediction list with a FLAT arg-max over [detections, thresholds]: more than one
+        # threshold overruns the list, evaluation_utils_2d.py:123)
+        m_ap, aps, cats, opt, fmax = ref_ev.evaluate_detection(copy.deepcopy(gt), copy.deepcopy(pred), thr)
+        mues, mue, cats_u, at = ref_ev.evaluate_u_error(copy.deepcopy(gt), copy.deepcopy(pred), thr)
+        eval_cases.append({"gt": gt, "pred": pred, "thresholds": thr, "mAP": float(m_ap), "aps": aps, "cat_list": cats,
+                           "optimal_score_thresholds": opt, "maximum_f_scores": fmax, "min_u_errors": mues,
+                           "min_u_error": float(mue), "scores_at_min_u_errors": at})
+    with open(os.path.join(OUT, "eval_metrics.json"), "w") as fp:
+        json.dump(eval_cases, fp)
+
     # ------------------------------------------------------------------ writers
     rng = np.random.default_rng(17)
     out_boxes = np.concatenate([rng.uniform(0, 200, (6, 2)), rng.uniform(200, 500, (6, 2))], 1)
