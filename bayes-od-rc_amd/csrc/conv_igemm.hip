@@ -198,7 +198,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     int* s_off2 = reinterpret_cast<int*>(smem + Cfg::OFF_OUT2);
 
     unsigned long long tstamp = 0;
-    if constexpr (ABL == 90) { tstamp = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[15], 1ull); }
+    unsigned long long treal = 0;
+    if constexpr (ABL == 90) { tstamp = __builtin_amdgcn_s_memtime(); treal = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[15], 1ull); }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
@@ -753,6 +754,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             }
         }
         phase_stamp<ABL>(tstamp, 5);        // store loop (issue)
+        if constexpr (ABL == 90) { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[14], __builtin_amdgcn_s_memrealtime() - treal); }   // 100 MHz ticks
         if (n + 1 < fan) __syncthreads();
     }
 }
@@ -786,6 +788,46 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_persistent_kernel(con
         conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG, false>(a, z, rem % nx, rem / nx, smem);
         __syncthreads();                         // LDS (epilogue tile + metadata) is reused by the next tile
     }
+}
+
+// Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
+// items, XCD x owning a contiguous eighth of them (neighbouring tiles share halo rows in that XCD's L2).  Removes the
+// workgroup retire / dispatch gap between tiles (measured with the phase clock: tiles cover 1.26-1.30 ms of a
+// 1.35-1.38 ms launch per CU).
+template <int ABL>
+__global__ __launch_bounds__(512) void conv_igemm_xr_persistent_kernel(const ConvArgs a, const int nx, const int total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = gridDim.x;                    // multiple of 8
+    const int v = __builtin_amdgcn_readfirstlane((blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3));
+    const int per = total / nb, extra = total - per * nb;
+    int t = __builtin_amdgcn_readfirstlane(v * per + (v < extra ? v : extra));
+    const int t1 = __builtin_amdgcn_readfirstlane(t + per + (v < extra ? 1 : 0));
+    for (; t < t1; ++t) {
+        const int z = t / nx;
+        conv_tile<256, 256, 2, 4, ABL, false, false, true>(a, z, t - z * nx, 0, smem);
+        __syncthreads();                         // LDS (epilogue tile + metadata) is reused by the next tile
+    }
+}
+
+template <int ABL>
+static hipError_t launch_xr_persistent(const ConvArgs& a, hipStream_t s) {
+    using Cfg = ConvCfg<256, 256, 2, 4, true>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    auto kern = conv_igemm_xr_persistent_kernel<ABL>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        n_cu = prop.multiProcessorCount & ~7;
+        attr_set = true;
+    }
+    const int nx = (a.M + 255) / 256, total = nx * a.groups;
+    const int nb = total < n_cu ? ((total + 7) & ~7) : n_cu;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(512), Cfg::LDS, s, a, nx, total);
+    return hipGetLastError();
 }
 
 template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT = false, bool STAG = false, bool PERSIST = false, bool XR = false>
@@ -929,6 +971,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         if (a.variant == 4) return launch_cfg<256, 256, 2, 4, 4, false, false, false, true>(a, s);     // cheap hash instead of Philox
         if (a.variant == 30) return launch_cfg<256, 256, 2, 4, 30, false, false, false, true>(a, s);   // no global stores
         if (a.variant == 90) return launch_cfg<256, 256, 2, 4, 90, false, false, false, true>(a, s);   // phase clock
+        if (a.variant == 96) return launch_xr_persistent<0>(a, s);                                      // persistent, one workgroup per CU
         if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, false, false, false, true>(a, s);   // epilogue ends after bias/ReLU/pack
         return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
     }

@@ -1522,7 +1522,9 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
         static const char* names[6] = {"set-up", "main loop", "barrier+bias/relu/pack", "philox+lds writes", "barrier", "store loop"};
         fprintf(stderr, "# phase clock, wave 0, cycles per tile (%.0f tiles):", tiles);
         for (int k = 0; k < 6; ++k) fprintf(stderr, "  %s %.0f", names[k], (double)c[k] / tiles);
-        fprintf(stderr, "\n");
+        double cyc = 0; for (int k = 0; k < 6; ++k) cyc += (double)c[k];
+        fprintf(stderr, "  | shader clock during the tiles %.3f GHz (cycles / 100 MHz real-time ticks); tiles account for %.3f ms of the %.3f ms launch per CU\n",
+                cyc / (double)c[14] * 0.1, (double)c[14] / tiles * 1e-5 * (tiles / (iters + 1)) / 256.0, ms / iters);
     }
     *mean_ms = ms / iters;
     if (flops) *flops = op->flops;
