@@ -177,11 +177,11 @@ struct KTilePipe {
     }
 };
 
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
-    constexpr int LTHREADS = SPLIT ? THREADS / 2 : THREADS;   // threads that stage
+    constexpr int LTHREADS = THREADS;            // threads that stage
     constexpr int RPI = LTHREADS / 8;            // tile rows covered by one staging instruction
     constexpr int BK = 64;                       // bf16 per K-tile row (128 B)
     constexpr int ROWB = BK * 2;
@@ -204,19 +204,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
     // split-K exists only in the 4-wave configurations (the 256x256 tile has no registers to spare for it)
-    constexpr bool CAN_SPLITK = (BC <= 128) && !XR && !STAG;
+    constexpr bool CAN_SPLITK = (BC <= 128) && !XR;
     const int nsplit = (CAN_SPLITK && a.ksplit > 1) ? a.ksplit : 1;
     const int grp = gz / nsplit, kpart = gz - grp * nsplit;          // split-K: this workgroup reduces chunks [c_begin, c_begin + cpt)
     const ConvGroup& G = a.g[grp];
     const int bp0 = bx * BP, bc0 = by * BC;
     const int cpt = a.cin / BK / nsplit;         // K-tiles per tap (of this split)
     const int c_begin = kpart * cpt;
-    const int KT = (ABL >= 50 && ABL <= 53) ? 1 : a.taps * cpt;   // 50..53: epilogue-only timing probes
+    const int KT = a.taps * cpt;
     const int wrow = a.taps * a.cin;             // elements per weight row [cout][taps][cin]
 
     // ---- per-thread staging descriptors
-    const bool loader = !SPLIT || tid >= THREADS / 2;
-    const int ltid = SPLIT ? (tid & (LTHREADS - 1)) : tid;
+    constexpr bool loader = true;
+    const int ltid = tid;
     const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
     const int ldrow = ltid >> 3;                             // 0..RPI-1 (+RPI*i)
     const int ldchunk = (ltid & 7) ^ ((ltid >> 4) & 7);      // source chunk (pre-swizzled)
@@ -252,7 +252,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     // the same activation rows in 9 consecutive K-tiles, so the re-reads hit L1/L2 instead of MALL/HBM
     auto issue_w = [&](int stage, int ky, int kx, int cc) {
         char* sb = smem + stage * STAGE;
-        if (ABL == 11 && (kx | ky | cc)) return;     // timing probe: no weight traffic
         const int woff = ((ky * a.KW + kx) * a.cin + cc * BK) * 2;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
@@ -262,8 +261,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     auto issue_x = [&](int stage, int ky, int kx, int cc) {
         char* sb = smem + stage * STAGE;
         const int tapoff = (kx * a.in_cstride + cc * BK) * 2;
-        if (ABL == 6 && (kx | ky)) return;          // timing probe: X traffic of a halo-reuse scheme (1 of 9 taps)
-        if (ABL == 12 && (kx | ky | cc)) return;    // timing probe: no activation traffic
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(xsrc[i] + ky * xpitch[i] + tapoff),
@@ -287,61 +284,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     phase_stamp<ABL>(tstamp, 0);            // tile set-up (row table, bias, pointers)
     if (loader && !XR) issue(0, 0, 0, 0);
     int cur = 0;
-    if constexpr (STAG) {
-        // Staggered schedule (the two wave rows of the block run one barrier apart): every k-step is a
-        // memory segment {stage pieces of the next tile, ds_read this k-step's fragments, wait} and a
-        // compute segment {8 MFMAs at raised priority}, separated by block barriers.  Wave row 1 is
-        // offset by one barrier, so on every SIMD one wave is always in its compute segment while its
-        // partner is in its memory segment.  Hazards: a stage is re-filled only after the barrier that
-        // follows the other row's last (waited) fragment read of it; a tile is read only after the
-        // barrier that follows every wave's vmcnt(0) for it.
-        static_assert(WC == 2 && !SPLIT, "staggered schedule is written for two wave rows");
-        const bool row1 = wc == 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-        for (int kt = 0; kt < KT; ++kt) {
-            const int st = kt & 1;
-            const bool more = kt + 1 < KT;
-            if (more) { if (++kx == a.KW) { kx = 0; if (++ky == KH) { ky = 0; ++cc; } } }
-            const char* wb = smem + st * STAGE + (wc * WTC + frow) * ROWB;
-            const char* xb = smem + st * STAGE + W_BYTES + (wp * WTP + frow) * ROWB;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                if (ks == 0 && more && ABL != 2) issue_w(st ^ 1, ky, kx, cc);
-                if (ks == 1 && more && ABL != 2) issue_x(st ^ 1, ky, kx, cc);
-                const int ch = ((ks * 2 + fhalf) ^ fswz) << 4;
-                bf16x8 af[FC], bfr[FP];
-#pragma unroll
-                for (int i = 0; i < FC; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 32 * ROWB + ch);
-#pragma unroll
-                for (int j = 0; j < FP; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(xb + j * 32 * ROWB + ch);
-                if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < FC; ++i)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (!row1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    } else if constexpr (XR && ABL != 81) {
+    if constexpr (XR && ABL != 81) {
         // Row-reuse loop, second generation: (a) compact staging state -- one weight pointer plus scalar
         // row strides, 32-bit activation offsets against the group's base pointer, advanced incrementally
         // per (chunk, ky) group -- frees the registers for (b) a software-pipelined fragment schedule: per
         // k-step the A fragments are double-buffered in pairs (i = 0,1 | 2,3) and the B fragments across
         // k-steps, every ds_read_b128 is issued >= 4 MFMAs before its first use, and the only exposed LDS
         // wait is the first fragment set after each block barrier (covered by issuing the LDS-DMA there).
-        static_assert(BC == 256 && BP == 256 && WC == 2 && WP == 4 && !SPLIT, "written for the 256x256 8-wave tile");
+        static_assert(BC == 256 && BP == 256 && WC == 2 && WP == 4, "written for the 256x256 8-wave tile");
         constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
         const char* in_base = reinterpret_cast<const char*>(G.in) + G.in_coff * 2;
         const char* wbase = wsrc[0];
@@ -365,16 +315,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 asm volatile("" : "+s"(off));                               // keep the sum scalar, do not hoist 4 pointers
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + stage * WST + (i * THREADS + wave * 64) * 16), 16, 0, 0);
             }
-        };
-        // pieces [i0, i1) of the NEXT group: advance the running offset, then stage
-        auto issue_xe = [&](int buf, bool next_row, int i0, int i1) {
-#pragma unroll
-            for (int i = 0; i < NXE; ++i)
-                if (i >= i0 && i < i1) {
-                    xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
-                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]),
-                                                     LDS_PTR(smem + 2 * WST + buf * XBUF + (i * THREADS + wave * 64) * 16), 16, 0, 0);
-                }
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -450,7 +390,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     } else if constexpr (XR) {
         // Activation row reuse: per (channel chunk, ky) the tile's extended rows are staged ONCE and the
         // three kx taps read them at row offsets 0/1/2; only the weights stream every K-tile.
-        static_assert(BC == 256 && BP == 256 && WC * WP == 8 && !SPLIT, "row reuse is written for the 256x256 8-wave tile");
+        static_assert(BC == 256 && BP == 256 && WC * WP == 8, "row reuse is written for the 256x256 8-wave tile");
         constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
         const char* xe[NXE];
         int xep[NXE];
@@ -527,7 +467,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             __syncthreads();
             const bool more = kt + 1 < KT;
             if (more) { if (++kx == a.KW) { kx = 0; if (++ky == KH) { ky = 0; ++cc; } } }
-            if (ABL == 3) { if (more && loader) issue(cur ^ 1, ky, kx, cc); cur ^= 1; continue; }
             KTilePipe<FC, FP, ROWB> pipe;
             pipe.smem = smem;
             pipe.wa = cur * STAGE + (wc * WTC + frow) * ROWB + a_c0;
@@ -686,7 +625,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         // dropout contract v2: one Philox call decides 8 channels with 16-bit words -- the lane's
                         // channel groups g4 = 2p and 2p+1 share the call keyed by (col>>5, p, fhalf)
                         if ((g4 & 1) == 0) {
-                            if (ABL == 4 || ABL == 51 || ABL == 52) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
+                            if (ABL == 4) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
                             else rr = philox4x32_10((uint32_t)rng[j].x, dropout_group8(bc0 + col),
                                                     sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
                         }
@@ -702,7 +641,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         phase_stamp<ABL>(tstamp, 3);        // Philox mask + LDS tile writes
         __syncthreads();
         phase_stamp<ABL>(tstamp, 4);        // barrier
-        if (ABL == 52) continue;
         if (fuse) {
             if (fuse_active) {
 #pragma unroll
@@ -761,7 +699,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 
 // One tile per workgroup.  XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous
 // range of pixel tiles so that neighbouring tiles (which share their 3x3 halo rows) share an L2.
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG, bool XR>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR>
 __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bx = blockIdx.x;
@@ -769,25 +707,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG, XR>(a, blockIdx.z, bx, blockIdx.y, smem);
-}
-
-// Persistent form: one workgroup per CU walks a contiguous range of (head, cout tile, pixel tile)
-// work items.  No workgroup retire / re-launch between tiles, and a tile's output stores drain
-// underneath the next tile's prologue and first K-tiles instead of gating the CU's next block.
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT, bool STAG>
-__global__ __launch_bounds__(64 * WC * WP) void conv_igemm_persistent_kernel(const ConvArgs a, const int nx,
-                                                                             const int ny, const int total) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nb = gridDim.x;                    // multiple of 8: XCD x gets blocks x, x+8, ...
-    const int v = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-    const int per = (total + nb - 1) / nb;
-    const int t0 = v * per, t1 = (t0 + per < total) ? t0 + per : total;
-    for (int t = t0; t < t1; ++t) {
-        const int z = t / (nx * ny), rem = t - z * (nx * ny);
-        conv_tile<BC, BP, WC, WP, ABL, SPLIT, STAG, false>(a, z, rem % nx, rem / nx, smem);
-        __syncthreads();                         // LDS (epilogue tile + metadata) is reused by the next tile
-    }
+    conv_tile<BC, BP, WC, WP, ABL, XR>(a, blockIdx.z, bx, blockIdx.y, smem);
 }
 
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
@@ -804,7 +724,7 @@ __global__ __launch_bounds__(512) void conv_igemm_xr_persistent_kernel(const Con
     const int t1 = __builtin_amdgcn_readfirstlane(t + per + (v < extra ? 1 : 0));
     for (; t < t1; ++t) {
         const int z = t / nx;
-        conv_tile<256, 256, 2, 4, ABL, false, false, true>(a, z, t - z * nx, 0, smem);
+        conv_tile<256, 256, 2, 4, ABL, true>(a, z, t - z * nx, 0, smem);
         __syncthreads();                         // LDS (epilogue tile + metadata) is reused by the next tile
     }
 }
@@ -830,30 +750,12 @@ static hipError_t launch_xr_persistent(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BC, int BP, int WC, int WP, int ABL, bool SPLIT = false, bool STAG = false, bool PERSIST = false, bool XR = false>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR = false>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     static bool attr_set = false;
     const int nx = (a.M + BP - 1) / BP, ny = a.cout_pad / BC;
-    if (PERSIST) {
-        auto kern = conv_igemm_persistent_kernel<BC, BP, WC, WP, ABL, SPLIT, STAG>;
-        static int n_cu = 0;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-            if (e != hipSuccess) return e;
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-            n_cu = prop.multiProcessorCount & ~7;
-            attr_set = true;
-        }
-        const int total = nx * ny * a.groups;
-        int nb = total < n_cu ? ((total + 7) & ~7) : n_cu;
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(Cfg::THREADS), Cfg::LDS, s, a, nx, ny, total);
-        return hipGetLastError();
-    }
-    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, SPLIT, STAG, XR>;
+    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, XR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -951,61 +853,33 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((q + 255) / 256), a.groups), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    // BOD_CONV_SCHEDULE=stag|persist|stag_persist selects the experimental schedules of the 256x256
-    // configuration for every eligible launch (bit-identical results; tests/test_gpu_conv.py)
-    static const int env_sched = [] {
-        const char* e = getenv("BOD_CONV_SCHEDULE");
-        if (!e) return 0;
-        const std::string v(e);
-        return v == "stag" ? 7 : v == "persist" ? 40 : v == "stag_persist" ? 41 : 0;
-    }();
-    int variant = a.variant;
-    if (variant == 0 && env_sched && big) variant = env_sched;
+    const int variant = a.variant;
     if (a.xreuse) {
         if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
         // xreuse == 2: every activation byte offset fits 32 bits -> compact-state, software-pipelined loop;
         // otherwise (or variant 81, for A/B timing) the first-generation loop with 64-bit pointers
-        if (a.xreuse != 2 || a.variant == 81) return launch_cfg<256, 256, 2, 4, 81, false, false, false, true>(a, s);
-        if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, false, false, false, true>(a, s);     // no epilogue
-        if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, false, false, false, true>(a, s);     // no staging after tile 0
-        if (a.variant == 4) return launch_cfg<256, 256, 2, 4, 4, false, false, false, true>(a, s);     // cheap hash instead of Philox
-        if (a.variant == 30) return launch_cfg<256, 256, 2, 4, 30, false, false, false, true>(a, s);   // no global stores
-        if (a.variant == 90) return launch_cfg<256, 256, 2, 4, 90, false, false, false, true>(a, s);   // phase clock
+        if (a.xreuse != 2 || a.variant == 81) return launch_cfg<256, 256, 2, 4, 81, true>(a, s);
+        if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, true>(a, s);     // no epilogue
+        if (a.variant == 2) return launch_cfg<256, 256, 2, 4, 2, true>(a, s);     // no staging after tile 0
+        if (a.variant == 4) return launch_cfg<256, 256, 2, 4, 4, true>(a, s);     // cheap hash instead of Philox
+        if (a.variant == 30) return launch_cfg<256, 256, 2, 4, 30, true>(a, s);   // no global stores
+        if (a.variant == 90) return launch_cfg<256, 256, 2, 4, 90, true>(a, s);   // phase clock
         if (a.variant == 96) return launch_xr_persistent<0>(a, s);                                      // persistent, one workgroup per CU
-        if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, false, false, false, true>(a, s);   // epilogue ends after bias/ReLU/pack
-        return launch_cfg<256, 256, 2, 4, 0, false, false, false, true>(a, s);
+        if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, true>(a, s);   // epilogue ends after bias/ReLU/pack
+        return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
     }
-    switch (variant) {
+    switch (variant) {          // ablation builds of the generic loop (tests/tools/bench_head_conv.py)
         case 0: break;
-        case 1: return launch_cfg<256, 256, 2, 4, 1>(a, s);
-        case 2: return launch_cfg<256, 256, 2, 4, 2>(a, s);
-        case 3: return launch_cfg<256, 256, 2, 4, 3>(a, s);
-        case 4: return launch_cfg<256, 256, 2, 4, 4>(a, s);
-        case 5: return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
-        case 6: return launch_cfg<256, 256, 2, 4, 6>(a, s);
-        case 30: return launch_cfg<256, 256, 2, 4, 30>(a, s);
-        case 31: return launch_cfg<256, 256, 2, 4, 31>(a, s);
-        case 60: return launch_cfg<256, 256, 2, 2, 0>(a, s);
-        case 61: return launch_cfg<256, 256, 2, 2, 1>(a, s);
-        case 62: return launch_cfg<256, 256, 2, 2, 2>(a, s);
-        case 50: return launch_cfg<256, 256, 2, 4, 50>(a, s);
-        case 51: return launch_cfg<256, 256, 2, 4, 51>(a, s);
-        case 52: return launch_cfg<256, 256, 2, 4, 52>(a, s);
-        case 53: return launch_cfg<256, 256, 2, 4, 53, false, false, true>(a, s);
-        case 40: return launch_cfg<256, 256, 2, 4, 0, false, false, true>(a, s);
-        case 41: return launch_cfg<256, 256, 2, 4, 0, false, true, true>(a, s);
-        case 42: return launch_cfg<256, 256, 2, 4, 1, false, true, true>(a, s);
+        case 1: return launch_cfg<256, 256, 2, 4, 1>(a, s);        // no epilogue
+        case 2: return launch_cfg<256, 256, 2, 4, 2>(a, s);        // no staging after tile 0
+        case 4: return launch_cfg<256, 256, 2, 4, 4>(a, s);        // cheap hash instead of Philox
+        case 30: return launch_cfg<256, 256, 2, 4, 30>(a, s);      // no global stores
+        case 31: return launch_cfg<256, 256, 2, 4, 31>(a, s);      // epilogue ends after bias/ReLU/pack
         case 91: return launch_cfg<128, 128, 2, 2, 90>(a, s);      // 128x128: phase clock
         case 92: return launch_cfg<128, 128, 2, 2, 1>(a, s);       // 128x128: no epilogue
         case 93: return launch_cfg<128, 128, 2, 2, 4>(a, s);       // 128x128: cheap hash instead of Philox
         case 94: return launch_cfg<256, 256, 2, 4, 0>(a, s);       // fan-out layer on the 256x256 tile
         case 95: return launch_cfg<128, 128, 2, 2, 30>(a, s);      // 128x128: no global stores
-        case 11: return launch_cfg<256, 256, 2, 4, 11>(a, s);
-        case 12: return launch_cfg<256, 256, 2, 4, 12>(a, s);
-        case 7: return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
-        case 8: return launch_cfg<256, 256, 2, 4, 1, false, true>(a, s);
-        case 9: return launch_cfg<256, 256, 2, 4, 2, false, true>(a, s);
-        case 10: return launch_cfg<128, 128, 2, 2, 0>(a, s);
         default: return hipErrorInvalidValue;
     }
     if (big) return launch_cfg<256, 256, 2, 4, 0>(a, s);
