@@ -76,6 +76,8 @@ SIGNATURES = {
     "bod_upload_frames_u8": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, _F, C.c_int32]),
     "bod_device_images": (C.c_void_p, [_H]),
     "bod_synchronize": (C.c_int, [_H]),
+    "bod_stage_conv_wgrad": (C.c_int, [C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F]),
     "bod_stage_conv": (C.c_int, [C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F,
                                  C.c_float, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, _F]),

@@ -16,6 +16,7 @@ SOURCES = [
     # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
     ("post_kernels.hip", ["-ffp-contract=off"]),
     ("loss_kernels.hip", ["-ffp-contract=off"]),
+    ("train_kernels.hip", []),
     ("engine.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -798,6 +798,12 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
     }
+    if (a.flags & CONV_OUT_F32) {                    // fp32 result (weight gradients): per-channel validity
+        float* o32 = reinterpret_cast<float*>(G.out) + (size_t)e.out_off * a.out_cstride + co;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (co + k < a.cout_valid) o32[k] = v[k];
+        return;
+    }
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
     const size_t off = (size_t)e.out_off * a.out_cstride + co;
@@ -844,7 +850,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
     if (a.ksplit > 1) {
-        if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & (CONV_DROPOUT | CONV_OUT_F32)) || a.variant != 0)
+        if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & CONV_DROPOUT) || a.variant != 0)
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
         hipError_t e = a.cout_pad % 128 == 0 ? launch_cfg<128, 128, 2, 2, 0>(a, s) : launch_cfg<64, 128, 1, 4, 0>(a, s);

@@ -1435,6 +1435,126 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     return done(run());
 }
 
+bod_status bod_stage_conv_wgrad(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                const float* dy, int32_t KH, int32_t KW, int32_t Cout, int32_t stride, int32_t same_padding,
+                                int32_t ksplit, float* dw, float* db) {
+    bod_context ctx;
+    bod_context* h = &ctx;
+    h->es = 2;
+    auto done = [&](bod_status s) {
+        if (s != BOD_OK) g_create_error = h->err;
+        if (h->stream) hipStreamSynchronize(h->stream);
+        for (void* p : h->allocs) hipFree(p);
+        if (h->stream) hipStreamDestroy(h->stream);
+        h->allocs.clear(); h->stream = nullptr;
+        return s;
+    };
+    if (!x || !dy || !dw || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || KH > 3 || KW > 3 || stride < 1 || stride > 2)
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv_wgrad: bad argument"));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return done(h->fail(BOD_ERR_NO_DEVICE, "no HIP device %d: libbayesod_hip has no CPU fallback", device));
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return done(h->fail(BOD_ERR_HIP, "cannot set up device %d", device));
+    h->cfg.batch = B;
+    int OH, OW, oy = 1, ox = 1;
+    if (same_padding) {
+        OH = (H + stride - 1) / stride; OW = (W + stride - 1) / stride;
+        oy = 1 - same_pad_before(H, KH, stride); ox = 1 - same_pad_before(W, KW, stride);
+    } else {
+        OH = (H - KH) / stride + 1; OW = (W - KW) / stride + 1;
+    }
+    if (OH < 1 || OW < 1) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv_wgrad: empty output"));
+    auto run = [&]() -> bod_status {
+        const int M = B * OH * OW, taps = KH * KW;
+        // ---- forward-layout inputs: padded bf16 plane of x, dense bf16 dY, the forward row table
+        Plane in;
+        BODCHK(new_plane(h, &in, B, H, W, Cin));
+        std::vector<uint16_t> hx((size_t)B * in.bstride * Cin, 0);
+        for (int b = 0; b < B; ++b)
+            for (int y = 0; y < H; ++y)
+                for (int xx = 0; xx < W; ++xx)
+                    for (int c = 0; c < Cin; ++c)
+                        hx[((size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1)) * Cin + c] = f2bf(x[(((size_t)b * H + y) * W + xx) * Cin + c]);
+        HIPCHK(h, hipMemcpyAsync(in.d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, h->stream));
+        std::vector<uint16_t> hdy((size_t)M * Cout);
+        for (size_t i = 0; i < hdy.size(); ++i) hdy[i] = f2bf(dy[i]);
+        uint16_t* d_dy = nullptr;
+        BODCHK(h->dalloc(&d_dy, hdy.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d_dy, hdy.data(), hdy.size() * 2, hipMemcpyHostToDevice, h->stream));
+        std::vector<RowEnt> rows((size_t)M);
+        size_t r = 0;
+        for (int b = 0; b < B; ++b)
+            for (int y = 0; y < OH; ++y)
+                for (int xx = 0; xx < OW; ++xx) {
+                    RowEnt e{};
+                    e.in_off = (int32_t)(b * in.bstride + (int64_t)(y * stride + oy) * in.pitch + (xx * stride + ox));
+                    e.in_pitch = in.pitch;
+                    rows[r++] = e;
+                }
+        RowEnt* d_rows = nullptr;
+        BODCHK(h->dalloc(&d_rows, rows.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        // ---- K-contiguous operands: dY^T [cout_pad][Kpad] and Xcol^T [taps*Cin + 1][Kpad] (last row = ones -> db)
+        const int cout_pad = (Cout + 63) / 64 * 64;
+        const int N = taps * Cin + 1;
+        int S = ksplit;
+        if (S < 1) {                                  // enough splits for ~512 workgroups, >= 4 K-tiles each
+            const long tiles = (long)((N + 127) / 128) * (cout_pad % 128 == 0 ? cout_pad / 128 : cout_pad / 64);
+            S = 1;
+            while (tiles * S < 512 && S < 64 && (long)M / (64L * S * 2) >= 4) S *= 2;
+        }
+        const int Kpad = (M + 64 * S - 1) / (64 * S) * (64 * S);
+        uint16_t* d_dyt = nullptr; uint16_t* d_xct = nullptr;
+        BODCHK(h->dalloc(&d_dyt, (size_t)cout_pad * Kpad));                 // zero-filled: rows >= Cout stay 0
+        BODCHK(h->dalloc(&d_xct, (size_t)N * Kpad, false));
+        const bool trace = getenv("BOD_TRACE_WGRAD") != nullptr;     // development aid: device time of the two phases
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        if (trace) { for (auto& e : ev) HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(ev[0], h->stream)); }
+        HIPCHK(h, launch_gather_transpose(d_dy, nullptr, d_dyt, M, Kpad, Cout, Cout, 1, 1, h->stream));
+        HIPCHK(h, launch_gather_transpose(in.d, d_rows, d_xct, M, Kpad, Cin, Cin, taps, KW, h->stream));
+        HIPCHK(h, launch_fill_row_bf16(d_xct + (size_t)taps * Cin * Kpad, M, Kpad, 1.0f, h->stream));
+        // ---- the forward kernel as a plain GEMM: "pixels" = rows of Xcol^T, "weights" = dY^T, reduction = pixels
+        if (trace) HIPCHK(h, hipEventRecord(ev[1], h->stream));
+        std::vector<RowEnt> grow((size_t)N);
+        for (int n = 0; n < N; ++n) { RowEnt e{}; e.in_off = n; e.out_off = n; grow[n] = e; }
+        RowEnt* d_grow = nullptr;
+        BODCHK(h->dalloc(&d_grow, grow.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d_grow, grow.data(), grow.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        float* d_zero = nullptr; float* d_out = nullptr; float* d_part = nullptr;
+        BODCHK(h->dalloc(&d_zero, (size_t)cout_pad));
+        BODCHK(h->dalloc(&d_out, (size_t)N * Cout));
+        ConvArgs a{};
+        a.rows = d_grow; a.M = N; a.taps = 1; a.KW = 1; a.cin = Kpad; a.in_cstride = Kpad;
+        a.cout_pad = cout_pad; a.cout_valid = Cout; a.out_cstride = Cout; a.res_cstride = Cout; a.groups = 1;
+        a.fan_count = 1; a.flags = CONV_OUT_F32;
+        a.g[0] = ConvGroup{d_xct, d_dyt, d_zero, d_out, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+        if (S > 1) {
+            a.ksplit = S;
+            BODCHK(h->dalloc(&d_part, (size_t)S * N * cout_pad, false));
+            a.partial = d_part;
+        }
+        HIPCHK(h, launch_conv_igemm(a, h->stream));
+        if (trace) {
+            HIPCHK(h, hipEventRecord(ev[2], h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            float t0 = 0, t1 = 0;
+            hipEventElapsedTime(&t0, ev[0], ev[1]); hipEventElapsedTime(&t1, ev[1], ev[2]);
+            const double fl = 2.0 * M * (double)taps * Cin * Cout;
+            fprintf(stderr, "# wgrad M=%d K=%dx%d Cout=%d S=%d: transposes %.3f ms, GEMM+reduce %.3f ms (%.1f TFLOP/s)\n",
+                    M, taps, Cin, Cout, S, t0, t1, fl / (t1 * 1e-3) / 1e12);
+            for (auto& e : ev) hipEventDestroy(e);
+        }
+        std::vector<float> ho((size_t)N * Cout);
+        HIPCHK(h, hipMemcpyAsync(ho.data(), d_out, ho.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(dw, ho.data(), (size_t)taps * Cin * Cout * 4);           // [(tap, ci)][co] == HWIO
+        if (db) std::memcpy(db, ho.data() + (size_t)taps * Cin * Cout, (size_t)Cout * 4);
+        return BOD_OK;
+    };
+    return done(run());
+}
+
 bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
                             const float* box, const float* box_t, const float* cov, const float* anchors,
                             const uint8_t* pos, const uint8_t* neg, int32_t do_cls, int32_t reg_kind,

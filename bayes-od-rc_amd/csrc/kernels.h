@@ -189,3 +189,10 @@ struct LossArgs {
     const uint8_t* pos; const uint8_t* neg;     // [B,A]
 };
 hipError_t launch_loss(const LossArgs& a, float* partial, int nblocks, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Training-step building blocks (train_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
+                                   int taps, int KW, hipStream_t s);
+hipError_t launch_fill_row_bf16(void* row, int n_set, int n_total, float value, hipStream_t s);

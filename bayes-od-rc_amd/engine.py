@@ -340,3 +340,29 @@ def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=N
                             layer_id, image_id, int(round_output_bf16), int(precision == 'fp32'), fptr(out))
     _lib.check(lib, None, st)
     return out
+
+
+def stage_conv_wgrad(x, dy, kernel_hw, stride=1, padding="same", ksplit=0, device=0):
+    """Weight / bias gradient of one Conv2D through the MFMA kernel (``bod_stage_conv_wgrad``): returns
+    (dw [KH,KW,Cin,Cout], db [Cout]) for layer input x [B,H,W,Cin] and output gradient dy [B,OH,OW,Cout]."""
+    lib = _lib.load()
+    x, dy = as_f32(x), as_f32(dy)
+    b, h, wd, cin = x.shape
+    kh, kw = int(kernel_hw[0]), int(kernel_hw[1])
+    cout = dy.shape[-1]
+    dw = np.empty((kh, kw, cin, cout), np.float32)
+    db = np.empty((cout,), np.float32)
+    st = lib.bod_stage_conv_wgrad(device, fptr(x), b, h, wd, cin, fptr(dy), kh, kw, cout, stride,
+                                  int(padding == "same"), int(ksplit), fptr(dw), fptr(db))
+    _lib.check(lib, None, st)
+    return dw, db
+
+
+def stage_conv_dgrad(dy, w, padding="same", device=0):
+    """Input gradient of a stride-1 Conv2D: the forward kernel on dy with the spatially flipped, cin/cout-swapped
+    weights (SAME: symmetric padding for odd kernels; VALID forward = full correlation, not covered here)."""
+    w = as_f32(w)
+    if padding != "same" or w.shape[0] % 2 == 0 or w.shape[1] % 2 == 0:
+        raise ValueError("stage_conv_dgrad covers stride-1 SAME convolutions with odd kernels")
+    wt = np.ascontiguousarray(np.transpose(w[::-1, ::-1], (0, 1, 3, 2)))
+    return stage_conv(dy, wt, None, stride=1, padding="same", device=device)

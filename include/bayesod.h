@@ -220,6 +220,18 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           float dropout_rate, uint64_t seed, int32_t layer_id, uint32_t image_id,
                           int32_t round_output_bf16, int32_t precision, float* out);
 
+/* Stage entry point of the training step's hot kernel (run_training.py:208-247
+ * tape.gradient): the WEIGHT GRADIENT of one Conv2D, dw[KH,KW,Cin,Cout] = dL/dW and db[Cout] = dL/db given the
+ * layer input x [B,H,W,Cin] and the output gradient dy [B,OH,OW,Cout] (keras Conv2D geometry as in
+ * bod_stage_conv; x and dy are rounded to bf16 like stored activations, accumulation is fp32).  Runs as a
+ * pixel-reduction GEMM on the forward implicit-GEMM MFMA kernel: im2col^T of x through the forward row table,
+ * dy transposed, reduction split over `ksplit` workgroups per tile (0 = chosen automatically).  The input
+ * gradient needs no entry point of its own: it is bod_stage_conv on dy with the spatially flipped, cin/cout
+ * swapped weights (tests/test_gpu_train_blocks.py).  Errors via bod_last_error(NULL). */
+bod_status bod_stage_conv_wgrad(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                const float* dy, int32_t KH, int32_t KW, int32_t Cout, int32_t stride,
+                                int32_t same_padding, int32_t ksplit, float* dw, float* db);
+
 /* model.get_loss(sample_dict, prediction_dict) forward (retinanet_model.py:151-328, core/losses.py:30-61;
  * BASELINE config 5's loss, forward only).  Host arrays: cls/cls_targets [B,A,C], box/box_targets [B,A,4],
  * covar_params [B,A,10] (pre fill_triangular; may be NULL unless reg_kind >= 2), anchors [A,4],
