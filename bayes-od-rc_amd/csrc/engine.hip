@@ -1555,10 +1555,10 @@ bod_status bod_stage_conv_wgrad(int32_t device, const float* x, int32_t B, int32
     return done(run());
 }
 
-bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
+static bod_status loss_impl(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
                             const float* box, const float* box_t, const float* cov, const float* anchors,
                             const uint8_t* pos, const uint8_t* neg, int32_t do_cls, int32_t reg_kind,
-                            float label_smoothing, double* out4) {
+                            float label_smoothing, double* out4, float w_cls, float w_reg, float* dcls, float* dbox, float* dcov) {
     bod_context ctx;
     bod_context* h = &ctx;
     auto done = [&](bod_status s) {
@@ -1604,9 +1604,39 @@ bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, con
         for (int q = 0; q < 4; ++q) out4[q] = 0.0;
         for (int b = 0; b < nblocks; ++b)
             for (int q = 0; q < 4; ++q) out4[q] += (double)hp[(size_t)b * 4 + q];
+        if (dcls || dbox || dcov) {
+            float* sums = nullptr; float* g_cls = nullptr; float* g_box = nullptr; float* g_cov = nullptr;
+            BODCHK(h->dalloc(&sums, 4));
+            if (dcls) BODCHK(h->dalloc(&g_cls, n * C));
+            if (dbox) BODCHK(h->dalloc(&g_box, n * 4));
+            if (dcov) BODCHK(h->dalloc(&g_cov, n * 10));
+            HIPCHK(h, launch_loss_reduce(partial, nblocks, sums, h->stream));
+            HIPCHK(h, launch_loss_backward(a, sums, w_cls, w_reg, g_cls, g_box, g_cov, h->stream));
+            if (dcls) HIPCHK(h, hipMemcpyAsync(dcls, g_cls, n * C * 4, hipMemcpyDeviceToHost, h->stream));
+            if (dbox) HIPCHK(h, hipMemcpyAsync(dbox, g_box, n * 16, hipMemcpyDeviceToHost, h->stream));
+            if (dcov) HIPCHK(h, hipMemcpyAsync(dcov, g_cov, n * 40, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
         return BOD_OK;
     };
     return done(run());
+}
+
+bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
+                            const float* box, const float* box_t, const float* cov, const float* anchors,
+                            const uint8_t* pos, const uint8_t* neg, int32_t do_cls, int32_t reg_kind,
+                            float label_smoothing, double* out4) {
+    return loss_impl(device, B, A, C, cls, cls_t, box, box_t, cov, anchors, pos, neg, do_cls, reg_kind, label_smoothing, out4,
+                     0.f, 0.f, nullptr, nullptr, nullptr);
+}
+
+bod_status bod_loss_backward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls, const float* cls_t,
+                             const float* box, const float* box_t, const float* cov, const float* anchors,
+                             const uint8_t* pos, const uint8_t* neg, int32_t do_cls, int32_t reg_kind,
+                             float label_smoothing, float w_cls, float w_reg, double* out4, float* dcls, float* dbox, float* dcov) {
+    if (!dcls && !dbox && !dcov) return BOD_ERR_INVALID_ARG;
+    return loss_impl(device, B, A, C, cls, cls_t, box, box_t, cov, anchors, pos, neg, do_cls, reg_kind, label_smoothing, out4,
+                     w_cls, w_reg, dcls, dbox, dcov);
 }
 
 bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters, double* mean_ms, double* flops) {

@@ -189,6 +189,9 @@ struct LossArgs {
     const uint8_t* pos; const uint8_t* neg;     // [B,A]
 };
 hipError_t launch_loss(const LossArgs& a, float* partial, int nblocks, hipStream_t s);
+hipError_t launch_loss_reduce(const float* partial, int nblocks, float* sums4, hipStream_t s);
+hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_cls, float w_reg, float* dcls, float* dbox, float* dcov,
+                                hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Training-step building blocks (train_kernels.hip)

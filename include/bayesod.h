@@ -245,6 +245,16 @@ bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, con
                             const uint8_t* negative_mask, int32_t do_classification, int32_t reg_kind,
                             float label_smoothing, double* out4);
 
+/* Gradient of  total = w_cls * S_cls / max(n_pos,1) + w_reg * (S_cmp + S_reg) / max(n_pos,1)  (the reference's
+ * total_loss before the L2 term, retinanet_model.py:183-323) with respect to the raw head outputs: dcls [B,A,C],
+ * dbox [B,A,4], dcov [B,A,10] (NULL = not wanted).  Arguments as bod_loss_forward; out4 receives the same sums.
+ * First piece of the training step's backward pass. */
+bod_status bod_loss_backward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls,
+                             const float* cls_targets, const float* box, const float* box_targets,
+                             const float* covar_params, const float* anchors, const uint8_t* positive_mask,
+                             const uint8_t* negative_mask, int32_t do_cls, int32_t reg_kind, float label_smoothing,
+                             float w_cls, float w_reg, double* out4, float* dcls, float* dbox, float* dcov);
+
 /* Kernel micro-benchmark (tests/tools): re-launches the handle's layer-`layer` head-tower conv
  * (0 = de-duplicated fan-out layer, 1..3 = per-sample layers) `iters` times on the handle's own
  * buffers and returns the mean duration; `variant` selects an ablation build of the kernel
