@@ -24,7 +24,8 @@ class BodConfig(C.Structure):
         ("kitti_scale_h", C.c_float), ("kitti_scale_w", C.c_float), ("precision", C.c_int32),
         ("mc_sample_base", C.c_int32),
         ("mc_ensemble_size", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("training", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -84,6 +85,9 @@ SIGNATURES = {
     "bod_loss_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F, _F, _F, _F, _F,
                                    C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_float,
                                    C.POINTER(C.c_double)]),
+    "bod_train_step": (C.c_int, [_H, C.c_void_p, C.c_int32, _F, _F, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32,
+                                 C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.POINTER(C.c_double)]),
+    "bod_train_get": (C.c_int, [_H, C.c_char_p, C.c_int32, C.c_int32, _F, C.c_int64]),
     "bod_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F, _F, _F, _F, _F,
                                     C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_float,
                                     C.c_float, C.c_float, C.POINTER(C.c_double), _F, _F, _F]),

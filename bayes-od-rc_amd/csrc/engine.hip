@@ -38,6 +38,7 @@ struct Op {
     bool is_head3x3 = false;
     double flops = 0;
     std::string name;
+    std::string wname[3], bnname[3];     // per group: conv / batch-norm layer names (training: parameter lookup)
 };
 
 uint16_t f2bf(float f) {
@@ -54,7 +55,9 @@ struct bod_context {
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
+    std::map<const void*, size_t> alloc_bytes;
     int64_t device_bytes = 0;
+    struct TrainState* train = nullptr;                 // training mode (train_impl.inc)
 
     // geometry
     int sh = 0, sw = 0, ph = 0, pw = 0;                 // stem / pool output
@@ -79,6 +82,7 @@ struct bod_context {
     int es = 2;                                          // bytes per activation / weight element (2 = bf16, 4 = fp32)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
     char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
+    char* head_act_t[3][4] = {{nullptr}};            // training: one buffer per tower layer
     float* raw[3] = {nullptr};                           // cls [B,N,P,9C] box [B,N,P,36] cov [B,N,P,90]
     std::map<std::string, RowEnt*> tables;
     std::vector<Op> ops;
@@ -129,6 +133,7 @@ struct bod_context {
             if (e != hipSuccess) return fail(BOD_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
         }
         allocs.push_back(q);
+        alloc_bytes[q] = bytes;
         device_bytes += (int64_t)bytes;
         *p = reinterpret_cast<T*>(q);
         return BOD_OK;
@@ -282,7 +287,7 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     op.conv.g[0] = ConvGroup{in.d, pc.w, pc.bias, out.d, res ? res->d : nullptr, out_relu, 0, 0, nullptr, nullptr, nullptr, 0, 0};
     op.conv.flags = relu ? CONV_RELU : 0;
     op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
-    op.name = name;
+    op.name = name; op.wname[0] = name; op.bnname[0] = bn;
     // Split-K for layers with too few output tiles to fill the chip and a long reduction (P6 always; most of
     // stage 3-5 at batch 1): enough splits for >= ~256 workgroups, each keeping >= 4 K-tiles.
     static const bool splitk_on = [] { const char* e = getenv("BOD_CONV_SPLITK"); return !e || atoi(e) != 0; }();
@@ -351,9 +356,13 @@ bod_status ensure_raw(bod_context* h) {
     return BOD_OK;
 }
 
+bod_status train_init(bod_context* h);          // train_impl.inc
+void train_destroy(bod_context* h);
+
 bod_status build_plan(bod_context* h) {
     const bod_config& c = h->cfg;
     const int B = c.batch, N = c.mc_samples;
+    const bool train_mode = c.training != 0;
     h->ops.clear();
     // ---------------- stem
     {
@@ -401,6 +410,13 @@ bod_status build_plan(bod_context* h) {
             snprintf(cb, sizeof cb, "res%d%c_branch", st, *bl);
             snprintf(bb, sizeof bb, "bn%d%c_branch", st, *bl);
             const std::string c_(cb), b_(bb);
+            if (train_mode) {                   // training keeps every activation: fresh planes per block
+                BODCHK(new_plane(h, &t1, B, hh, ww, f1));
+                BODCHK(new_plane(h, &t2, B, hh, ww, f1));
+                BODCHK(new_plane(h, &sc, B, hh, ww, f3));
+                BODCHK(new_plane(h, &oa, B, hh, ww, f3));
+                BODCHK(new_plane(h, &ob, B, hh, ww, f3));
+            }
             Plane& out = use_a ? oa : ob;
             if (*bl == 'a') {
                 BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, first_stride, false, true, nullptr));
@@ -455,6 +471,10 @@ bod_status build_plan(bod_context* h) {
     const size_t act_elems = (size_t)B * N * h->Ppad * 256 * h->es;
     for (int hd = 0; hd < 3; ++hd) {
         if (hd == 2 && !c.has_covar_head) continue;
+        if (train_mode) {                       // every tower activation is kept for the backward pass
+            for (int l = 0; l < kHeadConvs[hd]; ++l) BODCHK(h->dalloc(&h->head_act_t[hd][l], act_elems));
+            continue;
+        }
         BODCHK(h->dalloc(&h->head_act[hd][0], act_elems));
         BODCHK(h->dalloc(&h->head_act[hd][1], act_elems));
     }
@@ -512,7 +532,7 @@ bod_status build_plan(bod_context* h) {
     // Activation row reuse for the per-sample 3x3 tower layers: re-pack the rows into 256-slot tiles made
     // of runs of x-adjacent pixels and list each tile's extended input rows (kernels.h, ConvArgs::ext).
     RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
-    bool xreuse = h->es == 2;
+    bool xreuse = h->es == 2 && !train_mode;
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -549,7 +569,7 @@ bod_status build_plan(bod_context* h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
 
-    const bool mc = std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77)
+    const bool mc = train_mode || std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77); training: dropout on (:113-129)
     const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 65536.0);
     const float dscale = (float)(1.0 / (1.0 - (double)c.dropout_rate));
     const int nheads = c.has_covar_head ? 3 : 2;
@@ -557,7 +577,7 @@ bod_status build_plan(bod_context* h) {
     // Fuse each head's 1x1 output conv into the epilogue of its last tower layer whenever that layer runs
     // with the full 256-channel cout tile (bf16 mode, enough rows): the last tower activation then never
     // goes to HBM and three launches disappear.  BOD_FUSE_HEAD_OUTPUT=0 keeps the separate launches.
-    bool fuse_out = h->es == 2;
+    bool fuse_out = h->es == 2 && !train_mode;
     if (const char* e = getenv("BOD_FUSE_HEAD_OUTPUT")) fuse_out = fuse_out && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -573,10 +593,11 @@ bod_status build_plan(bod_context* h) {
             BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc));
             if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
                 return h->fail(BOD_ERR_INVALID_ARG, "head conv %s_%d must be 3x3 256->256", kHeadPrefix[hd], layer);
+            op.wname[g] = std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer);
             ConvGroup cg{};
-            cg.in = layer == 0 ? h->pyramid.d : h->head_act[hd][(layer + 1) & 1];
+            cg.in = layer == 0 ? h->pyramid.d : (train_mode ? h->head_act_t[hd][layer - 1] : h->head_act[hd][(layer + 1) & 1]);
             cg.w = pc.w; cg.bias = pc.bias;
-            cg.out = h->head_act[hd][layer & 1];
+            cg.out = train_mode ? h->head_act_t[hd][layer] : h->head_act[hd][layer & 1];
             cg.layer_id = hd * 4 + layer;
             if (fuse_out && layer == kHeadConvs[hd] - 1) {
                 PackedConv po;
@@ -614,11 +635,11 @@ bod_status build_plan(bod_context* h) {
             return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], pc.cin, pc.cout);
         Op op; op.kind = Op::CONV;
         ConvArgs a = base_args(pc, d3, B * N * h->P, 256, out_ch[hd]);
-        a.g[0] = ConvGroup{h->head_act[hd][(kHeadConvs[hd] - 1) & 1], pc.w, pc.bias, h->raw[hd], nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+        a.g[0] = ConvGroup{train_mode ? h->head_act_t[hd][kHeadConvs[hd] - 1] : h->head_act[hd][(kHeadConvs[hd] - 1) & 1], pc.w, pc.bias, h->raw[hd], nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0};
         a.flags = CONV_OUT_F32;
         op.conv = a;
         op.flops = 2.0 * a.M * pc.cout * 256.0;
-        op.name = kHeadPrefix[hd];
+        op.name = kHeadPrefix[hd]; op.wname[0] = kHeadPrefix[hd];
         h->ops.push_back(op);
     }
     if (h->splitk_elems) {
@@ -829,6 +850,8 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
         (c.mc_ensemble_size > 0 && c.mc_sample_base + c.mc_samples > c.mc_ensemble_size))
         return bail(h->fail(BOD_ERR_INVALID_ARG, "mc_sample_base=%d / mc_samples=%d / mc_ensemble_size=%d inconsistent",
                             c.mc_sample_base, c.mc_samples, c.mc_ensemble_size));
+    if (c.training && (c.precision != BOD_PRECISION_BF16 || c.mc_samples != 1))
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "training handles run in bf16 precision with mc_samples = 1 (dropout stays on)"));
     if (c.num_classes != 4 && c.num_classes != 8)
         return bail(h->fail(BOD_ERR_INVALID_ARG, "num_classes (incl. background) must be 4 or 8, got %d", c.num_classes));
     if (c.anchors_per_location < 1 || (c.anchors_per_location * c.num_classes) % 4 != 0)
@@ -863,6 +886,7 @@ bod_status bod_destroy(bod_handle h) {
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
     if (h->ev_posterior) hipEventDestroy(h->ev_posterior);
     for (int sidx = 0; sidx < 2; ++sidx) if (h->ev_done[sidx]) hipEventDestroy(h->ev_done[sidx]);
+    train_destroy(h);
     for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
@@ -923,6 +947,7 @@ bod_status bod_finalize_weights(bod_handle h) {
     if (h->weights_ready) return BOD_OK;
     if (!h->ops.empty()) return h->fail(BOD_ERR_INVALID_ARG, "weights were already finalized; create a new handle to reload");
     BODCHK(build_plan(h));
+    if (h->cfg.training) BODCHK(train_init(h));
     h->host_w.clear();
     h->weights_ready = true;
     return BOD_OK;
@@ -1705,3 +1730,5 @@ bod_status bod_profile_end(bod_handle h, double* head_ms, int64_t* head_launches
 }
 
 }  // extern "C"
+
+#include "train_impl.inc"

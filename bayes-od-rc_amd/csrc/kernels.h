@@ -199,3 +199,44 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
                                    int taps, int KW, hipStream_t s);
 hipError_t launch_fill_row_bf16(void* row, int n_set, int n_total, float value, hipStream_t s);
+
+struct FoldArgs {
+    const float* kernel;        // master [taps][cin][cout]
+    const float* bias;          // master [cout] or nullptr
+    const float *gamma, *beta, *mean, *var;   // BatchNorm (nullptr: no BN)
+    float eps;
+    int32_t taps, cin, cout, cout_pad;
+    uint16_t* w_fwd;            // [cout_pad][taps][cin] bf16 (or nullptr)
+    float* w_fwd32;             // stem: fp32 [taps*cin][cout] (or nullptr)
+    uint16_t* w_bwd;            // [(tap, ci)][cout_pad] bf16 (or nullptr)
+    float* b_fwd;               // folded bias [cout_pad]
+};
+struct ActBwdArgs {
+    const float* dout;          // gradient of the layer output, laid out like the output buffer
+    const uint16_t* out_bf16;   // stored output (mask source) or nullptr (no activation: fp32 raw head outputs)
+    const RowEnt* rows;
+    float* dres;                // gradient buffer of the residual input or nullptr
+    uint16_t* dz;               // dense [M][cout_pad] bf16
+    int32_t M, cout, cout_pad, out_cstride, res_cstride;
+    float scale;                // dropout keep scale (1 without dropout)
+};
+struct UnfoldArgs {
+    const float* dwp;           // [(taps*cin) + 1][cout]: folded-weight gradient, last row = folded-bias gradient
+    const float* kernel; const float* bias;
+    const float *gamma, *mean, *var;
+    float eps;
+    int32_t taps, cin, cout;
+    float *d_kernel, *d_bias, *d_gamma, *d_beta;
+};
+hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s);
+hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s);
+hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s);
+hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin, int in_cstride, hipStream_t s);
+hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,
+                                     int pool_plane, hipStream_t s);
+hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s);
+hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s);
+hipError_t launch_sumsq(const float* g, long n, float* acc, hipStream_t s);
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
+                       float eps, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

@@ -52,3 +52,227 @@ hipError_t launch_fill_row_bf16(void* row, int n_set, int n_total, float value, 
                        (uint16_t)(u >> 16));
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The rest of the backward pass: everything except the two GEMMs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f_dev(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf_dev(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Per step: fp32 master weights (HWIO) + BatchNorm parameters -> the forward packing [cout_pad][taps][cin] (bf16), the
+// folded bias (fp32) and the input-gradient packing [(tap, ci)][cout_pad] (bf16, no flip: it is used as a plain GEMM).
+__global__ __launch_bounds__(256) void fold_pack_kernel(FoldArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)a.cout_pad * a.taps * a.cin;
+    if (i < n) {
+        const int ci = (int)(i % a.cin);
+        const int t = (int)((i / a.cin) % a.taps);
+        const int co = (int)(i / ((long)a.cin * a.taps));
+        float v = 0.f;
+        if (co < a.cout) {
+            const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
+            v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
+        }
+        if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
+        if (a.w_fwd32) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;      // stem: fp32 [tap*cin][cout]
+        if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
+    }
+    if (i < a.cout_pad) {
+        float b = 0.f;
+        if (i < a.cout) {
+            b = a.bias ? a.bias[i] : 0.f;
+            if (a.gamma) { const float s = a.gamma[i] / sqrtf(a.var[i] + a.eps); b = (b - a.mean[i]) * s + a.beta[i]; }
+        }
+        a.b_fwd[i] = b;
+    }
+}
+
+// dZ[m][co] (dense bf16, cout_pad columns) = dOut[out_off(m)][co] * (mask from the stored output); the same value is
+// what the residual input of the layer receives (out = act(conv + res)), scattered with atomics because a nearest-
+// upsampled residual (FPN) is read by several output pixels.
+__global__ __launch_bounds__(256) void act_backward_gather_kernel(ActBwdArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.M * a.cout_pad) return;
+    const int m = (int)(i / a.cout_pad), co = (int)(i % a.cout_pad);
+    float g = 0.f;
+    if (co < a.cout) {
+        const RowEnt e = a.rows[m];
+        const size_t o = (size_t)e.out_off * a.out_cstride + co;
+        g = a.dout[o];
+        if (a.out_bf16) { if (bf2f_dev(a.out_bf16[o]) == 0.f) g = 0.f; else g *= a.scale; }
+        if (a.dres && g != 0.f) atomicAdd(a.dres + (size_t)e.res_off * a.res_cstride + co, g);
+    }
+    a.dz[i] = f2bf_dev(g);
+}
+
+// second consumer of a layer's output through its ReLU'd copy (P6 -> relu -> P7): dOut += dOutRelu * [out > 0]
+__global__ __launch_bounds__(256) void relu_merge_kernel(const float* dout_relu, const uint16_t* out, float* dout, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && bf2f_dev(out[i]) > 0.f) dout[i] += dout_relu[i];
+}
+
+// col2im: dIn[(in_off(m) + ky*pitch + kx)][ci] += dXcol[m][(tap, ci)]
+__global__ __launch_bounds__(256) void col2im_kernel(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin,
+                                                     int in_cstride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)M * taps * cin;
+    if (i >= n) return;
+    const int ci = (int)(i % cin);
+    const int t = (int)((i / cin) % taps);
+    const int m = (int)(i / ((long)cin * taps));
+    const float v = dxcol[i];
+    if (v == 0.f) return;
+    const RowEnt e = rows[m];
+    const int ky = t / KW, kx = t - ky * KW;
+    atomicAdd(din + ((size_t)e.in_off + (size_t)ky * e.in_pitch + kx) * in_cstride + ci, v);
+}
+
+// ZeroPadding2D((1,2)) + MaxPool 3x3 s2 backward: the gradient goes to the first maximum of the window in row-major
+// scan order (the element the forward kernel's strict '>' scan keeps); masked by the stem's ReLU.
+__global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t* stem_out, const float* dpool, uint16_t* dz, int B, int ih, int iw,
+                                                                 int oh, int ow, int pool_pitch, int pool_plane) {
+    // one thread per stem pixel-channel: sum the pooled gradients of the (up to 4) windows whose arg-max it is
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)B * ih * iw * 64;
+    if (i >= n) return;
+    const int c = (int)(i & 63);
+    const int x = (int)((i >> 6) % iw), y = (int)((i >> 6) / iw % ih), b = (int)((i >> 6) / ((long)iw * ih));
+    const float v = bf2f_dev(stem_out[i]);
+    float g = 0.f;
+    if (v > 0.f) {
+        // windows (oy, ox) cover padded rows 2oy..2oy+2 (pad 1 on top) and padded cols 2ox..2ox+2 (pad 2 on the left)
+        for (int oy = (y + 1 - 2 + 1) / 2 < 0 ? 0 : (y + 1 - 2 + 1) / 2; oy <= (y + 1) / 2 && oy < oh; ++oy) {
+            if (2 * oy > y + 1 || 2 * oy + 2 < y + 1) continue;
+            for (int ox = (x + 2 - 2 + 1) / 2 < 0 ? 0 : (x + 2 - 2 + 1) / 2; ox <= (x + 2) / 2 && ox < ow; ++ox) {
+                if (2 * ox > x + 2 || 2 * ox + 2 < x + 2) continue;
+                // is (y, x) the first maximum of this window?
+                bool first = true;
+                for (int wy = 0; wy < 3 && first; ++wy)
+                    for (int wx = 0; wx < 3; ++wx) {
+                        const int sy = 2 * oy + wy - 1, sx = 2 * ox + wx - 2;
+                        float u = 0.f;                                           // zero padding (inputs are post-ReLU)
+                        if (sy >= 0 && sy < ih && sx >= 0 && sx < iw) u = bf2f_dev(stem_out[(((size_t)b * ih + sy) * iw + sx) * 64 + c]);
+                        const bool before = sy < y || (sy == y && sx < x);
+                        if (u > v || (u == v && before)) { first = false; break; }
+                    }
+                if (first) g += dpool[((size_t)b * pool_plane + (size_t)(oy + 1) * pool_pitch + (ox + 1)) * 64 + c];
+            }
+        }
+    }
+    dz[i] = f2bf_dev(g);
+}
+
+// dW'[n = (tap, ci)][co] and db'[co] (row N-1) of the folded layer -> gradients of the master parameters:
+//   dKernel = dW' * s,  dBias = db' * s,  dGamma = (sum_n dW' * K + db' * (bias - mean)) / sigma,  dBeta = db'      (s = gamma / sigma)
+__global__ __launch_bounds__(256) void unfold_grad_kernel(UnfoldArgs a) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= a.cout) return;
+    const int nk = a.taps * a.cin;
+    const float sigma = a.gamma ? sqrtf(a.var[co] + a.eps) : 1.0f;
+    const float s = a.gamma ? a.gamma[co] / sigma : 1.0f;
+    float dot = 0.f;
+    for (int n = 0; n < nk; ++n) {
+        const float g = a.dwp[(size_t)n * a.cout + co];
+        const float k = a.kernel[(size_t)n * a.cout + co];
+        a.d_kernel[(size_t)n * a.cout + co] += g * s;
+        dot += g * k;
+    }
+    const float dbp = a.dwp[(size_t)nk * a.cout + co];
+    if (a.d_bias) a.d_bias[co] += dbp * s;
+    if (a.gamma) {
+        const float b = a.bias ? a.bias[co] : 0.f;
+        a.d_gamma[co] += (dot + dbp * (b - a.mean[co])) / sigma;
+        a.d_beta[co] += dbp;
+    }
+}
+
+__global__ __launch_bounds__(256) void l2_grad_kernel(const float* w, float* g, long n, float rate, float* loss_acc) {
+    __shared__ float red[256];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (i < n) { const float v = w[i]; g[i] += 2.0f * rate * v; s = rate * v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(loss_acc, red[0]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* acc) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = g[i]; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+
+// tf.clip_by_global_norm(5.0) + keras Adam(epsilon): g *= clip / max(norm, clip); m, v updates; w -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip,
+                                                   float lr_t, float beta1, float beta2, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float norm = sqrtf(*sumsq);
+    const float gi = g[i] * (clip / fmaxf(norm, clip));
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s) {
+    const long n = (long)a.cout_pad * a.taps * a.cin;
+    hipLaunchKernelGGL(fold_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s) {
+    const long n = (long)a.M * a.cout_pad;
+    hipLaunchKernelGGL(act_backward_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s) {
+    hipLaunchKernelGGL(relu_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout_relu, reinterpret_cast<const uint16_t*>(out), dout, n);
+    return hipGetLastError();
+}
+hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin, int in_cstride, hipStream_t s) {
+    const long n = (long)M * taps * cin;
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dxcol, rows, din, M, taps, KW, cin, in_cstride);
+    return hipGetLastError();
+}
+hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,
+                                     int pool_plane, hipStream_t s) {
+    const long n = (long)B * ih * iw * 64;
+    hipLaunchKernelGGL(stem_pool_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(stem_out), dpool,
+                       reinterpret_cast<uint16_t*>(dz), B, ih, iw, oh, ow, pool_pitch, pool_plane);
+    return hipGetLastError();
+}
+hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(unfold_grad_kernel, dim3((a.cout + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s) {
+    hipLaunchKernelGGL(l2_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, n, rate, loss_acc);
+    return hipGetLastError();
+}
+hipError_t launch_sumsq(const float* g, long n, float* acc, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, g, n, acc);
+    return hipGetLastError();
+}
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
+                       float eps, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, m, v, n, sumsq, clip, lr_t, beta1, beta2, eps);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, uint16_t* out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f2bf_dev(in[i]);
+}
+hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, reinterpret_cast<uint16_t*>(out), n);
+    return hipGetLastError();
+}

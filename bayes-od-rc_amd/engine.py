@@ -16,7 +16,7 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
                 dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
                 has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
                 num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16', mc_sample_base=0,
-                mc_ensemble_size=0):
+                mc_ensemble_size=0, training=False):
     """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
     into a ``bod_config``."""
     bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
@@ -47,6 +47,7 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
         raise ValueError("precision must be 'bf16' or 'fp32'")
     cfg.precision = int(precision == 'fp32')
     cfg.mc_sample_base, cfg.mc_ensemble_size = int(mc_sample_base), int(mc_ensemble_size)
+    cfg.training = int(bool(training))
     if dataset_name == 'kitti':
         if orig_size is None:
             raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")
@@ -208,6 +209,38 @@ class Engine(object):
 
     def posterior(self, seed=0, first_image_id=0):
         self._chk(self.lib.bod_posterior(self.h, seed, first_image_id))
+
+    # -- training ------------------------------------------------------
+    def train_step(self, images, cls_targets, box_targets, positive_mask, negative_mask, seed=0, first_image_id=0,
+                   reg_kind=3, label_smoothing=0.001, w_cls=5.0, w_reg=1.0, l2_rate=1e-6, learning_rate=1e-3,
+                   apply_update=True):
+        """run_training.train_single_step on a handle made with make_config(training=True): returns a dict with
+        total_loss, cls_loss, reg_loss, covariance_loss, regularization_loss and the global gradient norm."""
+        b, a = self.B, self.A
+        ct = as_f32(cls_targets).reshape(b, a, self.Ccls)
+        bt = as_f32(box_targets).reshape(b, a, 4)
+        pm = np.ascontiguousarray(np.asarray(positive_mask).reshape(b, a), dtype=np.uint8)
+        nm = np.ascontiguousarray(np.asarray(negative_mask).reshape(b, a), dtype=np.uint8)
+        out = (C.c_double * 6)()
+        u8 = C.POINTER(C.c_uint8)
+        if images is None:
+            ptr, on_dev = self.lib.bod_device_images(self.h), 1
+        else:
+            img = self._img(images)
+            ptr, on_dev = img.ctypes.data, 0
+        self._chk(self.lib.bod_train_step(self.h, ptr, on_dev, fptr(ct), fptr(bt), pm.ctypes.data_as(u8), nm.ctypes.data_as(u8),
+                                          seed, first_image_id, int(reg_kind), float(label_smoothing), float(w_cls), float(w_reg),
+                                          float(l2_rate), float(learning_rate), int(bool(apply_update)), out))
+        keys = ("total_loss", "cls_loss", "reg_loss", "covariance_loss", "regularization_loss", "grad_norm")
+        return dict(zip(keys, [out[i] for i in range(6)]))
+
+    def train_get(self, layer, kind, shape, what="value"):
+        """A trainable tensor (kind: 'kernel' | 'bias' | 'gamma' | 'beta') or its gradient / Adam moments."""
+        kinds = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3}
+        whats = {"value": 0, "grad": 1, "adam_m": 2, "adam_v": 3}
+        out = np.empty(shape, np.float32)
+        self._chk(self.lib.bod_train_get(self.h, layer.encode(), kinds[kind], whats[what], fptr(out), out.size))
+        return out
 
     def validation_post(self):
         """validation_utils.post_process_predictions up to the NMS input (softmax, background filter, ranking)."""

@@ -71,7 +71,11 @@ typedef struct {
                                     MC dropout is on iff max(mc_ensemble_size, mc_samples) > 1
                                     (retinanet_model.py:74-77 decides on the ensemble size), so a rank holding a
                                     single sample of a sharded ensemble still applies its dropout masks.       */
-    int32_t reserved[5];
+    int32_t training;            /* 1: the handle also runs training steps (bod_train_step):
+                                    every layer keeps its activation, dropout is on with mc_samples = 1
+                                    (retinanet_model.py:113-147, training branch), fp32 master weights, gradients
+                                    and Adam moments live on the device.  bf16 precision only.                 */
+    int32_t reserved[4];
 } bod_config;
 
 /* Sizes the caller needs to allocate host buffers. */
@@ -231,6 +235,23 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
 bod_status bod_stage_conv_wgrad(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                                 const float* dy, int32_t KH, int32_t KW, int32_t Cout, int32_t stride,
                                 int32_t same_padding, int32_t ksplit, float* dw, float* db);
+
+/* One training step, run_training.train_single_step (:208-247), on a handle created with training = 1:
+ * forward in training mode (dropout on, batch-norm frozen), total loss = w_cls * focal + w_reg * regression
+ * (reg_kind as in bod_loss_forward) + Keras l2(l2_rate) on the header tower kernels and cov_out, backward through
+ * the whole network, tf.clip_by_global_norm(5.0) and keras Adam(epsilon = 1e-2) with `learning_rate` (the piecewise
+ * schedule is the caller's, :48-61).  Targets as the dataset handler produces them: cls_targets [B,A,C],
+ * box_targets [B,A,4], positive / negative anchor masks [B,A] (bytes).  apply_update = 0 stops after the
+ * gradients (tests).  out6 = {total_loss, cls_loss, reg_loss, covariance_loss, regularization_loss, global
+ * gradient norm before clipping}. */
+bod_status bod_train_step(bod_handle h, const float* images, int32_t images_on_device, const float* cls_targets,
+                          const float* box_targets, const uint8_t* positive_mask, const uint8_t* negative_mask,
+                          uint64_t seed, uint32_t first_image_id, int32_t reg_kind, float label_smoothing,
+                          float w_cls, float w_reg, float l2_rate, float learning_rate, int32_t apply_update,
+                          double* out6);
+/* Read a trainable tensor of a training handle back: layer = Keras layer name (conv or batch-norm), kind 0 kernel
+ * (HWIO) / 1 bias / 2 gamma / 3 beta, what 0 value / 1 gradient of the last step / 2, 3 Adam moments. */
+bod_status bod_train_get(bod_handle h, const char* layer, int32_t kind, int32_t what, float* out, int64_t n);
 
 /* model.get_loss(sample_dict, prediction_dict) forward (retinanet_model.py:151-328, core/losses.py:30-61;
  * BASELINE config 5's loss, forward only).  Host arrays: cls/cls_targets [B,A,C], box/box_targets [B,A,4],

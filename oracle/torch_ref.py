@@ -55,7 +55,7 @@ def bn(x, tw, name):
 
 
 def backbone_fpn(tw, image_nhwc):
-    x = _t(image_nhwc).permute(0, 3, 1, 2)
+    x = (image_nhwc if torch.is_tensor(image_nhwc) else _t(image_nhwc)).permute(0, 3, 1, 2)
     x = F.relu(bn(conv(x, tw, "conv1", 2), tw, "bn_conv1"))
     x = F.max_pool2d(F.pad(x, (2, 2, 1, 1)), 3, 2)
     taps = {}
