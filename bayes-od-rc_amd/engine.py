@@ -69,6 +69,7 @@ class Engine(object):
         self.levels = [(s.level_h[i], s.level_w[i]) for i in range(s.num_levels)]
         self.B, self.N, self.Ccls = cfg.batch, cfg.mc_samples, cfg.num_classes
         self.K = cfg.nms_max_output_size
+        self._anchors_set = False
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, st):
@@ -110,6 +111,7 @@ class Engine(object):
     def set_anchors(self, anchors):
         a = as_f32(anchors)
         self._chk(self.lib.bod_set_anchors(self.h, fptr(a), a.shape[0]))
+        self._anchors_set = True
 
     # ------------------------------------------------------------------ stages
     def _img(self, images):
