@@ -227,6 +227,7 @@ struct UnfoldArgs {
     float eps;
     int32_t taps, cin, cout;
     float *d_kernel, *d_bias, *d_gamma, *d_beta;
+    float* dot;                 // [cout] zero-initialised scratch for the gamma dot products (left zeroed)
 };
 hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s);
 hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s);

@@ -168,25 +168,41 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t*
 
 // dW'[n = (tap, ci)][co] and db'[co] (row N-1) of the folded layer -> gradients of the master parameters:
 //   dKernel = dW' * s,  dBias = db' * s,  dGamma = (sum_n dW' * K + db' * (bias - mean)) / sigma,  dBeta = db'      (s = gamma / sigma)
+// Pass 1: one block per (64 channels, 256 rows): coalesced over channels, partial dot products by atomics.  Pass 2: per channel.
 __global__ __launch_bounds__(256) void unfold_grad_kernel(UnfoldArgs a) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + c;
+    const int nk = a.taps * a.cin;
+    float dot = 0.f;
+    if (co < a.cout) {
+        const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
+        const int n1 = min(nk, (int)(blockIdx.y + 1) * 256);
+        for (int n = blockIdx.y * 256 + r; n < n1; n += 4) {
+            const size_t i = (size_t)n * a.cout + co;
+            const float g = a.dwp[i];
+            a.d_kernel[i] += g * s;
+            dot += g * a.kernel[i];
+        }
+    }
+    red[r][c] = dot;
+    __syncthreads();
+    if (r == 0 && co < a.cout && a.gamma) atomicAdd(a.dot + co, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+__global__ __launch_bounds__(256) void unfold_grad_final_kernel(UnfoldArgs a) {
     const int co = blockIdx.x * 256 + threadIdx.x;
     if (co >= a.cout) return;
     const int nk = a.taps * a.cin;
     const float sigma = a.gamma ? sqrtf(a.var[co] + a.eps) : 1.0f;
     const float s = a.gamma ? a.gamma[co] / sigma : 1.0f;
-    float dot = 0.f;
-    for (int n = 0; n < nk; ++n) {
-        const float g = a.dwp[(size_t)n * a.cout + co];
-        const float k = a.kernel[(size_t)n * a.cout + co];
-        a.d_kernel[(size_t)n * a.cout + co] += g * s;
-        dot += g * k;
-    }
     const float dbp = a.dwp[(size_t)nk * a.cout + co];
     if (a.d_bias) a.d_bias[co] += dbp * s;
     if (a.gamma) {
         const float b = a.bias ? a.bias[co] : 0.f;
-        a.d_gamma[co] += (dot + dbp * (b - a.mean[co])) / sigma;
+        a.d_gamma[co] += (a.dot[co] + dbp * (b - a.mean[co])) / sigma;
         a.d_beta[co] += dbp;
+        a.dot[co] = 0.f;                       // ready for the next layer
     }
 }
 
@@ -251,7 +267,9 @@ hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, v
     return hipGetLastError();
 }
 hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(unfold_grad_kernel, dim3((a.cout + 255) / 256), dim3(256), 0, s, a);
+    const int nk = a.taps * a.cin;
+    hipLaunchKernelGGL(unfold_grad_kernel, dim3((a.cout + 63) / 64, (nk + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(unfold_grad_final_kernel, dim3((a.cout + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s) {
