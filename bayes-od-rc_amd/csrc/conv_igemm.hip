@@ -528,9 +528,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     float v[4] = {acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
                                   acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w};
                     float* o = reinterpret_cast<float*>(G.out) + (size_t)out_off * a.out_cstride + co;
+                    const bool accum = a.flags & CONV_ACCUM;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (co + q < a.cout_valid) o[q] = relu ? fmaxf(v[q], 0.f) : v[q];
+                    for (int q = 0; q < 4; ++q) {
+                        if (co + q >= a.cout_valid) continue;
+                        const float r = relu ? fmaxf(v[q], 0.f) : v[q];
+                        o[q] = accum ? o[q] + r : r;
+                    }
                 }
             }
         }

@@ -40,7 +40,8 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     int32_t out2_cstride;
 };
 
-enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4 };
+enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4,
+                 CONV_ACCUM = 8 };     // with CONV_OUT_F32: out += result (input gradients of 1x1 layers accumulate in place)
 
 struct ConvArgs {
     ConvGroup g[3];
@@ -241,3 +242,4 @@ hipError_t launch_sumsq(const float* g, long n, float* acc, hipStream_t s);
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
                        float eps, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);
+hipError_t launch_make_dgrad_rows(const RowEnt* fwd, RowEnt* out, int M, hipStream_t s);

@@ -33,6 +33,38 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(const uint16_t* i
     }
 }
 
+// Vector form for channel counts / pixel strides that are multiples of 8: 16-byte reads along the channels, 16-byte
+// writes along the pixels.
+__global__ __launch_bounds__(256) void gather_transpose_vec_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
+                                                                   int M, int Kpad, int C, int cstride, int KW) {
+    __shared__ uint16_t tile[64][72];                                  // [m][c], 144-byte rows keep the 16-byte row writes aligned
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const int sub = threadIdx.x & 7, row = threadIdx.x >> 3;            // 8 threads x 16 B per 64-channel row, 32 rows per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = row + p * 32, m = m0 + r, c = c0 + sub * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (m < M && c < C) {
+            long pix = m;
+            if (rows) { const RowEnt e = rows[m]; pix = (long)e.in_off + (long)ky * e.in_pitch + kx; }
+            v = *reinterpret_cast<const uint4*>(in + pix * cstride + c);
+        }
+        *reinterpret_cast<uint4*>(&tile[r][sub * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int cr = row + p * 32, c = c0 + cr, m = m0 + sub * 8;     // this thread: channel c, pixels m .. m+7
+        if (c < C && m < Kpad) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = (uint32_t)tile[sub * 8 + 2 * q][cr] | ((uint32_t)tile[sub * 8 + 2 * q + 1][cr] << 16);
+            *reinterpret_cast<uint4*>(out + ((size_t)tap * C + c) * Kpad + m) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 __global__ void fill_row_bf16_kernel(uint16_t* row, int n_set, int n_total, uint16_t value) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_total) row[i] = i < n_set ? value : (uint16_t)0;
@@ -41,6 +73,11 @@ __global__ void fill_row_bf16_kernel(uint16_t* row, int n_set, int n_total, uint
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
                                    int taps, int KW, hipStream_t s) {
     dim3 grid((Kpad + 63) / 64, (C + 63) / 64, taps);
+    if (C % 8 == 0 && cstride % 8 == 0 && Kpad % 8 == 0) {
+        hipLaunchKernelGGL(gather_transpose_vec_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
+                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gather_transpose_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
                        reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW);
     return hipGetLastError();
@@ -292,5 +329,18 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, uint1
 }
 hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, reinterpret_cast<uint16_t*>(out), n);
+    return hipGetLastError();
+}
+
+// row table of the input-gradient GEMM of a 1x1 layer: row m reads dZ row m and accumulates into input pixel in_off(m)
+__global__ __launch_bounds__(256) void make_dgrad_rows_kernel(const RowEnt* fwd, RowEnt* out, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    RowEnt e{};
+    e.in_off = m; e.out_off = fwd[m].in_off;
+    out[m] = e;
+}
+hipError_t launch_make_dgrad_rows(const RowEnt* fwd, RowEnt* out, int M, hipStream_t s) {
+    hipLaunchKernelGGL(make_dgrad_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, s, fwd, out, M);
     return hipGetLastError();
 }
