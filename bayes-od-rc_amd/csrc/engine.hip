@@ -39,6 +39,7 @@ struct Op {
     double flops = 0;
     std::string name;
     std::string wname[3], bnname[3];     // per group: conv / batch-norm layer names (training: parameter lookup)
+    bool same_geom = false;              // 3x3 stride-1 SAME with identically laid-out input / output planes (training: input gradient as a convolution)
 };
 
 uint16_t f2bf(float f) {
@@ -288,6 +289,8 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     op.conv.flags = relu ? CONV_RELU : 0;
     op.flops = 2.0 * op.conv.M * pc.cout * pc.taps * pc.cin;
     op.name = name; op.wname[0] = name; op.bnname[0] = bn;
+    op.same_geom = stride == 1 && same && pc.taps == 9 && pc.kw == 3 && in.base == out.base && in.bstride == out.bstride && in.pitch == out.pitch &&
+                   in.h == out.h && in.w == out.w;
     // Split-K for layers with too few output tiles to fill the chip and a long reduction (P6 always; most of
     // stage 3-5 at batch 1): enough splits for >= ~256 workgroups, each keeping >= 4 K-tiles.
     static const bool splitk_on = [] { const char* e = getenv("BOD_CONV_SPLITK"); return !e || atoi(e) != 0; }();
@@ -626,6 +629,7 @@ bod_status build_plan(bod_context* h) {
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g;
         op.name = "head_tower_layer_" + std::to_string(layer);
+        op.same_geom = N == 1;            // pyramid [B][Ppad] and head planes [B*N][Ppad] coincide at N = 1
         h->ops.push_back(op);
     }
     for (int hd = 0; hd < nheads && !fuse_out; ++hd) {

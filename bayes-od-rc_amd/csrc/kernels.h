@@ -210,6 +210,7 @@ struct FoldArgs {
     uint16_t* w_fwd;            // [cout_pad][taps][cin] bf16 (or nullptr)
     float* w_fwd32;             // stem: fp32 [taps*cin][cout] (or nullptr)
     uint16_t* w_bwd;            // [(tap, ci)][cout_pad] bf16 (or nullptr)
+    uint16_t* w_flip;           // [cin][taps, flipped][cout_pad] bf16: the input gradient of a stride-1 SAME layer as a convolution (or nullptr)
     float* b_fwd;               // folded bias [cout_pad]
 };
 struct ActBwdArgs {
@@ -218,6 +219,7 @@ struct ActBwdArgs {
     const RowEnt* rows;
     float* dres;                // gradient buffer of the residual input or nullptr
     uint16_t* dz;               // dense [M][cout_pad] bf16
+    uint16_t* dzp;              // the same values in the output plane's own (zero-bordered) layout, or nullptr
     int32_t M, cout, cout_pad, out_cstride, res_cstride;
     float scale;                // dropout keep scale (1 without dropout)
 };

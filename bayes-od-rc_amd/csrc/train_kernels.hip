@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(FoldArgs a) {
         if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
         if (a.w_fwd32) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;      // stem: fp32 [tap*cin][cout]
         if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
+        if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
     }
     if (i < a.cout_pad) {
         float b = 0.f;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void act_backward_gather_kernel(ActBwdArgs a) 
         g = a.dout[o];
         if (a.out_bf16) { if (bf2f_dev(a.out_bf16[o]) == 0.f) g = 0.f; else g *= a.scale; }
         if (a.dres && g != 0.f) atomicAdd(a.dres + (size_t)e.res_off * a.res_cstride + co, g);
+        if (a.dzp) a.dzp[o] = f2bf_dev(g);
     }
     a.dz[i] = f2bf_dev(g);
 }
