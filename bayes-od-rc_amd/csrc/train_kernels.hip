@@ -65,6 +65,34 @@ __global__ __launch_bounds__(256) void gather_transpose_vec_kernel(const uint16_
     }
 }
 
+// Few channels per pixel (the stem's image, C = 3): tile over the joint row index n = tap * C + c instead of wasting
+// 61 of 64 channel lanes.
+__global__ __launch_bounds__(256) void gather_transpose_smallc_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
+                                                                      int M, int Kpad, int C, int cstride, int KW, int NR) {
+    __shared__ uint16_t tile[64][66];                                  // [n][m]
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int m = m0 + tx;
+    RowEnt e{};
+    if (m < M && rows) e = rows[m];
+    for (int r = ty; r < 64; r += 4) {
+        const int n = n0 + r;
+        uint16_t v = 0;
+        if (m < M && n < NR) {
+            const int tap = n / C, c = n - tap * C;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const long pix = rows ? (long)e.in_off + (long)ky * e.in_pitch + kx : m;
+            v = in[pix * cstride + c];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int n = n0 + r;
+        if (n < NR && m < Kpad) out[(size_t)n * Kpad + m] = tile[r][tx];
+    }
+}
+
 __global__ void fill_row_bf16_kernel(uint16_t* row, int n_set, int n_total, uint16_t value) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_total) row[i] = i < n_set ? value : (uint16_t)0;
@@ -76,6 +104,12 @@ hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out
     if (C % 8 == 0 && cstride % 8 == 0 && Kpad % 8 == 0) {
         hipLaunchKernelGGL(gather_transpose_vec_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
                            reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW);
+        return hipGetLastError();
+    }
+    if (C < 16) {
+        const int NR = taps * C;
+        hipLaunchKernelGGL(gather_transpose_smallc_kernel, dim3((Kpad + 63) / 64, (NR + 63) / 64), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
+                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, NR);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(gather_transpose_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
@@ -148,6 +182,41 @@ __global__ __launch_bounds__(256) void act_backward_gather_kernel(ActBwdArgs a) 
     a.dz[i] = f2bf_dev(g);
 }
 
+// 8 channels per thread (cout, cout_pad and both pixel strides multiples of 8)
+__global__ __launch_bounds__(256) void act_backward_gather_vec_kernel(ActBwdArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = a.cout_pad / 8;
+    if (i >= (long)a.M * c8) return;
+    const int m = (int)(i / c8), co = (int)(i % c8) * 8;
+    uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+    if (co < a.cout) {
+        const RowEnt e = a.rows[m];
+        const size_t o = (size_t)e.out_off * a.out_cstride + co;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.dout + o), g1 = *reinterpret_cast<const float4*>(a.dout + o + 4);
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        if (a.out_bf16) {
+            const uint4 y = *reinterpret_cast<const uint4*>(a.out_bf16 + o);
+            const uint32_t yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint16_t h = (uint16_t)(yw[k >> 1] >> ((k & 1) * 16));
+                g[k] = (h & 0x7FFFu) == 0 ? 0.f : g[k] * a.scale;
+            }
+        }
+        if (a.dres) {
+            float* r = a.dres + (size_t)e.res_off * a.res_cstride + co;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (g[k] != 0.f) atomicAdd(r + k, g[k]);
+        }
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf_dev(g[2 * k]) | ((uint32_t)f2bf_dev(g[2 * k + 1]) << 16);
+        packed = make_uint4(w[0], w[1], w[2], w[3]);
+        if (a.dzp) *reinterpret_cast<uint4*>(a.dzp + o) = packed;
+    }
+    *reinterpret_cast<uint4*>(a.dz + (size_t)m * a.cout_pad + co) = packed;
+}
+
 // second consumer of a layer's output through its ReLU'd copy (P6 -> relu -> P7): dOut += dOutRelu * [out > 0]
 __global__ __launch_bounds__(256) void relu_merge_kernel(const float* dout_relu, const uint16_t* out, float* dout, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -207,7 +276,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t*
 
 // dW'[n = (tap, ci)][co] and db'[co] (row N-1) of the folded layer -> gradients of the master parameters:
 //   dKernel = dW' * s,  dBias = db' * s,  dGamma = (sum_n dW' * K + db' * (bias - mean)) / sigma,  dBeta = db'      (s = gamma / sigma)
-// Pass 1: one block per (64 channels, 256 rows): coalesced over channels, partial dot products by atomics.  Pass 2: per channel.
+// Pass 1: one block per (64 channels, 32 rows): coalesced over channels, partial dot products by atomics.  Pass 2: per channel.
 __global__ __launch_bounds__(256) void unfold_grad_kernel(UnfoldArgs a) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
@@ -216,8 +285,8 @@ __global__ __launch_bounds__(256) void unfold_grad_kernel(UnfoldArgs a) {
     float dot = 0.f;
     if (co < a.cout) {
         const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
-        const int n1 = min(nk, (int)(blockIdx.y + 1) * 256);
-        for (int n = blockIdx.y * 256 + r; n < n1; n += 4) {
+        const int n1 = min(nk, (int)(blockIdx.y + 1) * 32);
+        for (int n = blockIdx.y * 32 + r; n < n1; n += 4) {
             const size_t i = (size_t)n * a.cout + co;
             const float g = a.dwp[i];
             a.d_kernel[i] += g * s;
@@ -285,6 +354,11 @@ hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s) {
+    if (a.cout % 8 == 0 && a.cout_pad % 8 == 0 && a.out_cstride % 8 == 0 && (!a.dres || a.res_cstride % 8 == 0)) {
+        const long nv = (long)a.M * (a.cout_pad / 8);
+        hipLaunchKernelGGL(act_backward_gather_vec_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long n = (long)a.M * a.cout_pad;
     hipLaunchKernelGGL(act_backward_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -307,7 +381,7 @@ hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, v
 }
 hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s) {
     const int nk = a.taps * a.cin;
-    hipLaunchKernelGGL(unfold_grad_kernel, dim3((a.cout + 63) / 64, (nk + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(unfold_grad_kernel, dim3((a.cout + 63) / 64, (nk + 31) / 32), dim3(256), 0, s, a);
     hipLaunchKernelGGL(unfold_grad_final_kernel, dim3((a.cout + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
