@@ -354,7 +354,8 @@ hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s) {
-    if (a.cout % 8 == 0 && a.cout_pad % 8 == 0 && a.out_cstride % 8 == 0 && (!a.dres || a.res_cstride % 8 == 0)) {
+    // layers with a residual input keep the one-thread-per-element form: its atomics are coalesced across the wavefront
+    if (!a.dres && a.cout % 8 == 0 && a.cout_pad % 8 == 0 && a.out_cstride % 8 == 0) {
         const long nv = (long)a.M * (a.cout_pad / 8);
         hipLaunchKernelGGL(act_backward_gather_vec_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);
         return hipGetLastError();
