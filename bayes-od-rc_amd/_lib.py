@@ -25,7 +25,8 @@ class BodConfig(C.Structure):
         ("mc_sample_base", C.c_int32),
         ("mc_ensemble_size", C.c_int32),
         ("training", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("backbone_depth", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

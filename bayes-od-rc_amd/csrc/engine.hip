@@ -395,7 +395,7 @@ bod_status build_plan(bod_context* h) {
     BODCHK(new_plane(h, &x, B, h->ph, h->pw, 64));
     Plane pool_out = x;
     h->ops[1].conv.g[0].out = pool_out.d;   // remember pool destination
-    const char* blocks[6] = {"", "", "abc", "abcd", "abcdef", "abc"};
+    const char* blocks[6] = {"", "", "abc", "abcd", c.backbone_depth == 101 ? "abcdefghijklmnopqrstuvw" : "abcdef", "abc"};
     const int f1s[6] = {0, 0, 64, 128, 256, 512};
     Plane taps[6];
     for (int st = 2; st <= 5; ++st) {
@@ -856,6 +856,8 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
                             c.mc_sample_base, c.mc_samples, c.mc_ensemble_size));
     if (c.training && (c.precision != BOD_PRECISION_BF16 || c.mc_samples != 1))
         return bail(h->fail(BOD_ERR_INVALID_ARG, "training handles run in bf16 precision with mc_samples = 1 (dropout stays on)"));
+    if (c.backbone_depth != 0 && c.backbone_depth != 50 && c.backbone_depth != 101)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "backbone_depth must be 50 or 101, got %d", c.backbone_depth));
     if (c.num_classes != 4 && c.num_classes != 8)
         return bail(h->fail(BOD_ERR_INVALID_ARG, "num_classes (incl. background) must be 4 or 8, got %d", c.num_classes));
     if (c.anchors_per_location < 1 || (c.anchors_per_location * c.num_classes) % 4 != 0)
@@ -919,7 +921,7 @@ bod_status bod_update_config(bod_handle h, const bod_config* cfg) {
         cfg->mc_samples != o.mc_samples || cfg->num_classes != o.num_classes ||
         cfg->anchors_per_location != o.anchors_per_location || cfg->min_level != o.min_level ||
         cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate ||
-        cfg->precision != o.precision || (std::max(cfg->mc_ensemble_size, cfg->mc_samples) > 1) != (std::max(o.mc_ensemble_size, o.mc_samples) > 1))
+        cfg->precision != o.precision || cfg->training != o.training || cfg->backbone_depth != o.backbone_depth || (std::max(cfg->mc_ensemble_size, cfg->mc_samples) > 1) != (std::max(o.mc_ensemble_size, o.mc_samples) > 1))
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: geometry / model fields cannot change on a live handle");
     if (cfg->nms_max_output_size != o.nms_max_output_size)
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: nms_max_output_size sizes device buffers and cannot change");

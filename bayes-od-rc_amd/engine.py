@@ -16,7 +16,7 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
                 dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
                 has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
                 num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16', mc_sample_base=0,
-                mc_ensemble_size=0, training=False):
+                mc_ensemble_size=0, training=False, backbone_depth=50):
     """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
     into a ``bod_config``."""
     bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
@@ -48,6 +48,9 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
     cfg.precision = int(precision == 'fp32')
     cfg.mc_sample_base, cfg.mc_ensemble_size = int(mc_sample_base), int(mc_ensemble_size)
     cfg.training = int(bool(training))
+    if int(backbone_depth) not in (50, 101):
+        raise ValueError("backbone_depth must be 50 or 101")
+    cfg.backbone_depth = int(backbone_depth)
     if dataset_name == 'kitti':
         if orig_size is None:
             raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")

@@ -48,6 +48,7 @@ class RetinaNetModel(object):
         self.batch = batch
         self.seed = seed
         self.precision = precision        # 'bf16' (throughput) or 'fp32' (reference-exact arithmetic)
+        self.backbone_depth = 101 if '101' in str(model_config.get('feature_extractor', {}).get('name', '')) else 50
         self.image_counter = 0
         self.prediction_dict = None
         self._weights = None
@@ -82,11 +83,11 @@ class RetinaNetModel(object):
                              "ValueError for a missing checkpoint, run_inference.py:56-58)")
         batch = batch or self.batch
         n = mc_samples or self.mc_dropout_samples
-        key = (int(image_hw[0]), int(image_hw[1]), batch, n, self.precision)
+        key = (int(image_hw[0]), int(image_hw[1]), batch, n, self.precision, self.backbone_depth)
         cfg = make_config(image_hw, batch=batch, mc_samples=n, num_classes=self.num_classes + 1,
                           anchors_per_location=self.anchors_per_location, device=self.device,
                           dropout_rate=self.dropout_rate, has_covar_head=self.compute_covar,
-                          precision=self.precision, **testing)
+                          precision=self.precision, backbone_depth=self.backbone_depth, **testing)
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(cfg)

@@ -60,7 +60,8 @@ class Trainer(object):
         self.engine = Engine(make_config(image_hw, batch=self.batch, mc_samples=1, num_classes=int(header['num_classes']) + 1,
                                          anchors_per_location=int(header['anchors_per_location']), device=device,
                                          dropout_rate=float(header['dropout_rate']),
-                                         has_covar_head='regression_covar' in model_config['output_names'], training=True))
+                                         has_covar_head='regression_covar' in model_config['output_names'], training=True,
+                                         backbone_depth=101 if '101' in str(model_config.get('feature_extractor', {}).get('name', '')) else 50))
         self.engine.load_weights(weights)
         self._init = weights
 

@@ -11,6 +11,7 @@ import numpy as np
 from .constants import MEANS_DICT
 
 _STAGES = ((2, "abc", 64), (3, "abcd", 128), (4, "abcdef", 256), (5, "abc", 512))
+_STAGE4_101 = "abcdefghijklmnopqrstuvw"            # 1 ConvBlock + 22 IdentityBlocks (ResNet-101)
 
 # cls foreground bias: the reference initialises it to -log(99) (multitask_headers.py:79-83),
 # which leaves ~0 anchors after the background filter on random weights.  For benchmarking the
@@ -33,8 +34,8 @@ def _bn(rng, c, gamma_lo=0.5, gamma_hi=1.5):
 
 
 def make_weights(num_classes_with_bknd=8, anchors_per_location=9, seed=1000, cls_fg_bias=None,
-                 cov_out_std=0.02, backbone_bias=True):
-    """Returns {layer_name: {...}} for ResNet-50 + FPN + the three heads."""
+                 cov_out_std=0.02, backbone_bias=True, depth=50):
+    """Returns {layer_name: {...}} for ResNet-50 (or -101: depth=101) + FPN + the three heads."""
     w = {}
     idx = [0]
 
@@ -51,11 +52,16 @@ def make_weights(num_classes_with_bknd=8, anchors_per_location=9, seed=1000, cls
     w["bn_conv1"] = _bn(rng(), 64)
     cin = 64
     for stage, blocks, f1 in _STAGES:
+        if stage == 4 and depth == 101:
+            blocks = _STAGE4_101
         for blk in blocks:
             cb, bb = "res%d%s_branch" % (stage, blk), "bn%d%s_branch" % (stage, blk)
             conv(cb + "2a", 1, 1, cin, f1, backbone_bias); w[bb + "2a"] = _bn(rng(), f1)
             conv(cb + "2b", 3, 3, f1, f1, backbone_bias); w[bb + "2b"] = _bn(rng(), f1)
-            conv(cb + "2c", 1, 1, f1, 4 * f1, backbone_bias); w[bb + "2c"] = _bn(rng(), 4 * f1, 0.2, 0.4)
+            # the residual branch's last BN keeps the un-normalised random network from growing block after block
+            # (23 blocks in the ResNet-101 stage 4: smaller gains there)
+            g_lo, g_hi = (0.05, 0.15) if (stage == 4 and depth == 101) else (0.2, 0.4)
+            conv(cb + "2c", 1, 1, f1, 4 * f1, backbone_bias); w[bb + "2c"] = _bn(rng(), 4 * f1, g_lo, g_hi)
             if blk == "a":
                 conv(cb + "1", 1, 1, cin, 4 * f1, backbone_bias); w[bb + "1"] = _bn(rng(), 4 * f1)
             cin = 4 * f1

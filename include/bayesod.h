@@ -75,7 +75,10 @@ typedef struct {
                                     every layer keeps its activation, dropout is on with mc_samples = 1
                                     (retinanet_model.py:113-147, training branch), fp32 master weights, gradients
                                     and Adam moments live on the device.  bf16 precision only.                 */
-    int32_t reserved[4];
+    int32_t backbone_depth;      /* 0 / 50: ResNet-50, the reference's only backbone (feature_extractor.py:6-9).  101: stage 4 with
+                                    1 ConvBlock + 22 IdentityBlocks (layer names res4a .. res4w) -- BASELINE config 5's
+                                    "ResNet-101", which has no counterpart in the reference.             */
+    int32_t reserved[3];
 } bod_config;
 
 /* Sizes the caller needs to allocate host buffers. */

@@ -185,12 +185,20 @@ def make_numerics(weights, mode="literal", dtype=np.float64):
 _STAGES = ((2, "abc", 1), (3, "abcd", 2), (4, "abcdef", 2), (5, "abc", 2))
 
 
+def stages_for(weights):
+    """ResNet-50 (the reference) unless the weights hold the 23-block stage 4 of the build's ResNet-101 option
+    (res4a .. res4w; BASELINE config 5, no reference counterpart: SURVEY F6)."""
+    if "res4w_branch2a" in weights:
+        return ((2, "abc", 1), (3, "abcd", 2), (4, "abcdefghijklmnopqrstuvw", 2), (5, "abc", 2))
+    return _STAGES
+
+
 def feature_extractor(nm, image):
     """FeatureExtractor.call (feature_extractor.py:104-139). Returns (C5, C4-tap, C3-tap)."""
     x = nm.conv(nm.inp(image), "conv1", "bn_conv1", stride=2, padding="valid", relu=True)
     x = stem_pool(x)
     taps = {}
-    for stage, blocks, first_stride in _STAGES:
+    for stage, blocks, first_stride in stages_for(nm.w):
         for blk in blocks:
             cb, bb = "res%d%s_branch" % (stage, blk), "bn%d%s_branch" % (stage, blk)
             if blk == "a":      # ConvBlock (:283-309): stride on conv_1 (1x1, valid) and shortcut

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .network import BN_EPS, HEAD_NUM_CONVS, HEAD_PREFIX, HEAD_ID, _STAGES, fill_triangular_4
+from .network import BN_EPS, HEAD_NUM_CONVS, HEAD_PREFIX, HEAD_ID, stages_for, fill_triangular_4
 
 
 def _t(a):
@@ -59,7 +59,7 @@ def backbone_fpn(tw, image_nhwc):
     x = F.relu(bn(conv(x, tw, "conv1", 2), tw, "bn_conv1"))
     x = F.max_pool2d(F.pad(x, (2, 2, 1, 1)), 3, 2)
     taps = {}
-    for stage, blocks, fs in _STAGES:
+    for stage, blocks, fs in stages_for(tw):
         for blk in blocks:
             cb, bb = "res%d%s_branch" % (stage, blk), "bn%d%s_branch" % (stage, blk)
             s = fs if blk == "a" else 1

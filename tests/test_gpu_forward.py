@@ -101,17 +101,17 @@ def test_geometry_mismatch_is_rejected():
         Engine(make_config((100, 100), batch=1, mc_samples=2))
 
 
-@pytest.mark.parametrize("hw,batch,n", [((128, 128), 2, 3), ((96, 160), 1, 1)])
-def test_fp32_mode_end_to_end(hw, batch, n):
+@pytest.mark.parametrize("hw,batch,n,depth", [((128, 128), 2, 3, 50), ((96, 160), 1, 1, 50), ((96, 96), 1, 2, 101)])
+def test_fp32_mode_end_to_end(hw, batch, n, depth):
     """precision='fp32' (fp32 storage + exact-fp32 MFMA): the whole forward pass -- stem, 53 backbone
     convs, FPN, MC-dropout heads -- agrees with the float64 oracle element-wise within the 1e-3 bar of
     BASELINE.json's north_star (observed ~1e-5, fp32 summation noise through ~50 layers)."""
     from bayes_od_rc_amd import synthetic
     from bayes_od_rc_amd.engine import Engine, make_config
     seed, first = 99, 3
-    w = synthetic.make_weights()
+    w = synthetic.make_weights(depth=depth)           # depth 101: the build's ResNet-101 option (BASELINE config 5; SURVEY F6)
     frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
-    eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision="fp32"))
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision="fp32", backbone_depth=depth))
     eng.load_weights(w)
     eng.forward(frames, seed=seed, first_image_id=first)
     cls, box, cov = eng.get_raw()
