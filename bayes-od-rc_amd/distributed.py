@@ -116,6 +116,12 @@ def all_gather_samples(local, full, group=None):
         full.copy_(local)
         return full
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves device tensors through the host anyway; used by the one-GPU test of this mode (RCCL in production)
+        host = torch.empty(tuple(full.shape), dtype=full.dtype)
+        all_gather_samples(local.cpu(), host, group)
+        full.copy_(host)
+        return full
     if b == 1:
         dist.all_gather_into_tensor(full.view((world * n,) + tuple(local.shape[2:])),
                                     local.view((n,) + tuple(local.shape[2:])), group=group)

@@ -348,3 +348,22 @@ def test_bench_two_ranks_on_one_gpu():
     rec = json.loads(line[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert "cpu_baseline" not in rec
+
+
+def test_sample_sharded_two_ranks_on_one_gpu():
+    """The MC-sample-sharded mode with a real process group (2 ranks, both on this box's GPU, gloo): every rank computes
+    3 of 6 samples, the all-gather rebuilds the ensemble, detections equal the single-handle run bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tests", "tools", "sample_shard_worker.py")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "SAMPLE_SHARD_OK" in out.stdout
