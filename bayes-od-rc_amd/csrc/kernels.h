@@ -240,7 +240,7 @@ hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, v
                                      int pool_plane, hipStream_t s);
 hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s);
 hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s);
-hipError_t launch_sumsq(const float* g, long n, float* acc, hipStream_t s);
+hipError_t launch_sumsq(const float* g, long n, float* acc, float* partial1024, hipStream_t s);
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
                        float eps, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);

@@ -325,14 +325,25 @@ __global__ __launch_bounds__(256) void l2_grad_kernel(const float* w, float* g, 
     if (threadIdx.x == 0 && red[0] != 0.f) atomicAdd(loss_acc, red[0]);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* acc) {
+// Squared global gradient norm, deterministic (fixed partition, fixed reduction order, no atomics): data-parallel replicas
+// must derive the same clip factor from the same all-reduced gradients, bit for bit.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* partial) {
     __shared__ float red[256];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = g[i]; s += v * v; }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int nblocks, float* acc) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) *acc = red[0];
 }
 
 // tf.clip_by_global_norm(5.0) + keras Adam(epsilon): g *= clip / max(norm, clip); m, v updates; w -= lr_t * m / (sqrt(v) + eps)
@@ -390,8 +401,9 @@ hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* l
     hipLaunchKernelGGL(l2_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, n, rate, loss_acc);
     return hipGetLastError();
 }
-hipError_t launch_sumsq(const float* g, long n, float* acc, hipStream_t s) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, g, n, acc);
+hipError_t launch_sumsq(const float* g, long n, float* acc, float* partial1024, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, g, n, partial1024);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial1024, 1024, acc);
     return hipGetLastError();
 }
 hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,

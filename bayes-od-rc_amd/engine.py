@@ -239,6 +239,20 @@ class Engine(object):
         keys = ("total_loss", "cls_loss", "reg_loss", "covariance_loss", "regularization_loss", "grad_norm")
         return dict(zip(keys, [out[i] for i in range(6)]))
 
+    def train_gradients_view(self):
+        """torch tensor aliasing the contiguous fp32 gradient arena (for the data-parallel all-reduce)."""
+        import torch
+        from .distributed import DeviceArray
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.bod_train_gradients(self.h, C.byref(ptr), C.byref(n)))
+        return torch.as_tensor(DeviceArray(ptr.value, (n.value,), "<f4"), device=torch.device("cuda", self.cfg.device))
+
+    def train_apply(self, learning_rate):
+        """Clip + Adam on the gradient arena's current contents; returns the global gradient norm."""
+        g = C.c_double()
+        self._chk(self.lib.bod_train_apply(self.h, float(learning_rate), C.byref(g)))
+        return g.value
+
     def train_get(self, layer, kind, shape, what="value"):
         """A trainable tensor (kind: 'kernel' | 'bias' | 'gamma' | 'beta') or its gradient / Adam moments."""
         kinds = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3}

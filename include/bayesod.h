@@ -252,6 +252,12 @@ bod_status bod_train_step(bod_handle h, const float* images, int32_t images_on_d
                           uint64_t seed, uint32_t first_image_id, int32_t reg_kind, float label_smoothing,
                           float w_cls, float w_reg, float l2_rate, float learning_rate, int32_t apply_update,
                           double* out6);
+/* Data-parallel training (one process per GPU): after bod_train_step(..., apply_update = 0) the gradients of ALL
+ * trainable tensors lie in one contiguous fp32 device array -- bod_train_gradients returns its address and length
+ * (the handle's stream is synchronised first) -- so the ranks need ONE all-reduce (RCCL) over it, then
+ * bod_train_apply runs the clip + Adam update on whatever the array then holds (the mean gradient). */
+bod_status bod_train_gradients(bod_handle h, void** device_ptr, int64_t* count);
+bod_status bod_train_apply(bod_handle h, float learning_rate, double* grad_norm);
 /* Read a trainable tensor of a training handle back: layer = Keras layer name (conv or batch-norm), kind 0 kernel
  * (HWIO) / 1 bias / 2 gamma / 3 beta, what 0 value / 1 gradient of the last step / 2, 3 Adam moments. */
 bod_status bod_train_get(bod_handle h, const char* layer, int32_t kind, int32_t what, float* out, int64_t n);

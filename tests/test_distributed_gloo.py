@@ -122,3 +122,33 @@ def test_all_gather_samples_world2_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == {0: {1: True, 2: True}, 1: {1: True, 2: True}}
+
+
+def _mean_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayes_od_rc_amd import distributed as bd
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    bd.all_reduce_mean_(g)
+    q.put((rank, g.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_mean_world2_gloo():
+    """The data-parallel training step's single collective: in-place mean of the contiguous gradient arena."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mean_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = np.arange(1000, dtype=np.float32) * 1.5
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
