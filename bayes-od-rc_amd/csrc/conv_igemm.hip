@@ -736,7 +736,8 @@ __global__ __launch_bounds__(512) void conv_igemm_xr_persistent_kernel(const Con
 template <int ABL>
 static hipError_t launch_xr_persistent(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<256, 256, 2, 4, true>;
-    static bool attr_set = false;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
     static int n_cu = 0;
     auto kern = conv_igemm_xr_persistent_kernel<ABL>;
     if (!attr_set) {
@@ -757,7 +758,8 @@ static hipError_t launch_xr_persistent(const ConvArgs& a, hipStream_t s) {
 template <int BC, int BP, int WC, int WP, int ABL, bool XR = false>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
-    static bool attr_set = false;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
     const int nx = (a.M + BP - 1) / BP, ny = a.cout_pad / BC;
     auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, XR>;
     if (!attr_set) {

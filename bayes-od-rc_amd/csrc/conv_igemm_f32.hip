@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
 template <int BC, int BP, int WC, int WP>
 static hipError_t launch_f32_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * (BC + BP) * 128;
-    static bool attr_set = false;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
     auto kern = conv_igemm_f32_kernel<BC, BP, WC, WP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

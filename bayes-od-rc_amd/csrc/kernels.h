@@ -80,6 +80,12 @@ struct ConvArgs {
 };
 constexpr int XR_EXT_ROWS = 320;
 
+// hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
+struct PerDeviceOnce {
+    bool done[64] = {false};
+    bool* slot() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return &done[d]; }
+};
+
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible
 void conv_igemm_phase_cycles(unsigned long long* out16, bool reset);   // instrumented build (variant 90)

@@ -674,7 +674,8 @@ __global__ __launch_bounds__(64) void nms_kernel(NmsArgs a) {
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
     if (a.max_out > NMS_MAX_OUT) return hipErrorInvalidValue;
     constexpr int LDS = (NMS_BOX_CAP + NMS_MAX_OUT) * 16 + NMS_LDS_CAP * 8;
-    static bool attr_set = false;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

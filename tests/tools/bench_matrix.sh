@@ -6,7 +6,7 @@ d = json.loads(sys.stdin.readline())
 r = d['roofline']
 print('frames/s %.1f  ms/step %.3f  head TF/s %.1f (frac %.3f, share %.2f)  M %s  post ns/anchor %s' % (d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['share_of_step'], d['config'].get('kept_anchors_M'), d['config'].get('per_anchor_covariance_latency_ns')))"; }
 run
-run --batch 64 --steps 20
+run --batch 32
 run --batch 16
 run --batch 8
 run --batch 1 --steps 100
