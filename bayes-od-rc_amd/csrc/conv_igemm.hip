@@ -610,13 +610,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 }
         return;
     }
+    uint32_t rng_seed_lo = a.seed_lo, rng_seed_hi = a.seed_hi, rng_image_base = a.image_base;
+    if (a.dyn_rng) { rng_seed_lo = a.dyn_rng[0]; rng_seed_hi = a.dyn_rng[1]; rng_image_base = a.dyn_rng[2]; }      // uniform: scalar loads
     const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
     for (int n = 0; n < fan; ++n) {
 #pragma unroll
         for (int j = 0; j < FP; ++j) {
             const int pixl = wp * WTP + j * 32 + frow;
             char* prow = smem + pixl * (BC * 2);
-            const uint32_t img = a.image_base + ((uint32_t)rng[j].y >> 16);
+            const uint32_t img = rng_image_base + ((uint32_t)rng[j].y >> 16);
             const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rng[j].y & 0xFFFFu));
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
@@ -631,7 +633,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         if ((g4 & 1) == 0) {
                             if (ABL == 4) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
                             else rr = philox4x32_10((uint32_t)rng[j].x, dropout_group8(bc0 + col),
-                                                    sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
+                                                    sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
                         }
                         const uint32_t w0 = (g4 & 1) ? rr.z : rr.x, w1 = (g4 & 1) ? rr.w : rr.y;
                         o.x &= ((w0 & 0xFFFFu) >= a.drop_threshold ? 0x0000FFFFu : 0u) | ((w0 >> 16) >= a.drop_threshold ? 0xFFFF0000u : 0u);

@@ -360,6 +360,7 @@ bod_status ensure_raw(bod_context* h) {
 }
 
 bod_status train_init(bod_context* h);          // train_impl.inc
+const uint32_t* train_dyn_rng(bod_context* h);
 void train_destroy(bod_context* h);
 
 bod_status build_plan(bod_context* h) {
@@ -731,6 +732,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
                 op.conv.image_base = first_image;
                 op.conv.sample_base = (uint32_t)c.mc_sample_base;
+                op.conv.dyn_rng = train_dyn_rng(h);              // training: device copy of {seed, image id} (graph replay)
                 const bool timed = h->profiling && op.is_head3x3;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {

@@ -76,6 +76,9 @@ struct ConvArgs {
     // bf16 store through the row table) behind it.  cin / 64 must be divisible by ksplit.
     int32_t ksplit;
     float* partial;
+    // Optional device copy of {seed_lo, seed_hi, image_base}: when set it overrides the three by-value fields, so a launch
+    // recorded in a hipGraph (training step) can be replayed with a new dropout seed / image id (nullptr in inference).
+    const uint32_t* dyn_rng;
     uint32_t sample_base;  // added to every MC sample index before it enters the dropout counter (sample sharding)
 };
 constexpr int XR_EXT_ROWS = 320;
@@ -247,7 +250,7 @@ hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, v
 hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s);
 hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s);
 hipError_t launch_sumsq(const float* g, long n, float* acc, float* partial1024, hipStream_t s);
-hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, const float* lr_t, float beta1, float beta2,
                        float eps, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, long n, hipStream_t s);
 hipError_t launch_make_dgrad_rows(const RowEnt* fwd, RowEnt* out, int M, hipStream_t s);

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, 
 
 // tf.clip_by_global_norm(5.0) + keras Adam(epsilon): g *= clip / max(norm, clip); m, v updates; w -= lr_t * m / (sqrt(v) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip,
-                                                   float lr_t, float beta1, float beta2, float eps) {
+                                                   const float* lr_t_ptr, float beta1, float beta2, float eps) {
+    const float lr_t = *lr_t_ptr;              // device scalar: the launch can be replayed from a hipGraph with a new rate
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float norm = sqrtf(*sumsq);
@@ -406,7 +407,7 @@ hipError_t launch_sumsq(const float* g, long n, float* acc, float* partial1024, 
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial1024, 1024, acc);
     return hipGetLastError();
 }
-hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, float lr_t, float beta1, float beta2,
+hipError_t launch_adam(float* w, const float* g, float* m, float* v, long n, const float* sumsq, float clip, const float* lr_t, float beta1, float beta2,
                        float eps, hipStream_t s) {
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, m, v, n, sumsq, clip, lr_t, beta1, beta2, eps);
     return hipGetLastError();
