@@ -1544,9 +1544,8 @@ bod_status bod_stage_conv_wgrad(int32_t device, const float* x, int32_t B, int32
         const bool trace = getenv("BOD_TRACE_WGRAD") != nullptr;     // development aid: device time of the two phases
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
         if (trace) { for (auto& e : ev) HIPCHK(h, hipEventCreate(&e)); HIPCHK(h, hipEventRecord(ev[0], h->stream)); }
-        HIPCHK(h, launch_gather_transpose(d_dy, nullptr, d_dyt, M, Kpad, Cout, Cout, 1, 1, h->stream));
-        HIPCHK(h, launch_gather_transpose(in.d, d_rows, d_xct, M, Kpad, Cin, Cin, taps, KW, h->stream));
-        HIPCHK(h, launch_fill_row_bf16(d_xct + (size_t)taps * Cin * Kpad, M, Kpad, 1.0f, h->stream));
+        HIPCHK(h, launch_gather_transpose(d_dy, nullptr, d_dyt, M, Kpad, Cout, Cout, 1, 1, false, h->stream));
+        HIPCHK(h, launch_gather_transpose(in.d, d_rows, d_xct, M, Kpad, Cin, Cin, taps, KW, true, h->stream));
         // ---- the forward kernel as a plain GEMM: "pixels" = rows of Xcol^T, "weights" = dY^T, reduction = pixels
         if (trace) HIPCHK(h, hipEventRecord(ev[1], h->stream));
         std::vector<RowEnt> grow((size_t)N);

@@ -207,7 +207,7 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 // Training-step building blocks (train_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
-                                   int taps, int KW, hipStream_t s);
+                                   int taps, int KW, bool append_ones_row, hipStream_t s);
 hipError_t launch_fill_row_bf16(void* row, int n_set, int n_total, float value, hipStream_t s);
 
 struct FoldArgs {
@@ -229,7 +229,8 @@ struct ActBwdArgs {
     float* dres;                // gradient buffer of the residual input or nullptr
     uint16_t* dz;               // dense [M][cout_pad] bf16
     uint16_t* dzp;              // the same values in the output plane's own (zero-bordered) layout, or nullptr
-    int32_t M, cout, cout_pad, out_cstride, res_cstride;
+    uint16_t* dzt;              // the same values transposed, [cout_pad][Kpad] (columns M..Kpad-1 zero), or nullptr
+    int32_t M, cout, cout_pad, out_cstride, res_cstride, Kpad;
     float scale;                // dropout keep scale (1 without dropout)
 };
 struct UnfoldArgs {
@@ -242,7 +243,9 @@ struct UnfoldArgs {
     float* dot;                 // [cout] zero-initialised scratch for the gamma dot products (left zeroed)
 };
 hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s);
-hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s);
+hipError_t launch_fold_pack_all(const FoldArgs* device_array, int count, long max_elems, hipStream_t s);
+// *wrote_transpose tells the caller whether a.dzt was produced by the same launch (tile form) or still needs a transpose pass
+hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s, bool* wrote_transpose = nullptr);
 hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s);
 hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin, int in_cstride, hipStream_t s);
 hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,

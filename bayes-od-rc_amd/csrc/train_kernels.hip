@@ -11,9 +11,11 @@
 // out[(tap*C + c)][m] = in[(rows[m].in_off + ky*rows[m].in_pitch + kx) * cstride + c]   (rows == nullptr: in_off = m)
 // for m < M, zero for M <= m < Kpad.  64 x 64 (m x c) tiles through LDS: reads are contiguous in c, writes in m.
 __global__ __launch_bounds__(256) void gather_transpose_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
-                                                               int M, int Kpad, int C, int cstride, int KW) {
+                                                               int M, int Kpad, int C, int cstride, int KW, int ones_row) {
     __shared__ uint16_t tile[64][66];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    if (ones_row >= 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64 && m0 + (int)threadIdx.x < Kpad)
+        out[(size_t)ones_row * Kpad + m0 + threadIdx.x] = m0 + (int)threadIdx.x < M ? (uint16_t)0x3F80 : (uint16_t)0;      // bf16 1.0: the bias-gradient row
     const int ky = tap / KW, kx = tap - ky * KW;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 4 rows of 64 threads
     for (int r = ty; r < 64; r += 4) {
@@ -36,9 +38,11 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(const uint16_t* i
 // Vector form for channel counts / pixel strides that are multiples of 8: 16-byte reads along the channels, 16-byte
 // writes along the pixels.
 __global__ __launch_bounds__(256) void gather_transpose_vec_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
-                                                                   int M, int Kpad, int C, int cstride, int KW) {
+                                                                   int M, int Kpad, int C, int cstride, int KW, int ones_row) {
     __shared__ uint16_t tile[64][72];                                  // [m][c], 144-byte rows keep the 16-byte row writes aligned
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+    if (ones_row >= 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64 && m0 + (int)threadIdx.x < Kpad)
+        out[(size_t)ones_row * Kpad + m0 + threadIdx.x] = m0 + (int)threadIdx.x < M ? (uint16_t)0x3F80 : (uint16_t)0;
     const int ky = tap / KW, kx = tap - ky * KW;
     const int sub = threadIdx.x & 7, row = threadIdx.x >> 3;            // 8 threads x 16 B per 64-channel row, 32 rows per pass
 #pragma unroll
@@ -68,9 +72,11 @@ __global__ __launch_bounds__(256) void gather_transpose_vec_kernel(const uint16_
 // Few channels per pixel (the stem's image, C = 3): tile over the joint row index n = tap * C + c instead of wasting
 // 61 of 64 channel lanes.
 __global__ __launch_bounds__(256) void gather_transpose_smallc_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
-                                                                      int M, int Kpad, int C, int cstride, int KW, int NR) {
+                                                                      int M, int Kpad, int C, int cstride, int KW, int NR, int ones_row) {
     __shared__ uint16_t tile[64][66];                                  // [n][m]
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    if (ones_row >= 0 && blockIdx.y == 0 && threadIdx.x < 64 && m0 + (int)threadIdx.x < Kpad)
+        out[(size_t)ones_row * Kpad + m0 + threadIdx.x] = m0 + (int)threadIdx.x < M ? (uint16_t)0x3F80 : (uint16_t)0;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int m = m0 + tx;
     RowEnt e{};
@@ -99,21 +105,22 @@ __global__ void fill_row_bf16_kernel(uint16_t* row, int n_set, int n_total, uint
 }
 
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
-                                   int taps, int KW, hipStream_t s) {
+                                   int taps, int KW, bool append_ones_row, hipStream_t s) {
+    const int ones_row = append_ones_row ? taps * C : -1;
     dim3 grid((Kpad + 63) / 64, (C + 63) / 64, taps);
     if (C % 8 == 0 && cstride % 8 == 0 && Kpad % 8 == 0) {
         hipLaunchKernelGGL(gather_transpose_vec_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
-                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW);
+                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, ones_row);
         return hipGetLastError();
     }
     if (C < 16) {
         const int NR = taps * C;
         hipLaunchKernelGGL(gather_transpose_smallc_kernel, dim3((Kpad + 63) / 64, (NR + 63) / 64), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
-                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, NR);
+                           reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, NR, ones_row);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(gather_transpose_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
-                       reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW);
+                       reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, ones_row);
     return hipGetLastError();
 }
 
@@ -215,6 +222,68 @@ __global__ __launch_bounds__(256) void act_backward_gather_vec_kernel(ActBwdArgs
         if (a.dzp) *reinterpret_cast<uint4*>(a.dzp + o) = packed;
     }
     *reinterpret_cast<uint4*>(a.dz + (size_t)m * a.cout_pad + co) = packed;
+}
+
+// 64 pixels x 64 channels per block: the vector form above plus, through an LDS tile, the transposed copy dZ^T that
+// the weight-gradient GEMM reads (saves the separate transpose launch); residual gradients are staged through LDS so
+// that a wavefront's atomics fall on consecutive channels of one pixel.
+__global__ __launch_bounds__(256) void act_backward_tile_kernel(ActBwdArgs a) {
+    __shared__ uint16_t tT[64][66];                                    // [channel][pixel]
+    __shared__ float tR[32][65];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tm = tid >> 3, cl = (tid & 7) * 8, co = c0 + cl;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int ml = pass * 32 + tm, m = m0 + ml;
+        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool live = m < a.M && co < a.cout;
+        size_t o = 0;
+        if (live) {
+            const RowEnt e = a.rows[m];
+            o = (size_t)e.out_off * a.out_cstride + co;
+            const float4 g0 = *reinterpret_cast<const float4*>(a.dout + o), g1 = *reinterpret_cast<const float4*>(a.dout + o + 4);
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            if (a.out_bf16) {
+                const uint4 y = *reinterpret_cast<const uint4*>(a.out_bf16 + o);
+                const uint32_t yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint16_t hv = (uint16_t)(yw[k >> 1] >> ((k & 1) * 16));
+                    g[k] = (hv & 0x7FFFu) == 0 ? 0.f : g[k] * a.scale;
+                }
+            }
+        }
+        uint16_t hb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { hb[k] = f2bf_dev(g[k]); tT[cl + k][ml] = hb[k]; }
+        if (m < a.M) {
+            const uint4 packed = make_uint4((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16),
+                                            (uint32_t)hb[4] | ((uint32_t)hb[5] << 16), (uint32_t)hb[6] | ((uint32_t)hb[7] << 16));
+            *reinterpret_cast<uint4*>(a.dz + (size_t)m * a.cout_pad + co) = packed;
+            if (live && a.dzp) *reinterpret_cast<uint4*>(a.dzp + o) = packed;
+        }
+        if (a.dres) {                                                  // (uniform across the block)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tR[tm][cl + k] = g[k];
+            __syncthreads();
+            const int cc = tid & 63;
+            for (int j = tid >> 6; j < 32; j += 4) {
+                const int mm = m0 + pass * 32 + j;
+                const float v = tR[j][cc];
+                if (mm < a.M && v != 0.f) atomicAdd(a.dres + (size_t)a.rows[mm].res_off * a.res_cstride + c0 + cc, v);
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int row = tid >> 2, mq = (tid & 3) * 16;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&tT[row][mq]);
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = src[k];
+    uint4* dst = reinterpret_cast<uint4*>(a.dzt + (size_t)(c0 + row) * a.Kpad + m0 + mq);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // second consumer of a layer's output through its ReLU'd copy (P6 -> relu -> P7): dOut += dOutRelu * [out > 0]
@@ -360,12 +429,52 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
     w[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
 
+// every convolution of the model in ONE launch: blockIdx.y selects the layer's descriptor (device array)
+__global__ __launch_bounds__(256) void fold_pack_all_kernel(const FoldArgs* all) {
+    const FoldArgs a = all[blockIdx.y];
+    const long n = (long)a.cout_pad * a.taps * a.cin;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int ci = (int)(i % a.cin);
+        const int t = (int)((i / a.cin) % a.taps);
+        const int co = (int)(i / ((long)a.cin * a.taps));
+        float v = 0.f;
+        if (co < a.cout) {
+            const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
+            v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
+        }
+        if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
+        if (a.w_fwd32 && co < a.cout) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;
+        if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
+        if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.cout_pad; i += stride) {
+        float b = 0.f;
+        if (i < a.cout) {
+            b = a.bias ? a.bias[i] : 0.f;
+            if (a.gamma) { const float s = a.gamma[i] / sqrtf(a.var[i] + a.eps); b = (b - a.mean[i]) * s + a.beta[i]; }
+        }
+        a.b_fwd[i] = b;
+    }
+}
+hipError_t launch_fold_pack_all(const FoldArgs* device_array, int count, long max_elems, hipStream_t s) {
+    const long want = (max_elems + 255) / 256;
+    hipLaunchKernelGGL(fold_pack_all_kernel, dim3((unsigned)(want < 96 ? want : 96), count), dim3(256), 0, s, device_array);
+    return hipGetLastError();
+}
+
 hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s) {
     const long n = (long)a.cout_pad * a.taps * a.cin;
     hipLaunchKernelGGL(fold_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s) {
+hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s, bool* wrote_transpose) {
+    if (wrote_transpose) *wrote_transpose = false;
+    if (a.dzt && a.cout % 8 == 0 && a.cout_pad % 64 == 0 && a.out_cstride % 8 == 0 && a.Kpad % 64 == 0) {
+        hipLaunchKernelGGL(act_backward_tile_kernel, dim3(a.Kpad / 64, a.cout_pad / 64), dim3(256), 0, s, a);
+        if (wrote_transpose) *wrote_transpose = true;
+        return hipGetLastError();
+    }
     // layers with a residual input keep the one-thread-per-element form: its atomics are coalesced across the wavefront
     if (!a.dres && a.cout % 8 == 0 && a.cout_pad % 8 == 0 && a.out_cstride % 8 == 0) {
         const long nv = (long)a.M * (a.cout_pad / 8);
