@@ -312,35 +312,53 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* dxcol, const R
 // scan order (the element the forward kernel's strict '>' scan keeps); masked by the stem's ReLU.
 __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t* stem_out, const float* dpool, uint16_t* dz, int B, int ih, int iw,
                                                                  int oh, int ow, int pool_pitch, int pool_plane) {
-    // one thread per stem pixel-channel: sum the pooled gradients of the (up to 4) windows whose arg-max it is
+    // one thread per stem pixel and 8 channels: sum the pooled gradients of the (up to 4) windows whose arg-max it is
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n = (long)B * ih * iw * 64;
+    const long n = (long)B * ih * iw * 8;
     if (i >= n) return;
-    const int c = (int)(i & 63);
-    const int x = (int)((i >> 6) % iw), y = (int)((i >> 6) / iw % ih), b = (int)((i >> 6) / ((long)iw * ih));
-    const float v = bf2f_dev(stem_out[i]);
-    float g = 0.f;
-    if (v > 0.f) {
+    const int c = (int)(i & 7) * 8;
+    const int x = (int)((i >> 3) % iw), y = (int)((i >> 3) / iw % ih), b = (int)((i >> 3) / ((long)iw * ih));
+    const uint4 vq = *reinterpret_cast<const uint4*>(stem_out + i * 8);
+    const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
+    float v[8], g[8];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = __uint_as_float((vw[k >> 1] >> ((k & 1) * 16)) << 16); g[k] = 0.f; any |= v[k] > 0.f; }
+    if (any) {
         // windows (oy, ox) cover padded rows 2oy..2oy+2 (pad 1 on top) and padded cols 2ox..2ox+2 (pad 2 on the left)
-        for (int oy = (y + 1 - 2 + 1) / 2 < 0 ? 0 : (y + 1 - 2 + 1) / 2; oy <= (y + 1) / 2 && oy < oh; ++oy) {
+        for (int oy = y / 2; oy <= (y + 1) / 2 && oy < oh; ++oy) {
             if (2 * oy > y + 1 || 2 * oy + 2 < y + 1) continue;
-            for (int ox = (x + 2 - 2 + 1) / 2 < 0 ? 0 : (x + 2 - 2 + 1) / 2; ox <= (x + 2) / 2 && ox < ow; ++ox) {
+            for (int ox = (x + 1) / 2; ox <= (x + 2) / 2 && ox < ow; ++ox) {
                 if (2 * ox > x + 2 || 2 * ox + 2 < x + 2) continue;
-                // is (y, x) the first maximum of this window?
-                bool first = true;
-                for (int wy = 0; wy < 3 && first; ++wy)
+                bool first[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) first[k] = v[k] > 0.f;
+                for (int wy = 0; wy < 3; ++wy)
                     for (int wx = 0; wx < 3; ++wx) {
                         const int sy = 2 * oy + wy - 1, sx = 2 * ox + wx - 2;
-                        float u = 0.f;                                           // zero padding (inputs are post-ReLU)
-                        if (sy >= 0 && sy < ih && sx >= 0 && sx < iw) u = bf2f_dev(stem_out[(((size_t)b * ih + sy) * iw + sx) * 64 + c]);
+                        uint4 uq = make_uint4(0u, 0u, 0u, 0u);                   // zero padding (inputs are post-ReLU)
+                        if (sy >= 0 && sy < ih && sx >= 0 && sx < iw)
+                            uq = *reinterpret_cast<const uint4*>(stem_out + (((size_t)b * ih + sy) * iw + sx) * 64 + c);
+                        const uint32_t uw[4] = {uq.x, uq.y, uq.z, uq.w};
                         const bool before = sy < y || (sy == y && sx < x);
-                        if (u > v || (u == v && before)) { first = false; break; }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float u = __uint_as_float((uw[k >> 1] >> ((k & 1) * 16)) << 16);
+                            if (u > v[k] || (u == v[k] && before)) first[k] = false;
+                        }
                     }
-                if (first) g += dpool[((size_t)b * pool_plane + (size_t)(oy + 1) * pool_pitch + (ox + 1)) * 64 + c];
+                const float* dp = dpool + ((size_t)b * pool_plane + (size_t)(oy + 1) * pool_pitch + (ox + 1)) * 64 + c;
+                const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
+                const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (first[k]) g[k] += d[k];
             }
         }
     }
-    dz[i] = f2bf_dev(g);
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf_dev(g[2 * k]) | ((uint32_t)f2bf_dev(g[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4*>(dz + i * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // dW'[n = (tap, ci)][co] and db'[co] (row N-1) of the folded layer -> gradients of the master parameters:
@@ -496,7 +514,7 @@ hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int
 }
 hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,
                                      int pool_plane, hipStream_t s) {
-    const long n = (long)B * ih * iw * 64;
+    const long n = (long)B * ih * iw * 8;
     hipLaunchKernelGGL(stem_pool_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(stem_out), dpool,
                        reinterpret_cast<uint16_t*>(dz), B, ih, iw, oh, ow, pool_pitch, pool_plane);
     return hipGetLastError();
