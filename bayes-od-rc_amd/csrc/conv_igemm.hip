@@ -512,7 +512,41 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     }
     const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT, of32 = a.flags & CONV_OUT_F32;
     if (of32) {
-        // ---- fp32 outputs (head 1x1 convs): direct stores, per-channel validity
+        // ---- fp32 outputs.  Channel counts that are multiples of 4 (input gradients, weight gradients): 16-byte
+        // accesses, and with CONV_ACCUM the four old values of a fragment row are loaded before the first store
+        const bool accum = a.flags & CONV_ACCUM;
+        if ((a.cout_valid & 3) == 0) {
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int m = bp0 + wp * WTP + j * 32 + frow;
+                if (m >= a.M) continue;
+                float* orow = reinterpret_cast<float*>(G.out) + (size_t)a.rows[m].out_off * a.out_cstride;
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const int co0 = bc0 + wc * WTC + i * 32 + fhalf * 4;
+                    float4 old[4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        old[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (accum && co0 + g4 * 8 < a.cout_valid) old[g4] = *reinterpret_cast<const float4*>(orow + co0 + g4 * 8);
+                    }
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int co = co0 + g4 * 8;
+                        if (co >= a.cout_valid) continue;
+                        const float4 bv = *reinterpret_cast<const float4*>(G.bias + co);
+                        float4 v = make_float4(acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
+                                               acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w);
+                        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        // (old + r, in this order: the same rounding as the per-channel path)
+                        if (accum) v = make_float4(old[g4].x + v.x, old[g4].y + v.y, old[g4].z + v.z, old[g4].w + v.w);
+                        *reinterpret_cast<float4*>(orow + co) = v;
+                    }
+                }
+            }
+            return;
+        }
+        // per-channel validity (head 1x1 convs: 36 / 90 / 720 channels)
 #pragma unroll
         for (int j = 0; j < FP; ++j) {
             const int m = bp0 + wp * WTP + j * 32 + frow;
@@ -528,7 +562,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     float v[4] = {acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
                                   acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w};
                     float* o = reinterpret_cast<float*>(G.out) + (size_t)out_off * a.out_cstride + co;
-                    const bool accum = a.flags & CONV_ACCUM;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (co + q >= a.cout_valid) continue;
@@ -827,10 +860,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // half the chip idles and the 128x128 configuration (two workgroups per CU, 4x the tiles) is 20-25 % faster
 // (measured on the stage-4 / FPN layers: 128 big tiles for 256 CUs).
 static bool conv_big_tile_pays(const ConvArgs& a) {
-    if (a.cout_pad % 256 != 0 || (a.flags & CONV_OUT_F32)) return false;
+    // fp32 accumulate-in-place launches (training: input gradients) take the big tile from 96 tiles on (measured on the
+    // training step, batch 8 and 32); other fp32-output launches never do.  BOD_F32_BIG_TILES=0 disables, =n moves the threshold
+    static const int f32_min_tiles = getenv("BOD_F32_BIG_TILES") ? atoi(getenv("BOD_F32_BIG_TILES")) : 96;
+    if (a.cout_pad % 256 != 0) return false;
     static const bool old_rule = getenv("BOD_TILE_RULE_OLD") != nullptr;          // A/B aid
-    if (old_rule) return a.M >= 16384;
+    if (old_rule) return a.M >= 16384 && !(a.flags & CONV_OUT_F32);
     const long tiles = (long)((a.M + 255) / 256) * (a.cout_pad / 256) * (a.groups > 0 ? a.groups : 1);
+    if (a.flags & CONV_OUT_F32) return (a.flags & CONV_ACCUM) && f32_min_tiles > 0 && tiles >= f32_min_tiles;
     return tiles >= 384;
 }
 

@@ -21,3 +21,18 @@ rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), 
                    "order by 7 desc limit 10").fetchall()
 for r in rows:
     print("%-48s grid=(%d,%d,%d) wg=%d calls=%d avg_us=%.1f vgpr=%s agpr=%s lds=%s" % ((r[0][:48],) + tuple(r[1:])))
+
+print()
+print("# launches grouped by (kernel, grid), by total time:")
+rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3 "
+                   "from kernels group by name, grid_x, grid_y, grid_z order by 7 desc limit 40").fetchall()
+for r in rows:
+    print("%-48s grid=(%d,%d,%d) wg=%d calls=%d total_ms=%.2f avg_us=%.1f" % ((r[0][:48],) + tuple(r[1:])))
+
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+for key in ("stream_id", "queue_id"):
+    if key in cols:
+        print()
+        print("# kernel time per %s:" % key)
+        for r in cur.execute("select %s, count(*), sum(end-start)/1e6, (max(end)-min(start))/1e6 from kernels group by %s order by 3 desc" % (key, key)).fetchall():
+            print("%s=%s launches=%d busy_ms=%.2f span_ms=%.2f" % (key, r[0], r[1], r[2], r[3]))
