@@ -449,35 +449,63 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
 
 // every convolution of the model in ONE launch: blockIdx.y selects the layer's descriptor (device array)
 __global__ __launch_bounds__(256) void fold_pack_all_kernel(const FoldArgs* all) {
+    __shared__ uint16_t tile[64][66];                                  // [ci][co]
     const FoldArgs a = all[blockIdx.y];
-    const long n = (long)a.cout_pad * a.taps * a.cin;
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const int ci = (int)(i % a.cin);
-        const int t = (int)((i / a.cin) % a.taps);
-        const int co = (int)(i / ((long)a.cin * a.taps));
-        float v = 0.f;
-        if (co < a.cout) {
-            const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
-            v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < a.cout_pad; i += 256) {
+            float b = 0.f;
+            if (i < a.cout) {
+                b = a.bias ? a.bias[i] : 0.f;
+                if (a.gamma) { const float s = a.gamma[i] / sqrtf(a.var[i] + a.eps); b = (b - a.mean[i]) * s + a.beta[i]; }
+            }
+            a.b_fwd[i] = b;
         }
-        if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
-        if (a.w_fwd32 && co < a.cout) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;
-        if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
-        if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
+    if (a.w_fwd32 || (a.cin & 63) || (a.cout_pad & 63)) {             // the stem (fp32 [tap*cin][cout], 3 input channels): element-wise
+        const long n = (long)a.cout_pad * a.taps * a.cin;
+        for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
+            const int ci = (int)(i % a.cin);
+            const int t = (int)((i / a.cin) % a.taps);
+            const int co = (int)(i / ((long)a.cin * a.taps));
+            float v = 0.f;
+            if (co < a.cout) {
+                const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
+                v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
+            }
+            if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
+            if (a.w_fwd32 && co < a.cout) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;
+            if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
+            if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
+        }
+        return;
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.cout_pad; i += stride) {
-        float b = 0.f;
-        if (i < a.cout) {
-            b = a.bias ? a.bias[i] : 0.f;
-            if (a.gamma) { const float s = a.gamma[i] / sqrtf(a.var[i] + a.eps); b = (b - a.mean[i]) * s + a.beta[i]; }
+    // 64 (ci) x 64 (co) tiles of one tap: the master kernel [tap][ci][co] is read along co; the two gradient-side
+    // layouts are co-contiguous as well, the forward layout [co][tap][ci] is written along ci through the LDS tile
+    const int ct = a.cin / 64, ot = a.cout_pad / 64;
+    const int ntiles = a.taps * ct * ot;
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int o_t = ti % ot, c_t = (ti / ot) % ct, t = ti / (ot * ct);
+        const int co = o_t * 64 + tx;
+        const float s = co < a.cout ? (a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f) : 0.f;
+        for (int r = ty; r < 64; r += 4) {
+            const int ci = c_t * 64 + r;
+            const float v = co < a.cout ? a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s : 0.f;
+            const uint16_t hv = f2bf_dev(v);
+            if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = hv;
+            if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = hv;
+            tile[r][tx] = hv;
         }
-        a.b_fwd[i] = b;
+        __syncthreads();
+        if (a.w_fwd)
+            for (int r = ty; r < 64; r += 4)
+                a.w_fwd[((size_t)(o_t * 64 + r) * a.taps + t) * a.cin + c_t * 64 + tx] = tile[tx][r];
+        __syncthreads();
     }
 }
 hipError_t launch_fold_pack_all(const FoldArgs* device_array, int count, long max_elems, hipStream_t s) {
-    const long want = (max_elems + 255) / 256;
-    hipLaunchKernelGGL(fold_pack_all_kernel, dim3((unsigned)(want < 96 ? want : 96), count), dim3(256), 0, s, device_array);
+    const long want = (max_elems + 4095) / 4096;                      // tiles of the largest layer
+    hipLaunchKernelGGL(fold_pack_all_kernel, dim3((unsigned)(want < 128 ? want : 128), count), dim3(256), 0, s, device_array);
     return hipGetLastError();
 }
 
