@@ -241,6 +241,8 @@ struct UnfoldArgs {
     int32_t taps, cin, cout;
     float *d_kernel, *d_bias, *d_gamma, *d_beta;
     float* dot;                 // [cout] zero-initialised scratch for the gamma dot products (left zeroed)
+    float l2;                   // Keras l2(rate) on the kernel: d_kernel += 2 rate K, *l2_loss += rate sum K^2 (0 = none)
+    float* l2_loss;
 };
 hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s);
 hipError_t launch_fold_pack_all(const FoldArgs* device_array, int count, long max_elems, hipStream_t s);

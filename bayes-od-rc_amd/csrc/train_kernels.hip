@@ -369,20 +369,32 @@ __global__ __launch_bounds__(256) void unfold_grad_kernel(UnfoldArgs a) {
     const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int co = blockIdx.x * 64 + c;
     const int nk = a.taps * a.cin;
-    float dot = 0.f;
+    float dot = 0.f, sq = 0.f;
     if (co < a.cout) {
         const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
         const int n1 = min(nk, (int)(blockIdx.y + 1) * 32);
         for (int n = blockIdx.y * 32 + r; n < n1; n += 4) {
             const size_t i = (size_t)n * a.cout + co;
-            const float g = a.dwp[i];
-            a.d_kernel[i] += g * s;
-            dot += g * a.kernel[i];
+            const float g = a.dwp[i], k = a.kernel[i];
+            a.d_kernel[i] += g * s + 2.0f * a.l2 * k;
+            dot += g * k;
+            sq += k * k;
         }
     }
     red[r][c] = dot;
     __syncthreads();
     if (r == 0 && co < a.cout && a.gamma) atomicAdd(a.dot + co, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    if (a.l2 > 0.f) {                                                  // (uniform) regularisation loss of this block's slice
+        __syncthreads();
+        red[r][c] = sq;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (threadIdx.x == 0 && v != 0.f) atomicAdd(a.l2_loss, a.l2 * v);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void unfold_grad_final_kernel(UnfoldArgs a) {
