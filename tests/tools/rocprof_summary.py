@@ -24,10 +24,16 @@ for r in rows:
 
 print()
 print("# launches grouped by (kernel, grid), by total time:")
-rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3 "
-                   "from kernels group by name, grid_x, grid_y, grid_z order by 7 desc limit 40").fetchall()
+kcols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+sid = "stream_id" if "stream_id" in kcols else "0"
+rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3, %s "
+                   "from kernels group by name, grid_x, grid_y, grid_z, %s order by 7 desc limit 40" % (sid, sid)).fetchall()
 for r in rows:
-    print("%-48s grid=(%d,%d,%d) wg=%d calls=%d total_ms=%.2f avg_us=%.1f" % ((r[0][:48],) + tuple(r[1:])))
+    print("%-48s grid=(%d,%d,%d) wg=%d calls=%d total_ms=%.2f avg_us=%.1f stream=%s" % ((r[0][:48],) + tuple(r[1:])))
+print()
+print("# per stream and kernel name:")
+for r in cur.execute("select %s, name, count(*), sum(end-start)/1e6 from kernels group by %s, name order by 1, 4 desc" % (sid, sid)).fetchall():
+    if r[3] >= 0.5: print("stream=%s %-64s calls=%d total_ms=%.2f" % (r[0], r[1][:64], r[2], r[3]))
 
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
 for key in ("stream_id", "queue_id"):
