@@ -646,6 +646,54 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     uint32_t rng_seed_lo = a.seed_lo, rng_seed_hi = a.seed_hi, rng_image_base = a.image_base;
     if (a.dyn_rng) { rng_seed_lo = a.dyn_rng[0]; rng_seed_hi = a.dyn_rng[1]; rng_image_base = a.dyn_rng[2]; }      // uniform: scalar loads
     const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
+    if (fan > 1 && !fuse && !G.out_relu && ABL == 0) {
+        // ---- N-way dropout fan-out (first tower layer: one convolution, N masked copies).  The unmasked tile goes
+        // through LDS ONCE; each thread then keeps (pixel, 16-channel group) items in registers and, per sample, draws
+        // the group's two Philox calls (contract v2: a call decides channels {x..x+3, x+8..x+11}), masks and stores
+        // 2 x 16 bytes -- no LDS traffic and no barrier inside the sample loop.
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int pixl = wp * WTP + j * 32 + frow;
+            char* prow = smem + pixl * (BC * 2);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
+                    *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = pk[i][j][g4];
+                }
+        }
+        __syncthreads();
+        constexpr int GPR = BC / 16;                                   // 16-channel groups per pixel row
+        const uint32_t thr = a.drop_threshold;
+        auto keep2 = [thr](uint32_t w) { return ((w & 0xFFFFu) >= thr ? 0x0000FFFFu : 0u) | ((w >> 16) >= thr ? 0xFFFF0000u : 0u); };
+#pragma unroll 1
+        for (int q = tid; q < BP * GPR; q += THREADS) {
+            const int pixl = q / GPR, gq = q % GPR;
+            const int off = s_off[pixl];
+            if (off < 0) continue;
+            const char* prow = smem + pixl * (BC * 2);
+            const uint4 va = *reinterpret_cast<const uint4*>(prow + ((((2 * gq) ^ pixl) & (CPR - 1)) << 4));
+            const uint4 vb = *reinterpret_cast<const uint4*>(prow + ((((2 * gq + 1) ^ pixl) & (CPR - 1)) << 4));
+            const int2 r = s_rng[pixl];
+            const uint32_t img = rng_image_base + ((uint32_t)r.y >> 16);
+            const int c0 = bc0 + gq * 16;
+            const uint32_t ga = dropout_group8(c0), gb = dropout_group8(c0 + 4);
+            uint16_t* o = reinterpret_cast<uint16_t*>(G.out) + (size_t)off * a.out_cstride + c0;
+            const size_t sample_stride = (size_t)a.fan_stride * a.out_cstride;
+#pragma unroll 1
+            for (int n = 0; n < fan; ++n) {
+                const uint32_t key = (a.sample_base + (uint32_t)n) | ((uint32_t)G.layer_id << 16);
+                const Philox4 p0 = philox4x32_10((uint32_t)r.x, ga, key, img, rng_seed_lo, rng_seed_hi);
+                const Philox4 p1 = philox4x32_10((uint32_t)r.x, gb, key, img, rng_seed_lo, rng_seed_hi);
+                const uint4 oa = make_uint4(va.x & keep2(p0.x), va.y & keep2(p0.y), va.z & keep2(p1.x), va.w & keep2(p1.y));
+                const uint4 ob = make_uint4(vb.x & keep2(p0.z), vb.y & keep2(p0.w), vb.z & keep2(p1.z), vb.w & keep2(p1.w));
+                *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride) = oa;
+                *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride + 8) = ob;
+            }
+        }
+        return;
+    }
     for (int n = 0; n < fan; ++n) {
 #pragma unroll
         for (int j = 0; j < FP; ++j) {
@@ -859,6 +907,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 // 256x256 tiles (one 8-wave workgroup per CU) pay once there are at least ~1.5 workgroups per CU; below that
 // half the chip idles and the 128x128 configuration (two workgroups per CU, 4x the tiles) is 20-25 % faster
 // (measured on the stage-4 / FPN layers: 128 big tiles for 256 CUs).
+// The N-way dropout fan-out layer takes the big tile too (from 1 024 tiles on) since its epilogue keeps the tile in
+// registers across the samples (1.9-2.0 ms on 256x256 tiles vs 2.2 ms on 128x128 at 64 frames; the older epilogue, an
+// LDS round trip and two barriers per sample, preferred two co-resident 128x128 workgroups).  BOD_FAN_SMALL=1: A/B aid.
+static bool fan_out_small_tile() {
+    static const bool small = getenv("BOD_FAN_SMALL") && atoi(getenv("BOD_FAN_SMALL")) == 1;
+    return small;
+}
+
 static bool conv_big_tile_pays(const ConvArgs& a) {
     // fp32 accumulate-in-place launches (training: input gradients) take the big tile from 96 tiles on (measured on the
     // training step, batch 8 and 32); other fp32-output launches never do.  BOD_F32_BIG_TILES=0 disables, =n moves the threshold
@@ -868,6 +924,7 @@ static bool conv_big_tile_pays(const ConvArgs& a) {
     if (old_rule) return a.M >= 16384 && !(a.flags & CONV_OUT_F32);
     const long tiles = (long)((a.M + 255) / 256) * (a.cout_pad / 256) * (a.groups > 0 ? a.groups : 1);
     if (a.flags & CONV_OUT_F32) return (a.flags & CONV_ACCUM) && f32_min_tiles > 0 && tiles >= f32_min_tiles;
+    if (a.fan_count > 1) return tiles >= 1024;        // (fan-out layer: -1 % at 513 tiles, +0.5 % from 1 026 on)
     return tiles >= 384;
 }
 
@@ -876,9 +933,7 @@ bool conv_igemm_uses_full_cout_tile(const ConvArgs& a) {
     // overrides the size heuristic (tests exercise both configurations on small inputs)
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     bool big = conv_big_tile_pays(a);
-    // the N-way dropout fan-out epilogue is VALU-bound (N Philox rounds per tile): run it with two
-    // resident blocks per CU (128x128 tiles) so one block's epilogue overlaps the other's MFMA loop
-    if (a.fan_count > 1) big = false;
+    if (a.fan_count > 1 && fan_out_small_tile()) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
     if (forced == 128) big = false;
     return big && a.cout_pad == 256;
@@ -889,7 +944,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     bool big = conv_big_tile_pays(a);
-    if (a.fan_count > 1) big = false;
+    if (a.fan_count > 1 && fan_out_small_tile()) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
     if (forced == 128) big = false;
     for (int g = 0; g < a.groups; ++g)
