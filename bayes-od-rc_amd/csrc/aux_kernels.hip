@@ -1,7 +1,7 @@
 // Stem of the ResNet-50 backbone: 7x7 s2 VALID conv + folded BN + ReLU, then
 // ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID   (src/retina_net/models/feature_extractor.py:17-33,
-// :107-111).  The 3-channel input stays fp32 (no bf16 rounding
-// of pixels); everything after is bf16 storage.
+// :107-111).  The 3-channel input is never rounded to bf16 (fp32 mode:
+// exact fp32 MFMA; bf16 mode: hi + lo split); everything after is bf16 storage.
 #include "kernels.h"
 
 __device__ __forceinline__ uint32_t f32_to_bf16_a(float f) {
@@ -110,13 +110,116 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const float* __restri
     }
 }
 
+// bf16 mode: the same implicit GEMM on v_mfma_f32_16x16x32_bf16.  The image stays exact to 2^-17: every staged
+// pixel value is split x = hi + lo (two bf16) when it is written to LDS, and both halves are multiplied with the
+// bf16-rounded folded weights (like every other layer of this mode, the stem's weights are bf16; fp32 accumulate).
+// K per ky row = 24 slots (21 real + 3 zero-weight) = 3 chunks of 8; an MFMA k-step covers chunks (2s, 2s+1), its
+// four k-blocks being (chunk 2s, hi), (2s+1, hi), (2s, lo), (2s+1, lo): 11 steps x 4 cout fragments = 44 MFMAs per
+// 16 pixels x 64 channels (the fp32 kernel: 168 four-times-slower ones).  Weights live in LDS (one copy per block),
+// so the kernel needs few registers and three blocks per CU keep enough loads in flight to stream the image.
+typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8_t;
+constexpr int SB_ROWE = 408;                    // uint16 per staged row (404 used)
+constexpr int SB_WROW = 184;                    // uint16 per weight row: 22 chunks x 8 + 8 pad (368 B: conflict-free b128 reads)
+
+__global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                             int B, int H, int W, int oh, int ow) {
+    __shared__ __attribute__((aligned(16))) uint16_t wl[64][SB_WROW];
+    __shared__ __attribute__((aligned(16))) uint16_t patch[2][2][7][SB_ROWE];       // [buffer][hi / lo][ky][element]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < 64 * SB_WROW; i += 256) {
+        const int co = i / SB_WROW, kp = i % SB_WROW;
+        const int c = kp >> 3, t = kp & 7, ky = c / 3, j = (c % 3) * 8 + t;
+        wl[co][kp] = (c < 21 && j < 21) ? (uint16_t)f32_to_bf16_a(w[(ky * 21 + j) * 64 + co]) : (uint16_t)0;
+    }
+    float bv[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[f][r] = bias[f * 16 + lq * 4 + r];
+
+    const int segs = (ow + ST_SEG - 1) / ST_SEG;
+    const int ntasks = B * oh * segs;
+    constexpr int ST_PER = (7 * ST_ROWF + 255) / 256;
+    float stage[ST_PER];
+    auto fetch = [&](int task) {
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        const float* src = img + ((size_t)b * H + 2 * oy) * W * 3 + (size_t)seg * ST_SEG * 2 * 3;
+        const int valid = W * 3 - seg * ST_SEG * 2 * 3;
+#pragma unroll
+        for (int q = 0; q < ST_PER; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / ST_ROWF, c = i % ST_ROWF;
+            stage[q] = (i < 7 * ST_ROWF && c < valid) ? src[(size_t)r * W * 3 + c] : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {                               // registers -> LDS as hi / lo bf16
+#pragma unroll
+        for (int q = 0; q < ST_PER; ++q) {
+            const int i = tid + q * 256;
+            if (i >= 7 * ST_ROWF) continue;
+            const int r = i / ST_ROWF, c = i % ST_ROWF;
+            const uint32_t hi = f32_to_bf16_a(stage[q]);
+            const uint32_t lo = f32_to_bf16_a(stage[q] - bf16_to_f32_a(hi));
+            patch[buf][0][r][c] = (uint16_t)hi;
+            patch[buf][1][r][c] = (uint16_t)lo;
+        }
+    };
+    // this lane's B source: plane (lq >> 1), pixel wave*16 + li, chunk parity lq & 1
+    const int role = lq >> 1, k1 = lq & 1;
+    int task = blockIdx.x, buf = 0;
+    if (task < ntasks) { fetch(task); commit(0); }
+    __syncthreads();
+    for (; task < ntasks; task += gridDim.x, buf ^= 1) {
+        const int nxt = task + gridDim.x;
+        if (nxt < ntasks) fetch(nxt);
+        f32x4_t acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const uint16_t* pb = &patch[buf][role][0][(wave * 16 + li) * 6];
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int c = 2 * s + k1;
+            const int cc = c < 21 ? c : 20;                    // chunk 21 has zero weights: any finite data will do
+            const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
+            union { uint32_t u[4]; stem_bf16x8_t v; } bq;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(pb + ky * SB_ROWE + j0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bq.u[t] = src[t];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const stem_bf16x8_t aq = *reinterpret_cast<const stem_bf16x8_t*>(&wl[f * 16 + li][c * 8]);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq.v, acc[f], 0, 0, 0);
+            }
+        }
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        const int ox = seg * ST_SEG + wave * 16 + li;
+        if (ox < ow) {
+            uint16_t* o = out + (((size_t)b * oh + oy) * ow + ox) * 64 + lq * 4;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                uint2 pk;
+                pk.x = f32_to_bf16_a(fmaxf(acc[f][0] + bv[f][0], 0.f)) | (f32_to_bf16_a(fmaxf(acc[f][1] + bv[f][1], 0.f)) << 16);
+                pk.y = f32_to_bf16_a(fmaxf(acc[f][2] + bv[f][2], 0.f)) | (f32_to_bf16_a(fmaxf(acc[f][3] + bv[f][3], 0.f)) << 16);
+                *reinterpret_cast<uint2*>(o + f * 16) = pk;
+            }
+        }
+        if (nxt < ntasks) commit(buf ^ 1);
+        __syncthreads();
+    }
+}
+
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s) {
     const int segs = (ow + ST_SEG - 1) / ST_SEG;
     const int ntasks = B * oh * segs;
     const int grid = ntasks < 1024 ? ntasks : 1024;
+    static const bool f32_stem = getenv("BOD_STEM_F32") && atoi(getenv("BOD_STEM_F32")) == 1;     // A/B aid: the exact-fp32 kernel in bf16 mode
     if (out_f32) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
-    else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
+    else if (f32_stem) hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
+    else hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(ntasks < 768 ? ntasks : 768), dim3(256), 0, s, img, w, bias,
+                            reinterpret_cast<uint16_t*>(out), B, H, W, oh, ow);
     return hipGetLastError();
 }
 

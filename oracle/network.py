@@ -12,8 +12,8 @@ Two numerics modes:
   * ``literal``  -- separate conv / BN / add / ReLU in ``dtype`` (float64 = ground truth,
                     float32 = what the TF reference computes).
   * ``bf16``     -- emulates the HIP path's storage precision exactly: BN folded into the
-                    conv (float64 fold -> float32), folded weights rounded to bf16 (stem kept
-                    fp32), activations rounded to bf16 (RNE) at every point where the device
+                    conv (float64 fold -> float32), folded weights rounded to bf16 (the stem's too;
+                    its fp32 pixels are NOT rounded: the device splits them hi + lo), activations rounded to bf16 (RNE) at every point where the device
                     stores them, fp32 accumulation.  See DESIGN.md "Numerics".
 Weights: dict  keras_layer_name -> {"kernel": HWIO, "bias": [O]}  /  BN name ->
 {"gamma","beta","mean","var"}.
@@ -161,7 +161,7 @@ class _Bf16:
 
     def conv(self, x, name, bn=None, stride=1, padding="valid", relu=False, residual=None,
              store=True):
-        w, b = self.folded(name, bn, round_w=(name != "conv1"))
+        w, b = self.folded(name, bn)
         y = conv2d(x, w, b, stride, padding)
         if residual is not None:
             y = y + residual
