@@ -202,6 +202,9 @@ def main():
         step(i)
     drain()
     fence()
+    # HIP events around every head-tower launch (and every posterior) of the timed steps, recorded on the streams the
+    # kernels run on; read back after the closing fence
+    eng.profile_begin()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -216,14 +219,8 @@ def main():
     value = total_images / elapsed
     kept = [] if fwd_only else eng.num_kept()
 
-    # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM), HIP events on the engine's stream
-    prof_steps = max(1, min(3, args.steps))
-    eng.profile_begin()
-    for i in range(prof_steps):
-        if fwd_only:
-            eng.forward(None, seed=0, first_image_id=lo + i * world * B)
-        else:
-            eng.infer(None, seed=0, first_image_id=lo + i * world * B)
+    # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM): the launches of the timed region itself
+    prof_steps = args.steps
     prof = eng.profile_end()
     launches = max(1, prof["head_conv_launches"])
     # algorithmic FLOPs: de-duplicated head convs = exactly what the 4 launches/step issue
@@ -247,6 +244,8 @@ def main():
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(prof["head_conv_ms"] / launches, 4), "launches_per_step": launches // prof_steps,
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
+    # per-anchor latency of the aggregate / posterior stage (a9-a11): HIP events around the stage's launches of the timed
+    # steps (main stream, between one batch's convolutions and the next)
     post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
 
     out = {"metric": "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency",
