@@ -13,6 +13,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
