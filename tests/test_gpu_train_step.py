@@ -69,13 +69,15 @@ def test_gradients_match_autograd(depth):
     assert np.median(cosines) > 0.99, float(np.median(cosines))
 
 
-@pytest.mark.parametrize("graph", ["0", "1"])
-def test_one_step_update_and_descent(graph, monkeypatch):
+@pytest.mark.parametrize("graph,threads,wgrad_streams", [("0", "1", "2"), ("1", "1", "2"), ("0", "2", "2"), ("0", "1", "1")])
+def test_one_step_update_and_descent(graph, threads, wgrad_streams, monkeypatch):
     """Adam(epsilon 1e-2) with global-norm clipping: the first update matches the oracle's in direction and size for every
     tensor, and repeated steps on a fixed batch lower the loss."""
     from bayes_od_rc_amd.engine import Engine, make_config
     from oracle import torch_train
     monkeypatch.setenv("BOD_TRAIN_GRAPH", graph)      # 1: the step is recorded into a hipGraph on its second run and replayed
+    monkeypatch.setenv("BOD_TRAIN_THREADS", threads)  # 2: the weight-gradient streams get their own enqueue thread
+    monkeypatch.setenv("BOD_TRAIN_WGRAD_STREAMS", wgrad_streams)   # weight-gradient streams (2 = one per half of the dZ^T double buffer)
     hw, batch = (64, 64), 2
     weights, anchors, frames, cls_t, box_t, pos, neg = _problem(hw, batch, seed=1)
     eng = Engine(make_config(hw, batch=batch, mc_samples=1, training=True))
