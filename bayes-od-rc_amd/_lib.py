@@ -96,6 +96,7 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.POINTER(C.c_double), _F, _F, _F]),
     "bod_bench_head_conv": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bod_profile_begin": (C.c_int, [_H]),
+    "bod_profile_select": (C.c_int, [_H, C.c_int32]),
     "bod_profile_end": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -121,7 +121,7 @@ struct bod_context {
     float* iou_scratch = nullptr; int64_t iou_cap = 0;
 
     // profiling
-    bool profiling = false;
+    bool profiling = false; int prof_which = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_head, ev_post;
     double prof_flops = 0;
 
@@ -740,7 +740,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 op.conv.image_base = first_image;
                 op.conv.sample_base = (uint32_t)c.mc_sample_base;
                 op.conv.dyn_rng = train_dyn_rng(h);              // training: device copy of {seed, image id} (graph replay)
-                const bool timed = h->profiling && op.is_head3x3;
+                const bool timed = h->profiling && op.is_head3x3 && (h->prof_which == 0 || (h->prof_which == 1) == (op.conv.xreuse != 0));
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {
                     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
@@ -1725,6 +1725,13 @@ bod_status bod_profile_begin(bod_handle h) {
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     h->ev_head.clear(); h->ev_post.clear(); h->prof_flops = 0; h->profiling = true;
+    return BOD_OK;
+}
+
+bod_status bod_profile_select(bod_handle h, int32_t which) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (which < 0 || which > 2) return h->fail(BOD_ERR_INVALID_ARG, "bod_profile_select: %d", which);
+    h->prof_which = which;
     return BOD_OK;
 }
 

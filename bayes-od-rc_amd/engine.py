@@ -359,7 +359,11 @@ class Engine(object):
         return ms.value, fl.value
 
     # ------------------------------------------------------------------ measurement
-    def profile_begin(self):
+    def profile_begin(self, which=None):
+        """which: None keeps the current selection; 0 = every head 3x3 launch, 1 = the row-reuse tower kernel's launches
+        only (one kernel symbol), 2 = the others (the fan-out launch of the first tower layer)."""
+        if which is not None:
+            self._chk(self.lib.bod_profile_select(self.h, int(which)))
         self._chk(self.lib.bod_profile_begin(self.h))
 
     def profile_end(self):

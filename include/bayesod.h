@@ -294,6 +294,10 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
 
 /* Measurement hooks (bench.py): HIP-event timing of the dominant kernel on the handle's stream. */
 bod_status bod_profile_begin(bod_handle h);
+/* Which head 3x3 launches the hook times: 0 = all of them (default), 1 = only the launches of the row-reuse tower kernel
+ * (tower layers 1..3 in bf16 mode: ONE kernel symbol, the one a rocprofv3 --kernel-trace summary lists first), 2 = the
+ * others (the N-way fan-out launch of layer 0).  Stays in force until changed. */
+bod_status bod_profile_select(bod_handle h, int32_t which);
 /* total ms in head 3x3 conv launches since begin, number of launches, FLOPs (2*MACs) issued */
 bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
                            double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
