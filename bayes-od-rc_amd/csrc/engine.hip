@@ -598,6 +598,7 @@ bod_status build_plan(bod_context* h) {
     for (int layer = 0; layer < 4; ++layer) {
         Op op; op.kind = Op::CONV; op.is_head3x3 = true;
         int g = 0; PackedConv pc0{};
+        double fused_flops = 0;
         for (int hd = 0; hd < nheads; ++hd) {
             if (layer >= kHeadConvs[hd]) continue;
             PackedConv pc;
@@ -616,7 +617,7 @@ bod_status build_plan(bod_context* h) {
                 if (po.cin != 256 || po.cout != out_ch[hd] || po.taps != 1)
                     return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], po.cin, po.cout);
                 cg.w2 = po.w; cg.bias2 = po.bias; cg.out2 = h->raw[hd]; cg.cout2 = po.cout; cg.out2_cstride = out_ch[hd];
-                op.flops += 0;      // head-conv roofline accounting stays the 3x3 FLOPs only
+                fused_flops += 2.0 * ((double)B * N * h->P) * 256.0 * out_ch[hd];      // the 1x1 output conv runs inside this launch
             }
             op.conv.g[g] = cg;
             if (g == 0) pc0 = pc;
@@ -635,7 +636,7 @@ bod_status build_plan(bod_context* h) {
             a.xreuse = act_elems < ((size_t)1 << 32) ? 2 : 1;       // 2: 32-bit activation offsets are safe
         }
         op.conv = a;
-        op.flops = 2.0 * M * 256.0 * 2304.0 * g;
+        op.flops = 2.0 * M * 256.0 * 2304.0 * g + fused_flops;
         op.name = "head_tower_layer_" + std::to_string(layer);
         op.same_geom = N == 1;            // pyramid [B][Ppad] and head planes [B*N][Ppad] coincide at N = 1
         h->ops.push_back(op);

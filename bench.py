@@ -236,7 +236,14 @@ def main():
     prof = eng.profile_end()
     tower_only = prof["head_conv_launches"] > 0
     if tower_only:
+        # SURVEY.md 8d, de-duplicated heads: N * (8 * 6.436 + 0.553) GFLOP per 512x512 image for these launches -- the eight
+        # 3x3 convs of tower layers 1..3 and the three 1x1 output convs fused into their epilogues
+        # (the plan fuses them whenever the launch uses the full-cout tile: from about 8 frames per step on; below that
+        # they are separate small launches and are not counted here)
+        out_flops = 2.0 * eng.P * 256 * 9 * (8 + 4 + 10)
         algo_flops = n * 8 * conv_flops * B * prof_steps
+        if abs(prof["head_conv_flops"] - algo_flops) / algo_flops > 1e-6:
+            algo_flops += n * out_flops * B * prof_steps
         kernel_name = "conv_igemm_kernel<256,256,2,4,0,true> (head towers, 3x3 256->256, layers 1-3)"
     else:                                # fp32 mode: no row-reuse kernel in the plan -- all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))
