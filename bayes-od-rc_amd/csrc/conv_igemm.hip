@@ -246,7 +246,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         s_rng[i] = *(reinterpret_cast<const int2*>(&a.rows[mm]) + 2);
         s_off2[i] = a.rows[mm].pad0;
     }
-    for (int i = tid; i < BC; i += THREADS) s_bias[i] = G.bias[bc0 + i];
+    // bias pre-multiplied by the dropout keep scale: the bf16 epilogue computes max(fma(acc, scale, bias*scale), 0),
+    // i.e. relu(acc + bias) * scale with one instruction less per element (scale = 1 without dropout: acc + bias exactly)
+    const float epi_scale = (a.flags & CONV_DROPOUT) && !(a.flags & CONV_OUT_F32) ? a.drop_scale : 1.0f;
+    for (int i = tid; i < BC; i += THREADS) s_bias[i] = G.bias[bc0 + i] * epi_scale;
 
     // K order: channel chunk OUTER, taps inner -- the 9 taps of one 64-channel chunk re-read (shifted)
     // the same activation rows in 9 consecutive K-tiles, so the re-reads hit L1/L2 instead of MALL/HBM
@@ -595,20 +598,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
                 const int co = bc0 + col;
                 const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
-                float v[4] = {acc[i][j][g4 * 4 + 0] + bv.x, acc[i][j][g4 * 4 + 1] + bv.y,
-                              acc[i][j][g4 * 4 + 2] + bv.z, acc[i][j][g4 * 4 + 3] + bv.w};
+                float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
+                              __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
                 if (G.res) {
                     const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)res_off[j] * a.res_cstride + co);
-                    v[0] += bf16_to_f32(r.x & 0xFFFFu); v[1] += bf16_to_f32(r.x >> 16);
-                    v[2] += bf16_to_f32(r.y & 0xFFFFu); v[3] += bf16_to_f32(r.y >> 16);
+                    v[0] += bf16_to_f32(r.x & 0xFFFFu) * epi_scale; v[1] += bf16_to_f32(r.x >> 16) * epi_scale;
+                    v[2] += bf16_to_f32(r.y & 0xFFFFu) * epi_scale; v[3] += bf16_to_f32(r.y >> 16) * epi_scale;
                 }
                 if (relu) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                }
-                if (drop) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] *= a.drop_scale;
                 }
                 pk[i][j][g4].x = pack_bf16x2(v[0], v[1]);
                 pk[i][j][g4].y = pack_bf16x2(v[2], v[3]);
