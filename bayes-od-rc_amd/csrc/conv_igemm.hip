@@ -49,6 +49,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
 #endif
 }
+// ReLU of two packed bf16 as ONE v_pk_max_i16: a negative bf16 is a negative int16 (sign bit), max with 0 clears it
+// (-0 becomes +0), positive values are unchanged.  round(max(x, 0)) == max(round(x), 0) for round-to-nearest.
+__device__ __forceinline__ uint32_t relu_bf16x2_pk(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
+    return r;
+#else
+    return ((w & 0x8000u) ? 0u : (w & 0xFFFFu)) | ((w & 0x80000000u) ? 0u : (w & 0xFFFF0000u));
+#endif
+}
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
     const uint32_t lo = (w & 0x8000u) ? 0u : (w & 0xFFFFu);
     const uint32_t hi = (w & 0x80000000u) ? 0u : (w & 0xFFFF0000u);
@@ -605,12 +616,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     v[0] += bf16_to_f32(r.x & 0xFFFFu) * epi_scale; v[1] += bf16_to_f32(r.x >> 16) * epi_scale;
                     v[2] += bf16_to_f32(r.y & 0xFFFFu) * epi_scale; v[3] += bf16_to_f32(r.y >> 16) * epi_scale;
                 }
-                if (relu) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                }
                 pk[i][j][g4].x = pack_bf16x2(v[0], v[1]);
                 pk[i][j][g4].y = pack_bf16x2(v[2], v[3]);
+                if (relu) { pk[i][j][g4].x = relu_bf16x2_pk(pk[i][j][g4].x); pk[i][j][g4].y = relu_bf16x2_pk(pk[i][j][g4].y); }
             }
         }
     }
