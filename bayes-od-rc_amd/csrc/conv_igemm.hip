@@ -60,6 +60,21 @@ __device__ __forceinline__ uint32_t relu_bf16x2_pk(uint32_t w) {
     return ((w & 0x8000u) ? 0u : (w & 0xFFFFu)) | ((w & 0x80000000u) ? 0u : (w & 0xFFFF0000u));
 #endif
 }
+// Dropout keep mask of two 16-bit uniform words at once: 0xFFFF where word >= threshold, else 0 (threshold >= 1).
+// saturating (word - (threshold-1)) is non-zero exactly when the word is kept; min(.,1) * 0xFFFF spreads it.
+__device__ __forceinline__ uint32_t keep_mask_u16x2(uint32_t w, uint32_t thr_m1_x2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d, m;
+    const uint32_t one = 0x00010001u, ones = 0xFFFFFFFFu;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(w), "v"(thr_m1_x2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m) : "v"(d), "v"(ones));
+    return m;
+#else
+    const uint32_t t = (thr_m1_x2 & 0xFFFFu) + 1u;
+    return ((w & 0xFFFFu) >= t ? 0x0000FFFFu : 0u) | ((w >> 16) >= t ? 0xFFFF0000u : 0u);
+#endif
+}
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t w) {
     const uint32_t lo = (w & 0x8000u) ? 0u : (w & 0xFFFFu);
     const uint32_t hi = (w & 0x80000000u) ? 0u : (w & 0xFFFF0000u);
@@ -653,6 +668,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     uint32_t rng_seed_lo = a.seed_lo, rng_seed_hi = a.seed_hi, rng_image_base = a.image_base;
     if (a.dyn_rng) { rng_seed_lo = a.dyn_rng[0]; rng_seed_hi = a.dyn_rng[1]; rng_image_base = a.dyn_rng[2]; }      // uniform: scalar loads
     const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
+    const uint32_t thr_m1 = a.drop_threshold > 0 ? a.drop_threshold - 1u : 0u;        // (dropout layers have threshold >= 1)
+    const uint32_t thr_m1_x2 = thr_m1 | (thr_m1 << 16);
     if (fan > 1 && !fuse && !G.out_relu && ABL == 0) {
         // ---- N-way dropout fan-out (first tower layer: one convolution, N masked copies).  The unmasked tile goes
         // through LDS ONCE; each thread then keeps (pixel, 16-channel group) items in registers and, per sample, draws
@@ -672,8 +689,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
         __syncthreads();
         constexpr int GPR = BC / 16;                                   // 16-channel groups per pixel row
-        const uint32_t thr = a.drop_threshold;
-        auto keep2 = [thr](uint32_t w) { return ((w & 0xFFFFu) >= thr ? 0x0000FFFFu : 0u) | ((w >> 16) >= thr ? 0xFFFF0000u : 0u); };
+        auto keep2 = [thr_m1_x2](uint32_t w) { return keep_mask_u16x2(w, thr_m1_x2); };
 #pragma unroll 1
         for (int q = tid; q < BP * GPR; q += THREADS) {
             const int pixl = q / GPR, gq = q % GPR;
@@ -724,8 +740,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                                     sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
                         }
                         const uint32_t w0 = (g4 & 1) ? rr.z : rr.x, w1 = (g4 & 1) ? rr.w : rr.y;
-                        o.x &= ((w0 & 0xFFFFu) >= a.drop_threshold ? 0x0000FFFFu : 0u) | ((w0 >> 16) >= a.drop_threshold ? 0xFFFF0000u : 0u);
-                        o.y &= ((w1 & 0xFFFFu) >= a.drop_threshold ? 0x0000FFFFu : 0u) | ((w1 >> 16) >= a.drop_threshold ? 0xFFFF0000u : 0u);
+                        o.x &= keep_mask_u16x2(w0, thr_m1_x2);
+                        o.y &= keep_mask_u16x2(w1, thr_m1_x2);
                         if (g4 & 1) __builtin_amdgcn_sched_barrier(0);   // keep the Philox chains from interleaving (registers)
                     }
                     *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = o;
@@ -946,7 +962,11 @@ bool conv_igemm_uses_full_cout_tile(const ConvArgs& a) {
     return big && a.cout_pad == 256;
 }
 
-hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a_local = a_in;
+    // a threshold of 0 keeps every element (rate < 2^-16): the packed keep-mask needs threshold >= 1, so run without dropout
+    if ((a_local.flags & CONV_DROPOUT) && a_local.drop_threshold == 0) a_local.flags &= ~CONV_DROPOUT;
+    const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
