@@ -16,6 +16,10 @@ of the reference is executed:
   * ``predictions_to_bdd_format`` / ``predictions_to_kitti_format`` / ``strip_checkpoint_id``
                                  src/retina_net/experiments/validation_utils.py:96-107,183-272
 
+  * PDQ: ``PBoxDetInst`` / ``BBoxDetInst`` heatmaps, ``gen_single_heatmap``, ``_calc_qual_img``, the ``PDQ`` totals
+                                 src/retina_net/offline_eval/pdq_data_holders.py:81-268, pdq.py:11-452
+                                 (``make_golden.py pdq`` writes only ``pdq.npz``)
+
 Outputs (data only, no reference source text): ``tests/golden/*.npz`` + ``writers.json``.
 """
 import json
@@ -73,11 +77,72 @@ def _iou_matrix_ref_convention(vuvu):
     return (inter / (union + np.float32(0.00001))).astype(np.float32)
 
 
+def golden_pdq():
+    """Inputs and the reference's outputs for the PDQ metric (small 40x56 images so the file stays small)."""
+    from src.retina_net.offline_eval import pdq as ref_pdq, pdq_data_holders as ref_dh
+    rng = np.random.default_rng(2024)
+    shape = (40, 56)
+    out = {"img_shape": np.array(shape)}
+    # ---- Gaussian corner heatmaps: interior, touching the top / left edges (outside-mass correction), near-singular
+    means = np.array([[20.3, 30.7], [1.2, 25.0], [18.0, 0.6], [0.4, 0.9], [35.5, 50.2], [12.0, 12.0]])
+    covs = np.array([[[4.0, 0.8], [0.8, 6.0]], [[3.0, -0.5], [-0.5, 2.0]], [[5.0, 1.0], [1.0, 1.5]],
+                     [[2.0, 0.3], [0.3, 2.5]], [[9.0, -2.0], [-2.0, 7.0]], [[1e-6, 0.0], [0.0, 1e-6]]])
+    out["corner_means"] = means
+    out["corner_covs"] = covs
+    out["corner_heatmaps"] = np.stack([ref_dh.gen_single_heatmap(shape, list(m), c) for m, c in zip(means, covs)])
+    out["corner_rois"] = np.array([list(ref_dh.find_roi(shape, list(m), c)) for m, c in zip(means, covs)])
+    # ---- probabilistic boxes and a plain fractional box
+    boxes = np.array([[10, 8, 30, 25], [2, 1, 20, 12], [35, 20, 54, 38], [5, 5, 50, 35]])
+    bcovs = np.stack([np.stack([_random_spd(rng, 1, 1.0)[0][:2, :2], _random_spd(rng, 1, 2.0)[0][:2, :2]]) for _ in boxes]).astype(np.float64)
+    probs = rng.dirichlet(np.ones(5) * 0.5, size=len(boxes))
+    out["pbox_boxes"], out["pbox_covs"], out["pbox_probs"] = boxes, bcovs, probs
+    out["pbox_heatmaps"] = np.stack([ref_dh.PBoxDetInst(p, b, [c[0], c[1]]).calc_heatmap(shape) for p, b, c in zip(probs, boxes, bcovs)])
+    fbox = np.array([10.3, 7.6, 30.2, 21.9])
+    out["bbox_box"] = fbox
+    out["bbox_heatmap"] = ref_dh.BBoxDetInst(probs[0], fbox, 0.8).calc_heatmap(shape)
+
+    # ---- whole images: lists of ground-truth boxes / detections -> _calc_qual_img sums, then the PDQ totals
+    def image(gt_boxes, gt_labels, det_idx):
+        gts = []
+        for b, l in zip(gt_boxes, gt_labels):
+            m = np.zeros(shape, dtype=bool)
+            m[b[1]:b[3], b[0]:b[2]] = True
+            gts.append(ref_dh.GroundTruthInstance(m, int(l), 0, 0, bounding_box=np.array(b)))
+        dets = [ref_dh.PBoxDetInst(probs[i], boxes[i], [bcovs[i][0], bcovs[i][1]]) for i in det_idx]
+        return gts, dets
+    images = [
+        ([[10, 8, 30, 25], [36, 21, 53, 37], [1, 30, 9, 38]], [int(np.argmax(probs[0])), 2, 1], [0, 2, 1, 3]),   # last gt too small
+        ([[4, 4, 49, 34], [2, 1, 19, 12]], [int(np.argmax(probs[3])), int(np.argmax(probs[1]))], [3]),
+        ([], [], [0, 1]),
+        ([[10, 8, 30, 25], [0, 0, 5, 5]], [0, 1], []),
+        ([[20, 10, 40, 30]], [4], [1]),                                                                        # disjoint: FP + FN
+    ]
+    ev = ref_pdq.PDQ()
+    res = []
+    for k, (gb, gl, di) in enumerate(images):
+        gts, dets = image(gb, gl, di)
+        r = ref_pdq._calc_qual_img(gts, dets)
+        res.append([float(r['overall']), float(r['spatial']), float(r['label']), r['TP'], r['FP'], r['FN']])
+        ev.add_img_eval(gts, dets)
+        out["img%d_gt_boxes" % k] = np.array(gb, dtype=np.int64).reshape(-1, 4)
+        out["img%d_gt_labels" % k] = np.array(gl, dtype=np.int64)
+        out["img%d_det_idx" % k] = np.array(di, dtype=np.int64)
+    out["n_images"] = np.array(len(images))
+    out["image_results"] = np.array(res, dtype=np.float64)
+    out["pdq_totals"] = np.array([ev.get_pdq_score(), ev.get_avg_spatial_score(), ev.get_avg_label_score(),
+                                  ev.get_avg_overall_quality_score()] + list(ev.get_assignment_counts()), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "pdq.npz"), **out)
+    print("pdq.npz written")
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not found at %s" % REF)
     _install_tf_stub()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "pdq":
+        golden_pdq()
+        return
     from src.retina_net.experiments import inference_utils as ref_iu
     from src.retina_net.anchor_generator import box_utils as ref_bu
     from src.core import evaluation_utils_2d as ref_ev
@@ -211,6 +276,7 @@ def main():
             "ckpt_ids": {p: ref_vu.strip_checkpoint_id(p)
                          for p in ("a/b/ckpt-101", "x/retinanet_bdd_covar-7", "ckpt-000012")},
         }, fp, indent=1)
+    golden_pdq()
     print("golden vectors written to", OUT)
 
 
