@@ -232,6 +232,7 @@ def main():
                 eng.infer(None, seed=0, first_image_id=lo + i * world * B)
 
     conv_flops = 2.0 * eng.P * 256 * 2304          # one 3x3 256->256 head conv over one image's pyramid, one sample
+    out_flops = 2.0 * eng.P * 256 * 9 * (8 + 4 + 10)     # the three 1x1 output convs (cls 9x8, box 9x4, cov 9x10 channels)
     prof_steps = args.steps
     prof = eng.profile_end()
     tower_only = prof["head_conv_launches"] > 0
@@ -240,18 +241,17 @@ def main():
         # 3x3 convs of tower layers 1..3 and the three 1x1 output convs fused into their epilogues
         # (the plan fuses them whenever the launch uses the full-cout tile: from about 8 frames per step on; below that
         # they are separate small launches and are not counted here)
-        out_flops = 2.0 * eng.P * 256 * 9 * (8 + 4 + 10)
         algo_flops = n * 8 * conv_flops * B * prof_steps
-        if abs(prof["head_conv_flops"] - algo_flops) / algo_flops > 1e-6:
-            algo_flops += n * out_flops * B * prof_steps
         kernel_name = "conv_igemm_kernel<256,256,2,4,0,true> (head towers, 3x3 256->256, layers 1-3)"
-    else:                                # fp32 mode: no row-reuse kernel in the plan -- all head 3x3 launches, three extra steps
+    else:                                # no row-reuse kernel in the plan (fp32 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))
         eng.profile_begin(which=0)
         more_steps(prof_steps)
         prof = eng.profile_end()
         algo_flops = head_flops_per_image(eng.P, n) * B * prof_steps
-        kernel_name = "conv_igemm_f32_kernel (head towers, 3x3 256->256)"
+        kernel_name = ("conv_igemm_f32_kernel" if args.precision == "fp32" else "conv_igemm_kernel") + " (head towers, 3x3 256->256)"
+    if abs(prof["head_conv_flops"] - algo_flops) / algo_flops > 1e-6:       # the plan fused the 1x1 output convs into these launches
+        algo_flops += n * out_flops * B * prof_steps
     launches = max(1, prof["head_conv_launches"])
     # algorithmic FLOPs: the de-duplicated head convs these launches issue
     assert abs(algo_flops - prof["head_conv_flops"]) / algo_flops < 1e-6
