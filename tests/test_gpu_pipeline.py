@@ -399,3 +399,45 @@ def test_model_without_covariance_head():
         scale = float(np.abs(ref["covs"]).max())
         assert rel_err(got["covs"], ref["covs"], scale) < 5e-3
     assert dets[0][0].shape[0] > 0 and np.isfinite(dets[0][2]).all()
+
+
+@pytest.mark.parametrize("hw,n,batch", [((512, 512), 10, 16), ((384, 1248), 30, 4)])
+def test_full_size_properties(hw, n, batch):
+    """BASELINE.json's metric configuration (512x512, N=10; 16 frames per step here: the row-reuse tower kernel, fused
+    1x1 outputs and the 256x256 fan-out tile are all in play) and its KITTI configuration (384x1248, N=30), where the
+    oracle is too slow: size-independent
+    properties instead -- two runs are bit-identical, the pipelined path equals the synchronous one, every fused
+    covariance is symmetric positive definite, class scores are distributions, counts are positive, boxes finite,
+    and the MC samples differ (dropout is on) while the first tower layer is shared."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+    eng.load_weights(synthetic.make_weights(cls_fg_bias=-3.2))
+    eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3)))
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=11)
+    eng.infer(frames, seed=9, first_image_id=100)
+    first = {k: v.copy() for k, v in eng.get_detections_batch().items()}
+    cls = eng.get_raw()[0]
+    assert np.isfinite(cls).all() and not np.array_equal(cls[0, 0], cls[0, 1])          # samples differ
+    eng.infer(frames, seed=9, first_image_id=100)
+    second = eng.get_detections_batch()
+    slot = eng.infer_async(frames, seed=9, first_image_id=100)
+    piped = eng.collect(slot)
+    kept = eng.num_kept()
+    assert (np.asarray(kept) > 100).all() and (np.asarray(kept) < 5000).all()             # the calibrated filter keeps ~1 000 anchors
+    for other in (second, piped):
+        assert np.array_equal(first["num"], other["num"])
+    for b in range(batch):
+        k = int(first["num"][b])
+        assert 1 <= k <= 100
+        for key in ("scores", "means", "covs", "counts"):
+            assert np.array_equal(first[key][b, :k], second[key][b, :k]), (b, key)
+            assert np.array_equal(first[key][b, :k], piped[key][b, :k]), (b, key)
+        covs = first["covs"][b, :k].astype(np.float64)
+        assert np.abs(covs - np.transpose(covs, (0, 2, 1))).max() <= 1e-6 * np.abs(covs).max()
+        assert (np.linalg.eigvalsh(0.5 * (covs + np.transpose(covs, (0, 2, 1)))) > 0).all()
+        assert np.allclose(first["scores"][b, :k].sum(axis=1), 1.0, atol=1e-5)
+        assert (first["counts"][b, :k] > 0).all() and np.isfinite(first["means"][b, :k]).all()
+        assert (first["means"][b, :k, 2:] > 0).all()                                      # heights and widths
+    eng.close()
