@@ -190,3 +190,23 @@ def test_data_parallel_two_ranks_on_one_gpu():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "DP_TRAIN_OK" in out.stdout
+
+
+@pytest.mark.parametrize("hw,batch,depth", [((512, 512), 3, 50), ((512, 512), 3, 101)])
+def test_full_size_step_descends(hw, batch, depth):
+    """The yaml's minibatch at the BASELINE geometry (config 5: depth 101), where autograd on the host is too slow:
+    the losses and the gradient norm stay finite, repeated steps on one batch lower the loss, and the inference API
+    of the same handle runs on the updated weights."""
+    from bayes_od_rc_amd.engine import Engine, make_config
+    weights, anchors, frames, cls_t, box_t, pos, neg = _problem(hw, batch, seed=2, depth=depth)
+    eng = Engine(make_config(hw, batch=batch, mc_samples=1, training=True, backbone_depth=depth))
+    eng.load_weights(weights)
+    eng.set_anchors(anchors)
+    eng.upload_images(frames)
+    out = [eng.train_step(None, cls_t, box_t, pos, neg, seed=4, first_image_id=0, learning_rate=1e-3) for _ in range(10)]
+    for o in out:
+        assert all(np.isfinite(v) for v in o.values()), o
+    assert out[-1]["total_loss"] < 0.9 * out[0]["total_loss"], [o["total_loss"] for o in out]
+    eng.forward(frames, seed=4, first_image_id=0)
+    assert np.isfinite(eng.get_raw()[0]).all()
+    eng.close()
