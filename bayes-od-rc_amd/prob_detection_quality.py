@@ -315,22 +315,31 @@ _VUHW_TO_CORNERS = np.array([[0, 1, 0, -0.5], [1, 0, -0.5, 0], [0, 1, 0, 0.5], [
 
 
 def frame_instances(gt_classes_onehot, gt_boxes_xyxy, pred_means_vuhw, pred_covs, pred_cat_params, img_shape,
-                    score_threshold=0.5445, cov_scale=70.0):
-    """One frame of the compute_pdq drivers (offline_eval/bdd/compute_pdq.py:83-140, kitti/compute_pdq.py likewise):
-    ground-truth boxes become box-shaped masks, predictions above ``score_threshold`` become PBoxDetInst with the
-    corner covariances T cov T^T * 70 (the x70 of the drivers comes on top of the one bayes_od_clustering applied).
-    Returns (gt_instances, det_instances)."""
+                    score_threshold=0.5445, cov_scale=70.0, class_columns=None, gt_boxes_vuvu=False, clip_max=None):
+    """One frame of the compute_pdq drivers: ground-truth boxes become box-shaped masks, predictions above
+    ``score_threshold`` become PBoxDetInst with the corner covariances T cov T^T * 70 (the x70 of the drivers comes on
+    top of the one bayes_od_clustering applied).  Defaults = the BDD driver (offline_eval/bdd/compute_pdq.py:83-140);
+    the KITTI driver (kitti/compute_pdq.py:66-118) is ``img_shape=(375, 1300), score_threshold=0.5,
+    class_columns=(0, 3)`` (car and person out of the BDD-trained class vector), ``gt_boxes_vuvu=True`` (its label
+    reader returns v1 u1 v2 u2) and ``clip_max=1300``.  Returns (gt_instances, det_instances)."""
     from .box_utils import vuhw_to_vuvu_np
     gts = []
     for onehot, box in zip(gt_classes_onehot, gt_boxes_xyxy):
         idx = np.asarray(box).astype(np.int32)
+        if gt_boxes_vuvu:
+            idx = np.array([idx[1], idx[0], idx[3], idx[2]])
+        if clip_max is not None:
+            idx = np.clip(idx, 0.0, clip_max).astype(np.int32)
         mask = np.zeros(img_shape, dtype=bool)
         mask[idx[1]:idx[3], idx[0]:idx[2]] = True
-        gts.append(GroundTruthInstance(mask, int(np.where(np.asarray(onehot) == 1)[0].item(0)), 0, 0, bounding_box=idx))
+        label = int(np.argmax(onehot)) if gt_boxes_vuvu else int(np.where(np.asarray(onehot) == 1)[0].item(0))
+        gts.append(GroundTruthInstance(mask, label, 0, 0, bounding_box=idx))
     dets = []
     if np.asarray(pred_covs).size:
-        covs = np.matmul(np.matmul(_VUHW_TO_CORNERS, np.asarray(pred_covs, np.float64)), _VUHW_TO_CORNERS.T) * cov_scale
+        covs = np.matmul(np.matmul(_VUHW_TO_CORNERS, np.asarray(pred_covs, np.float64) * cov_scale), _VUHW_TO_CORNERS.T)
         boxes = vuhw_to_vuvu_np(np.asarray(pred_means_vuhw))
+        if class_columns is not None:
+            pred_cat_params = np.stack([np.asarray(pred_cat_params)[:, c] for c in class_columns], axis=1)
         for cat, b, cv in zip(pred_cat_params, boxes, covs):
             if np.max(cat) >= score_threshold:
                 dets.append(PBoxDetInst(cat, np.array([b[1], b[0], b[3], b[2]]).astype(np.int32), [cv[0:2, 0:2], cv[2:4, 2:4]]))

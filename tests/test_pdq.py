@@ -85,3 +85,19 @@ def test_frame_instances_from_prediction_files():
     np.testing.assert_allclose(dets[0].covs[1][1, 1], (0.02 + 0.04 / 4) * 70, rtol=1e-12)
     out = pdq.evaluate([(gts, dets)])
     assert 0.0 <= out["score"] <= 100.0 and out["TP"] + out["FP"] + out["FN"] >= 1
+
+
+def test_kitti_driver_options():
+    """kitti/compute_pdq.py:66-118: v-u ordered label boxes, car / person columns of the BDD-trained class vector,
+    0.5 threshold, clipping to the 1300-wide canvas."""
+    means = np.array([[16.0, 20.0, 16.0, 20.0], [30.0, 40.0, 8.0, 10.0]])
+    covs = np.stack([np.diag([0.02, 0.03, 0.04, 0.05]), np.diag([0.01, 0.01, 0.01, 0.01])])
+    cats = np.array([[0.52, 0.2, 0.1, 0.1, 0.02, 0.02, 0.02, 0.02], [0.1, 0.6, 0.1, 0.1, 0.025, 0.025, 0.025, 0.025]])
+    gts, dets = pdq.frame_instances(np.array([[0, 1, 0, 0]]), np.array([[8.0, 10.0, 24.0, 30.0]]), means, covs, cats, SHAPE,
+                                    score_threshold=0.5, class_columns=(0, 3), gt_boxes_vuvu=True, clip_max=1300)
+    assert list(gts[0].bounding_box) == [10, 8, 30, 24] and gts[0].class_label == 1
+    assert len(dets) == 1 and list(dets[0].class_list) == [0.52, 0.1]                   # the truck-dominant detection is dropped
+    bdd_gts, bdd_dets = pdq.frame_instances(np.array([[0, 1, 0]]), np.array([[10.0, 8.0, 30.0, 24.0]]), means, covs, cats[:, :3], SHAPE,
+                                            score_threshold=0.5)
+    np.testing.assert_array_equal(gts[0].segmentation_mask, bdd_gts[0].segmentation_mask)
+    np.testing.assert_allclose(dets[0].covs[0], bdd_dets[0].covs[0], rtol=1e-12)
