@@ -157,14 +157,17 @@ def main():
         print("calibrated cls foreground bias:", synthetic.calibrate_fg_bias(cls[0], args.fg_bias))
         return
 
-    views = [bdist.torch_views(eng, s) for s in (0, 1)] if world > 1 else None
+    # BOD_BENCH_FORCE_GATHER=1: run the N>1 record path (device-side pack, gather, host copy on rank 0) at world size 1 too,
+    # to measure what it costs per step on one GPU
+    force_gather = os.environ.get("BOD_BENCH_FORCE_GATHER") == "1"
+    views = [bdist.torch_views(eng, s) for s in (0, 1)] if (world > 1 or force_gather) else None
     host_out = [None, None]
     gathered = None
 
     def collect(slot):
         """Detections of the batch in `slot` -> host (rank 0 receives every rank's records)."""
         nonlocal gathered
-        if world > 1:
+        if world > 1 or force_gather:
             eng.wait_slot(slot)
             v = views[slot]
             rec = bdist.pack_records(v["num"], v["scores"], v["means"], v["covs"], v["counts"])
