@@ -322,7 +322,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // wait is the first fragment set after each block barrier (covered by issuing the LDS-DMA there).
         static_assert(BC == 256 && BP == 256 && WC == 2 && WP == 4, "written for the 256x256 8-wave tile");
         constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
-        const char* in_base = reinterpret_cast<const char*>(G.in) + G.in_coff * 2;
+        // 32-bit offsets are taken against the tile's FIRST extended row (the smallest pixel index of the tile: the
+        // host builds the list in increasing order and pads it with that row), so the activation buffer may be of any size
+        const int ext_first = __builtin_amdgcn_readfirstlane(a.ext[(size_t)bx * XR_EXT_ROWS].x);
+        const char* in_base = reinterpret_cast<const char*>(G.in) + ((size_t)ext_first * a.in_cstride + G.in_coff) * 2;
         const char* wbase = wsrc[0];
         const int wrs = RPI * wrow * 2;                                     // bytes between the rows of two weight pieces
         uint32_t xo[NXE];
@@ -330,7 +333,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
         for (int i = 0; i < NXE; ++i) {
             const int2 e = a.ext[(size_t)bx * XR_EXT_ROWS + i * (THREADS / 8) + (tid >> 3)];
-            xo[i] = ((uint32_t)e.x * (uint32_t)a.in_cstride + ldchunk * 8) * 2u;
+            xo[i] = ((uint32_t)(e.x - ext_first) * (uint32_t)a.in_cstride + ldchunk * 8) * 2u;
             xp[i] = e.y * a.in_cstride * 2;
         }
         int xrow[FP];

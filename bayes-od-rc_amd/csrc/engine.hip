@@ -570,7 +570,11 @@ bod_status build_plan(bod_context* h) {
                 nx += take + 2; pix += take; r += take;
             }
             while (tiled.size() < tile0 + 256) tiled.push_back(invalid);
-            while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(int2{0, 0});      // pixel 0 is a zero border pixel
+            // pad with the tile's first row: never read by a valid pixel, and it keeps the first entry the smallest of
+            // the tile (the kernel takes its 32-bit activation offsets against it)
+            while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(ext[ext0]);
+            for (size_t q = ext0; q < ext0 + XR_EXT_ROWS; ++q)
+                if (ext[q].x < ext[ext0].x) return h->fail(BOD_ERR_INVALID_ARG, "row-reuse tiling: extended rows out of order");
         }
         m2x = (int)tiled.size();
         BODCHK(h->dalloc(&d2x, tiled.size(), false));
@@ -633,7 +637,7 @@ bod_status build_plan(bod_context* h) {
         a.drop_threshold = thr; a.drop_scale = dscale;
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;
-            a.xreuse = act_elems < ((size_t)1 << 32) ? 2 : 1;       // 2: 32-bit activation offsets are safe
+            a.xreuse = 2;       // 32-bit activation offsets against the tile's first extended row: any buffer size
         }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g + fused_flops;

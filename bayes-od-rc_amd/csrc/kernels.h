@@ -69,7 +69,8 @@ struct ConvArgs {
     // pixels plus one on either side, so the three kx taps read the SAME staged rows at offsets 0/1/2
     // (RowEnt.pad1 = a pixel's extended-row index) and activations are staged once per (chunk, ky).
     const int2* ext;
-    int32_t xreuse;        // 0 off; 1 on; 2 on and the group's activation buffer is < 4 GiB (32-bit byte offsets)
+    int32_t xreuse;        // 0 off; 2 on: compact-state loop, 32-bit byte offsets against the tile's first extended row
+                           // (ext[tile * 320] must be the tile's smallest pixel index); 1: first-generation loop, 64-bit pointers
     // Split-K (small-M layers: P6, the stage-4/5 layers at batch 1): ksplit > 1 splits the input-channel chunks over
     // ksplit workgroups per tile (blockIdx.z = group * ksplit + split); every split writes its raw fp32 accumulators to
     // partial[(z * M + m) * cout_pad + co] and launch_conv_igemm runs the reduce kernel (sum, bias, residual, ReLU,

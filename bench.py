@@ -97,8 +97,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step (128: the largest N=10 batch whose tower "
-                    "activations stay below 4 GiB, i.e. on the 32-bit-offset loop; +2 %% over 64)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256: ~60 GB of the 288 GB; the tower "
+                    "launches then hold 218 tiles per CU and the step's fixed costs are amortised: +4 %% over 64)")
     ap.add_argument("--mc", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)

@@ -6,13 +6,13 @@ d = json.loads(sys.stdin.readline())
 r = d['roofline']
 print('frames/s %.1f  ms/step %.3f  head TF/s %.1f (frac %.3f, share %.2f)  M %s  post ns/anchor %s' % (d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['share_of_step'], d['config'].get('kept_anchors_M'), d['config'].get('per_anchor_covariance_latency_ns')))"; }
 run
+run --batch 128
 run --batch 64
 run --batch 32
 run --batch 16
 run --batch 8
 run --batch 1 --steps 100
 run --mc 1
-run --mc 30 --batch 40 --steps 15
 run --mc 30 --batch 64 --steps 15
 run --height 384 --width 1248 --mc 30 --batch 16 --steps 10
 run --height 384 --width 1248 --mc 10 --batch 64 --steps 20
