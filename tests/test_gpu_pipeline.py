@@ -441,3 +441,54 @@ def test_full_size_properties(hw, n, batch):
         assert (first["counts"][b, :k] > 0).all() and np.isfinite(first["means"][b, :k]).all()
         assert (first["means"][b, :k, 2:] > 0).all()                                      # heights and widths
     eng.close()
+
+
+_LARGE_BATCH_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG
+from bayes_od_rc_amd import synthetic
+from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+from bayes_od_rc_amd.engine import Engine, make_config
+hw, n = (512, 512), 10
+weights = synthetic.make_weights(cls_fg_bias=-3.2)
+anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+frames = synthetic.make_frames(16, hw[0], hw[1], seed=21)
+out = []
+for batch in (16, 256):
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+    eng.load_weights(weights)
+    eng.set_anchors(anchors)
+    clip = frames if batch == 16 else np.concatenate([frames] * 16)          # frames 240..255 = frames 0..15 again
+    eng.infer(clip, seed=5, first_image_id=300)
+    det = {k: v.copy() for k, v in eng.get_detections_batch().items()}
+    out.append((det, eng.get_raw()[1][:16].copy()))
+    eng.close()
+(small, raw_small), (big, raw_big) = out
+assert np.array_equal(raw_small, raw_big), "raw box outputs differ"
+assert np.array_equal(small["num"], big["num"][:16])
+for b in range(16):
+    k = int(small["num"][b])
+    for key in ("scores", "means", "covs", "counts"):
+        assert np.array_equal(small[key][b, :k], big[key][b, :k]), (b, key)
+assert not np.array_equal(big["means"][0, :5], big["means"][240, :5])
+print("large batch == small batch")
+"""
+
+
+def test_large_batch_equals_small_batch():
+    """The bench's default shard (256 frames: 6 GiB tower activation buffers, far beyond 32-bit byte offsets from the
+    buffer base) returns, for its first frames, bit for bit what a 16-frame handle returns for the same frames and
+    image ids -- with the tile rule pinned (256x256 tiles, no split-K: otherwise the two batch sizes pick different
+    tilings for the small backbone layers and differ in fp32 summation order): the row-reuse loop's tile-relative
+    offsets, the tile packing across image boundaries and the batch size do not enter the arithmetic.  Runs in its own
+    process because the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_CONV_SPLITK="0")
+    r = subprocess.run([sys.executable, "-c", _LARGE_BATCH_SCRIPT, root], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
