@@ -992,7 +992,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const int variant = a.variant;
     if (a.xreuse) {
         if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
-        // xreuse == 2: every activation byte offset fits 32 bits -> compact-state, software-pipelined loop;
+        // xreuse == 2: compact-state, software-pipelined loop (32-bit byte offsets against the tile's first extended row);
         // otherwise (or variant 81, for A/B timing) the first-generation loop with 64-bit pointers
         if (a.xreuse != 2 || a.variant == 81) return launch_cfg<256, 256, 2, 4, 81, true>(a, s);
         if (a.variant == 1) return launch_cfg<256, 256, 2, 4, 1, true>(a, s);     // no epilogue
