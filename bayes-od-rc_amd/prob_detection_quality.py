@@ -351,5 +351,5 @@ def evaluate(matches):
     ev = PDQ()
     score = ev.score(matches) * 100
     tp, fp, fn = ev.get_assignment_counts()
-    return {'score': score, 'TP': tp, 'FP': fp, 'FN': fn, 'avg_spatial_quality': ev.get_avg_spatial_score(),
-            'avg_label_quality': ev.get_avg_label_score(), 'avg_overall_quality': ev.get_avg_overall_quality_score()}
+    return {'score': float(score), 'TP': int(tp), 'FP': int(fp), 'FN': int(fn), 'avg_spatial_quality': float(ev.get_avg_spatial_score()),
+            'avg_label_quality': float(ev.get_avg_label_score()), 'avg_overall_quality': float(ev.get_avg_overall_quality_score())}

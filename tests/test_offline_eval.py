@@ -76,3 +76,37 @@ def test_clutter_lowers_scores_and_matches_direct_calls(tmp_path):
                                     np.load(os.path.join(root, 'cov', 'frame03.jpg.npy')),
                                     np.load(os.path.join(root, 'cat_param', 'frame03.jpg.npy')), SHAPE)
     assert len(gts) == 1 and not pdq.gt_counts_for_pdq(gts[0]) and len(dets) == 3
+
+
+def test_kitti_tree(tmp_path):
+    """KITTI twins: label_2 text files + the per-frame text predictions the KITTI writer emits."""
+    rng = np.random.default_rng(9)
+    label_dir = tmp_path / 'label_2'
+    label_dir.mkdir()
+    w = PredictionWriter(str(tmp_path), 'kitti', 3)
+    names = {0: 'Car', 1: 'Pedestrian'}
+    for f in range(3):
+        rows, vuvu, cls5, cls8 = [], [], [], []
+        for _ in range(2):
+            x1, y1 = int(rng.integers(10, 600)), int(rng.integers(10, 200))
+            bw, bh = int(rng.integers(40, 120)), int(rng.integers(40, 100))
+            c = int(rng.integers(0, 2))
+            rows.append('%s 0.00 0 -10 %d.00 %d.00 %d.00 %d.00 1 1 1 0 0 0 0' % (names[c], x1, y1, x1 + bw, y1 + bh))
+            vuvu.append([y1, x1, y1 + bh, x1 + bw])
+            p5 = np.full(5, 0.02, np.float32); p5[c] = 0.92
+            p8 = np.full(8, 0.01, np.float32); p8[0 if c == 0 else 3] = 0.93        # BDD-trained vector: car = 0, person = 3
+            cls5.append(p5); cls8.append(p8)
+        rows.append('DontCare -1 -1 -10 1.00 1.00 5.00 5.00 -1 -1 -1 -1000 -1000 -1000 -10')
+        (label_dir / ('%06d.txt' % f)).write_text('\n'.join(rows) + '\n')
+        vuvu = np.array(vuvu, np.float32)
+        w.write('%06d' % f, vuvu, np.array(cls5), box_utils.vuvu_to_vuhw_np(vuvu), np.tile(np.eye(4, dtype=np.float32)[None] * 0.004, (2, 1, 1)),
+                np.array(cls8), np.array(cls8) * 30)
+    w.close()
+    g_cls, g_box = offline_eval.read_kitti_labels(str(label_dir / '000000.txt'), 'all', ('car', 'pedestrian'))
+    assert g_cls.shape == (2, 4) and g_box.shape == (2, 4)
+    gt, pred = offline_eval.kitti_records(str(label_dir), w.root)
+    assert len(gt) == 6 and len(pred) == 6
+    ap = offline_eval.main(['ap', '--dataset', 'kitti', '--labels', str(label_dir), '--predictions', w.root])
+    assert abs(ap['mean_ap'] - 100.0) < 1e-9
+    res = offline_eval.main(['pdq', '--dataset', 'kitti', '--labels', str(label_dir), '--predictions', w.root])
+    assert res['TP'] == 6 and res['FP'] == 0 and res['FN'] == 0 and res['score'] > 50.0
