@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Sums the PMC counters of the row-reuse tower kernel over the dispatches of tests/tools/pmc_head_conv.sh's three
+passes (rocprofv3 --pmc ... --output-format csv) and prints the derived ratios quoted in DESIGN.md section 5.1.
+usage: pmc_head_summary.py <dir with pmc_sq1/ pmc_sq2/ pmc_tcc/>  > profiles/round1_head_conv_counters.json"""
+import csv, glob, json, os, sys
+
+root = sys.argv[1]
+tot = {}
+for sub in ("pmc_sq1", "pmc_sq2", "pmc_tcc"):
+    for path in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fp:
+            for row in csv.DictReader(fp):
+                if "true>" not in row.get("Kernel_Name", ""):
+                    continue
+                tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+out = {"kernel": "conv_igemm_kernel<256,256,2,4,0,true> (tests/tools/bench_head_conv.py, layer 1, B=8)", "counters": tot}
+g = tot.get("GRBM_GUI_ACTIVE")
+if g:
+    # GRBM_* are reported summed over the 8 XCDs (GUI_ACTIVE / 8 / dispatches = the launch duration in shader clocks:
+    # 2.78 M cycles = 1.33 ms at 2.09 GHz); SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs
+    out["xcds"] = 8
+    out["mfma_busy_fraction_of_1024_simds"] = tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g / 8 * 1024)
+    out["ta_busy_fraction"] = tot.get("GRBM_TA_BUSY", 0.0) / g
+    if tot.get("SQ_INSTS_MFMA"):
+        out["gui_active_cycles_per_mfma_instruction_per_simd"] = (g / 8 * 1024) / tot["SQ_INSTS_MFMA"]
+h, m = tot.get("TCC_HIT_sum", 0.0), tot.get("TCC_MISS_sum", 0.0)
+if h + m:
+    out["l2_hit_rate"] = h / (h + m)
+if tot.get("SQ_LDS_IDX_ACTIVE"):
+    out["lds_bank_conflict_fraction_of_lds_cycles"] = tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"]
+print(json.dumps(out, indent=1))
