@@ -210,3 +210,26 @@ def test_full_size_step_descends(hw, batch, depth):
     eng.forward(frames, seed=4, first_image_id=0)
     assert np.isfinite(eng.get_raw()[0]).all()
     eng.close()
+
+
+def test_run_validation_over_training_checkpoints(tmp_path, monkeypatch):
+    """run_training writes checkpoints, run_validation evaluates each of them once (run_validation.py:86-228): losses,
+    post-processed predictions in the BDD json layout, evaluated_ckpts.txt bookkeeping, nothing to do on a second pass."""
+    import json
+    import os
+    monkeypatch.setenv("BAYESOD_DATA_DIR", str(tmp_path))
+    from bayes_od_rc_amd import run_training, run_validation
+    history, ckpt_dir = run_training.main(["--gpu_device", "0", "--synthetic", "3", "--image_size", "128", "128", "--steps", "6"])
+    assert os.path.exists(os.path.join(ckpt_dir, "ckpt-6.npz"))
+    res = run_validation.main(["--gpu_device", "0", "--synthetic", "2", "--image_size", "128", "128"])
+    assert [r["ckpt_id"] for r in res] == sorted(r["ckpt_id"] for r in res) and res[-1]["ckpt_id"] == 6
+    for r in res:
+        assert r["num_frames"] == 2 and np.isfinite(r["mean_total_loss"]) and set(r["mean_losses"]) >= {"cls_loss", "reg_loss"}
+    pred_root = os.path.join(os.path.dirname(ckpt_dir), "predictions")
+    with open(os.path.join(pred_root, "validation", "6", "data", "predictions.json")) as fp:
+        records = json.load(fp)
+    assert len(records) == res[-1]["num_detections"]
+    for rec in records[:5]:
+        assert set(rec) >= {"name", "category", "bbox", "score"} and len(rec["bbox"]) == 4
+    assert list(run_validation.get_evaluated_ckpts(pred_root)) == [r["ckpt_id"] for r in res]
+    assert run_validation.main(["--gpu_device", "0", "--synthetic", "2", "--image_size", "128", "128"]) == []
