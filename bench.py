@@ -291,6 +291,12 @@ def main():
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
     if fan_out:
         roofline["other_head_launch"] = fan_out
+    # BASELINE.md section 3, "reported beside it": the whole pipeline's de-duplicated conv FLOPs per image x images/sec
+    # (backbone + FPN 49.05 GFLOP at 512x512, linear in the pixel count; heads 3 + 8 N convs + N 1x1 sets)
+    image_gflop = (49.05e9 * (hw[0] * hw[1]) / (512.0 * 512.0) + (3 + 8 * n) * conv_flops + n * out_flops) / 1e9
+    roofline["pipeline"] = {"dedup_gflop_per_image": round(image_gflop, 1),
+                            "achieved": round(image_gflop * value / world / 1e3, 2), "unit": "TFLOP/s per GPU",
+                            "frac": round(image_gflop * value / world / 1e3 / peak, 4)}
     # per-anchor latency of the aggregate / posterior stage (a9-a11): HIP events around the stage's launches of the timed
     # steps (main stream, between one batch's convolutions and the next)
     post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
