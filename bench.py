@@ -301,6 +301,15 @@ def main():
     # steps (main stream, between one batch's convolutions and the next)
     post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
 
+    # where a step's time goes on the main stream (soft-NMS, cluster-fuse and the D2H of the records run on the side stream
+    # underneath the next batch); per-layer detail: BOD_TRACE_OPS=k
+    step_ms = elapsed / args.steps * 1e3
+    stages = {"head_towers_layers_1_3": round(prof["head_conv_ms"] / prof_steps, 3) if tower_only else None,
+              "head_tower_layer_0_fan_out": round(fan_out["avg_launch_ms"], 3) if fan_out else None,
+              "posterior": round(prof["posterior_ms"] / max(1, prof["posterior_launches"]), 3) if prof["posterior_launches"] else None}
+    known = sum(v for v in stages.values() if v)
+    stages["stem_backbone_fpn_and_gaps"] = round(step_ms - known, 3) if tower_only else None
+
     out = {"metric": "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency",
            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -312,7 +321,8 @@ def main():
                       "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
                       "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
                       "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
-                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4)},
+                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),
+                      "stages_ms_per_step": stages},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(hw, n, frames, weights, anchors)
