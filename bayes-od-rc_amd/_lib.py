@@ -67,6 +67,7 @@ SIGNATURES = {
     "bod_set_nms": (C.c_int, [_H, C.c_int32, _I, C.c_int32]),
     "bod_get_iou_matrix": (C.c_int, [_H, C.c_int32, _F]),
     "bod_cluster_fuse": (C.c_int, [_H]),
+    "bod_set_affinity": (C.c_int, [_H, C.c_int32, _F, C.c_int32, C.c_int32]),
     "bod_get_detections": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
     "bod_get_detections_batch": (C.c_int, [_H, _I, _F, _F, _F, _F]),
     "bod_device_detections": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -37,8 +37,38 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HEADER = os.path.join(os.path.dirname(HERE), "include", "bayesod.h")
+CDEF = os.path.join(os.path.dirname(HERE), "include", "bayesod_cdef.h")
+
+
+def cdef_text():
+    """include/bayesod.h reduced to what ``cffi.FFI().cdef()`` (or any pycparser-based binder) accepts: comments,
+    preprocessor lines and the extern "C" bracket removed, declarations untouched."""
+    import re
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = []
+    for line in text.splitlines():
+        t = line.strip()
+        if not t or t.startswith("#") or t == 'extern "C" {' or t == "}":
+            continue
+        out.append(line.rstrip())
+    return ("/* GENERATED from include/bayesod.h by bayes_od_rc_amd.build.write_cdef(): the same declarations without\n"
+            " * comments / preprocessor lines, for ffi.cdef(open('include/bayesod_cdef.h').read()).  Do not edit. */\n"
+            + "\n".join(out) + "\n")
+
+
+def write_cdef():
+    text = cdef_text()
+    if not os.path.exists(CDEF) or open(CDEF).read() != text:
+        with open(CDEF, "w") as fp:
+            fp.write(text)
+    return CDEF
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
+    write_cdef()
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)

@@ -24,6 +24,7 @@ import numpy as np
 SUFFIX = "/.ATTRIBUTES/VARIABLE_VALUE"
 _BN_FIELDS = {"gamma": "gamma", "beta": "beta", "moving_mean": "mean", "moving_variance": "var"}
 _CONV_FIELDS = {"kernel": "kernel", "bias": "bias"}
+OPTIONAL_PREFIX = "net/reg_header/conv_4/"      # constructed, never called: no variables in a real checkpoint
 _STAGE_BLOCKS = {2: "abc", 3: "abcd", 4: "abcdef", 5: "abc"}          # ResNet-50 (feature_extractor.py:36-100)
 
 
@@ -77,9 +78,12 @@ def convert(reader, require_all=True):
         raise ValueError("checkpoint holds model variables this converter does not map (not the ResNet-50 "
                          "RetinaNet of retinanet_model.py?): %s" % unknown[:5])
     missing = sorted(set(keymap) - set(present))
-    # cov_header exists only for 'regression_covar' models; reg conv_4 is constructed but never called (a4)
-    missing = [k for k in missing if not k.startswith("net/cov_header/")] if not any(
-        k.startswith("net/cov_header/") for k in present) else missing
+    # RegHeader constructs conv_4 but never calls it (multitask_headers.py:181-194 vs :209-230), so Keras never builds
+    # it and a real checkpoint holds no variables for it; the engine does not read pyramid_regression_3 either.
+    missing = [k for k in missing if not k.startswith(OPTIONAL_PREFIX)]
+    # cov_header exists only for 'regression_covar' / 'regression_var' models (retinanet_model.py:53-62): absent as a whole is fine
+    if not any(k.startswith("net/cov_header/") for k in present):
+        missing = [k for k in missing if not k.startswith("net/cov_header/")]
     if require_all and missing:
         raise ValueError("checkpoint lacks %d expected variables, e.g. %s" % (len(missing), missing[:5]))
     return weights

@@ -119,6 +119,7 @@ struct bod_context {
         out_covs = out_covs_s[sidx]; out_counts = out_counts_s[sidx];
     }
     float* iou_scratch = nullptr; int64_t iou_cap = 0;
+    float* affinity = nullptr; int affinity_img = -1;   // bod_set_affinity: centre columns of a caller-supplied affinity matrix (one-shot)
 
     // profiling
     bool profiling = false; int prof_which = 0;
@@ -816,6 +817,8 @@ bod_status run_cluster(bod_context* h, hipStream_t st) {
     a.num_kept = h->pb.num_kept; a.selected = h->nms_sel; a.num_selected = h->nms_nsel;
     a.corners = h->pb.corners; a.counts = h->pb.counts; a.means = h->pb.means; a.covs = h->pb.covs;
     a.thr = c.nms_iou_threshold;
+    a.affinity = h->affinity_img >= 0 ? h->affinity : nullptr; a.affinity_img = h->affinity_img;
+    h->affinity_img = -1;                         // consumed by this call
     a.out_scores = h->out_scores; a.out_means = h->out_means; a.out_covs = h->out_covs; a.out_counts = h->out_counts;
     HIPCHK(h, launch_cluster_fuse(a, st));
     h->cluster_done = true;
@@ -910,6 +913,7 @@ bod_status bod_destroy(bod_handle h) {
     for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
+    if (h->affinity) hipFree(h->affinity);
     if (h->d_frames_u8) hipFree(h->d_frames_u8);
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1233,6 +1237,27 @@ bod_status bod_get_iou_matrix(bod_handle h, int32_t img, float* iou) {
     HIPCHK(h, launch_iou_matrix(h->pb.corners + (size_t)img * h->A * 4, m, h->iou_scratch, h->stream));
     BODCHK(d2h(h, iou, h->iou_scratch, (size_t)need));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BOD_OK;
+}
+
+bod_status bod_set_affinity(bod_handle h, int32_t img, const float* centre_columns, int32_t k, int32_t m) {
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms / bod_set_nms has not run");
+    if (img < 0 || img >= h->cfg.batch || !centre_columns) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_affinity: bad image index / NULL");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int32_t mm = 0, kk = 0;
+    BODCHK(image_m(h, img, &mm));
+    HIPCHK(h, hipMemcpyAsync(&kk, h->nms_nsel + img, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (m != mm || k != kk)
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_set_affinity: got %d columns of %d rows, the image has %d centres and %d boxes", k, m, kk, mm);
+    if (!h->affinity && hipMalloc((void**)&h->affinity, (size_t)h->cfg.nms_max_output_size * h->A * 4) != hipSuccess)
+        return h->fail(BOD_ERR_OOM, "bod_set_affinity: %zu bytes", (size_t)h->cfg.nms_max_output_size * h->A * 4);
+    if (k > 0 && m > 0)
+        HIPCHK(h, hipMemcpy2DAsync(h->affinity, (size_t)h->A * 4, centre_columns, (size_t)m * 4, (size_t)m * 4, (size_t)k,
+                                   hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->affinity_img = img;
     return BOD_OK;
 }
 

@@ -166,6 +166,9 @@ struct ClusterArgs {
     const float* means;           // [B,A,4]
     const float* covs;            // [B,A,16]
     float thr;
+    // optional caller-supplied affinity (bayes_od_clustering's `affinity_matrix`, inference_utils.py:316): for image
+    // `affinity_img`, row k = affinity_matrix[:, centre_k] ([max_out][A] floats); nullptr = IoU of the means on the fly
+    const float* affinity; int32_t affinity_img;
     // outputs [B,max_out,...]
     float* out_scores; float* out_means; float* out_covs; float* out_counts;
 };

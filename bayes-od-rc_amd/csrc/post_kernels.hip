@@ -739,8 +739,9 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_fuse_kernel(ClusterArgs a) {
     float tk[3] = {INFINITY, INFINITY, INFINITY};
     int ti[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
     int cnt = 0;
+    const float* aff = (a.affinity && b == a.affinity_img) ? a.affinity + (size_t)k * a.A : nullptr;
     for (int i = tid; i < M; i += CL_BLOCK) {
-        if (!(iou_plus1(boxes[i], cbox) > a.thr)) continue;
+        if (!((aff ? aff[i] : iou_plus1(boxes[i], cbox)) > a.thr)) continue;
         ++cnt;
         Mat4 cv;
 #pragma unroll

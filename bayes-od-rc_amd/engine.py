@@ -302,6 +302,11 @@ class Engine(object):
         c = np.ascontiguousarray(centres, dtype=np.int32)
         self._chk(self.lib.bod_set_nms(self.h, image_index, iptr(c), c.shape[0]))
 
+    def set_affinity(self, image_index, centre_columns):
+        """centre_columns [K,M]: affinity_matrix[:, centre_k] for every cluster centre (one-shot, next cluster_fuse)."""
+        c = as_f32(centre_columns)
+        self._chk(self.lib.bod_set_affinity(self.h, image_index, fptr(c), c.shape[0], c.shape[1]))
+
     def get_iou_matrix(self, image_index=0):
         m = int(self.num_kept()[image_index])
         out = np.empty((m, m), np.float32)

@@ -65,9 +65,11 @@ def bayes_od_clustering(predicted_boxes_class_counts, predicted_boxes_means, pre
     """Bayesian cluster-and-fuse on the device (reference :285-364).
 
     Returns (final_scores [K,C], final_means [K,4,1], final_covs [K,4,4] (x70), final_counts [K,C]).
-    The affinity of the reference is ``bbox_iou_vuvu`` of the posterior means (:204-215); the
-    device evaluates exactly that on the fly against each centre, so ``affinity_matrix`` is
-    accepted for signature compatibility and not read.
+    ``affinity_matrix`` [M,M] is used exactly as the reference uses it (:316, members of centre k =
+    ``affinity_matrix[:, k] > affinity_threshold``): its K centre columns are uploaded (K*M floats, not M*M).
+    ``affinity_matrix=None`` selects the reference pipeline's own affinity, ``bbox_iou_vuvu`` of the
+    posterior means (:204-215, run_inference.py:145-149), evaluated on the fly against each centre
+    on the device without ever building the M x M matrix.
     """
     from .engine import Engine, make_config
     counts = np.ascontiguousarray(predicted_boxes_class_counts, dtype=np.float32)
@@ -85,6 +87,13 @@ def bayes_od_clustering(predicted_boxes_class_counts, predicted_boxes_means, pre
     eng.update_config(cfg)
     eng.set_posterior(0, counts, means, covs, np.zeros(m, np.float32))
     eng._set_centres(0, centres)
+    if affinity_matrix is not None:
+        aff = np.asarray(affinity_matrix)
+        if aff.shape != (m, m):
+            raise ValueError("affinity_matrix must be [M,M] = [%d,%d], got %s" % (m, m, aff.shape))
+        if centres.min() < 0 or centres.max() >= m:
+            raise ValueError("cluster centre out of range [0,%d)" % m)
+        eng.set_affinity(0, np.ascontiguousarray(aff[:, centres].T, dtype=np.float32))
     eng.cluster_fuse()
     scores, fmeans, fcovs, fcounts = eng.get_detections(0)
     return scores, fmeans[:, :, None], fcovs, fcounts
@@ -135,16 +144,27 @@ class BayesOdPipeline(object):
 
     def __init__(self, model, image_hw, batch, bayes_od_config, nms_config, use_full_covar=True,
                  dataset_name='bdd', orig_size=None, nms_variant='A', anchors=None):
-        kw = dict(bayes_od_config=bayes_od_config, nms_config=nms_config, use_full_covar=use_full_covar,
-                  dataset_name=dataset_name, nms_variant=nms_variant, orig_size=orig_size)
-        self.model = model
-        self.engine = model.engine_for(image_hw, batch=batch, mc_samples=model.mc_dropout_samples, **kw)
+        self._kw = dict(bayes_od_config=bayes_od_config, nms_config=nms_config, use_full_covar=use_full_covar,
+                        dataset_name=dataset_name, nms_variant=nms_variant, orig_size=orig_size)
+        self.model, self._hw, self._batch = model, tuple(image_hw), batch
+        self.engine = self.bind()
         if anchors is not None:
             self.engine.set_anchors(anchors)
+
+    def bind(self, orig_size=None):
+        """(Re-)apply this pipeline's testing configuration to its engine.  Engines are cached by the model per
+        (network size, batch, N), so two pipelines that differ only in ``orig_size`` -- KITTI frames of 370x1224 and
+        375x1242 both resize to the same network input -- share one handle: the S mu / S Sigma S^T factors
+        (inference_utils.py:147-167 takes them per sample from ORIGINAL_IM_SIZE) must be set before every batch."""
+        if orig_size is not None:
+            self._kw['orig_size'] = tuple(orig_size)
+        self.engine = self.model.engine_for(self._hw, batch=self._batch, mc_samples=self.model.mc_dropout_samples, **self._kw)
+        return self.engine
 
     def __call__(self, images=None, seed=0, first_image_id=0):
         """images [B,H,W,3] (or None to reuse the uploaded device batch).  Returns, per image,
         (output_classes [K,C], output_boxes_vuhw [K,4], output_covs [K,4,4], output_counts [K,C])."""
+        self.bind()
         self.engine.infer(images, seed=seed, first_image_id=first_image_id)
         return [self.engine.get_detections(b) for b in range(self.engine.B)]
 

@@ -48,9 +48,14 @@ def test_model(config, args):
     anchors = gen.generate_all((hw[0], hw[1], 3))
     batch = max(1, min(args.batch, len(frames)))
     orig = tuple(args.orig_size) if args.orig_size else (hw[0], hw[1])
-    pipe = inference_utils.BayesOdPipeline(model, hw, batch, test_config['bayes_od_config'], nms_config,
-                                           use_full_covar=test_config['use_full_covar'],
-                                           dataset_name=test_dataset, orig_size=orig, anchors=anchors)
+    pipes = {}
+
+    def pipe_for(b):                      # the tail (len(frames) % batch frames) runs through a smaller-batch handle
+        if b not in pipes:
+            pipes[b] = inference_utils.BayesOdPipeline(model, hw, b, test_config['bayes_od_config'], nms_config,
+                                                       use_full_covar=test_config['use_full_covar'],
+                                                       dataset_name=test_dataset, orig_size=orig, anchors=anchors)
+        return pipes[b]
     predictions_dir = os.path.join(config_utils.data_dir(), 'outputs', config['checkpoint_name'], 'predictions')
     writer = writers.PredictionWriter(predictions_dir, test_dataset, test_config['ckpt_idx'],
                                       test_config['uncertainty_method'],
@@ -58,8 +63,9 @@ def test_model(config, args):
     categories = dataset_config[training_dataset]['training_data_config']['categories']
     start = time.time()
     n_done = 0
-    for lo in range(0, len(frames) - batch + 1, batch):
-        dets = pipe(frames[lo:lo + batch], seed=args.seed, first_image_id=lo)
+    for lo in range(0, len(frames), batch):              # every frame, like the reference's loop (run_inference.py:137)
+        chunk = frames[lo:lo + batch]
+        dets = pipe_for(len(chunk))(chunk, seed=args.seed, first_image_id=lo)
         for b, (classes, boxes_vuhw, covs, counts) in enumerate(dets):
             boxes = box_utils.vuhw_to_vuvu_np(boxes_vuhw) if boxes_vuhw.size else boxes_vuhw
             mapped = classes
@@ -104,6 +110,7 @@ def _test_model_on_dataset(config, args, model):
                 use_full_covar=test_config['use_full_covar'], dataset_name=test_dataset, orig_size=src_hw,
                 anchors=gen.generate_all((hw[0], hw[1], 3)))
         pipe = pipes[key]
+        pipe.bind(orig_size=src_hw)      # the handle may be shared with a pipe of another source size: re-apply the KITTI scale
         pipe.engine.upload_frames_u8(frames, constants.MEANS_DICT[handler.im_normalization], aspect_resize=kitti)
         dets = pipe(None, seed=args.seed, first_image_id=pending[0][2])
         for (name, _, _), (classes, boxes_vuhw, covs, counts) in zip(pending, dets):

@@ -159,6 +159,12 @@ bod_status bod_get_iou_matrix(bod_handle h, int32_t image_index, float* iou);
 /* bayes_od_clustering (inference_utils.py:285-364) on the device, affinity = the IoU above,
  * threshold = nms_iou_threshold; covariances x70. */
 bod_status bod_cluster_fuse(bod_handle h);
+/* The `affinity_matrix` argument of bayes_od_clustering (inference_utils.py:290,316) when the caller's affinity is
+ * not the IoU of the posterior means: centre_columns [k][m] holds, for each of the image's k cluster centres (in
+ * bod_set_nms / bod_get_nms order), the column affinity_matrix[:, centre] over the image's m boxes.  The NEXT
+ * bod_cluster_fuse tests `centre_columns[k][i] > nms_iou_threshold` for that image instead of evaluating the IoU on
+ * the fly, then the columns are dropped (one-shot).  k and m must equal the image's centre and box counts. */
+bod_status bod_set_affinity(bod_handle h, int32_t image_index, const float* centre_columns, int32_t k, int32_t m);
 /* Final detections of one image: K <= max_detections rows.
  * scores [K,C], means [K,4] (v,u,h,w), covs [K,16], counts [K,C]. */
 bod_status bod_get_detections(bod_handle h, int32_t image_index, int32_t* num_detections,

@@ -135,6 +135,35 @@ def golden_pdq():
     print("pdq.npz written")
 
 
+def golden_affinity():
+    """bayes_od_clustering with a caller-supplied affinity that is NOT the IoU of the means (inference_utils.py:290,316):
+    a Gaussian kernel on the box-centre distance, threshold 0.6.  Writes only ``clustering_affinity.npz``."""
+    from src.retina_net.experiments import inference_utils as ref_iu
+    cases, idx = {}, 0
+    for seed in range(3):
+        for (m, n_obj, k, c) in ((5, 2, 2, 8), (40, 4, 6, 8), (150, 9, 20, 4)):
+            rng = np.random.default_rng(7000 + 100 * seed + m)
+            vuhw, _ = _boxes_vuhw(rng, m, n_obj)
+            d2 = ((vuhw[:, None, :2] - vuhw[None, :, :2]) ** 2).sum(-1)
+            aff = np.exp(-d2 / np.float32(2.0 * 6.0 ** 2)).astype(np.float32)
+            aff[np.abs(aff - 0.6) < 1e-3] = 0.7          # keep every entry away from the threshold
+            covs = _random_spd(rng, m, 4.0)
+            probs = rng.dirichlet(np.ones(c) * 0.6, size=m)
+            counts = np.stack([rng.multinomial(30, p) for p in probs]).astype(np.float32) + np.float32(1.0 / c)
+            centres = rng.choice(m, size=min(k, m), replace=False).astype(np.int32)
+            means = vuhw[:, :, None].astype(np.float32)
+            scores, fmeans, fcovs, fcounts = ref_iu.bayes_od_clustering(counts, means, covs, centres, aff, affinity_threshold=0.6)
+            tag = "a%02d" % idx
+            for name, val in (("counts", counts), ("means", means), ("covs", covs), ("centres", centres), ("affinity", aff),
+                              ("out_scores", scores), ("out_means", fmeans), ("out_covs", fcovs), ("out_counts", fcounts)):
+                cases["%s_%s" % (tag, name)] = np.asarray(val)
+            idx += 1
+    cases["n_cases"] = np.int32(idx)
+    cases["affinity_threshold"] = np.float32(0.6)
+    np.savez_compressed(os.path.join(OUT, "clustering_affinity.npz"), **cases)
+    print("clustering_affinity.npz written (%d cases)" % idx)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not found at %s" % REF)
@@ -142,6 +171,9 @@ def main():
     sys.path.insert(0, REF)
     if len(sys.argv) > 1 and sys.argv[1] == "pdq":
         golden_pdq()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "affinity":
+        golden_affinity()
         return
     from src.retina_net.experiments import inference_utils as ref_iu
     from src.retina_net.anchor_generator import box_utils as ref_bu

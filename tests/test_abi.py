@@ -34,6 +34,20 @@ def test_header_and_binding_and_library_agree(lib):
     assert lib.bod_version().decode().startswith("bayesod-hip")
 
 
+def test_cdef_header_for_cffi_is_current_and_plain_c():
+    """INTEGRATION.md's cffi route: include/bayesod_cdef.h must be the header minus comments / preprocessor lines (what
+    ffi.cdef accepts), declare exactly the header's symbols, and compile as plain C given <stdint.h>."""
+    import subprocess
+    from bayes_od_rc_amd import build
+    path = os.path.join(ROOT, "include", "bayesod_cdef.h")
+    text = open(path).read()
+    assert text == build.cdef_text(), "include/bayesod_cdef.h is stale: run bayes_od_rc_amd.build.write_cdef()"
+    body = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert "#" not in body and "extern" not in body and body.count("{") == body.count("}")
+    assert sorted(set(re.findall(r"\b(bod_[a-z0-9_]+)\s*\(", body))) == _header_symbols()
+    subprocess.check_call(["gcc", "-fsyntax-only", "-include", "stdint.h", "-x", "c", path])
+
+
 def test_struct_layout_matches_header():
     from bayes_od_rc_amd._lib import BodConfig, BodSizes
     assert ctypes.sizeof(BodConfig) == 23 * 4 + 8 * 4

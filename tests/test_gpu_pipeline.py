@@ -4,7 +4,7 @@ inputs), and for batch / API consistency."""
 import numpy as np
 import pytest
 
-from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG, rel_err
+from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG, compare_posterior, rel_err
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-3
@@ -40,13 +40,11 @@ def test_infer_stage_chain_matches_oracle():
         u = philox.categorical_uniforms(seed, first + b, eng.A)
         pred = {"anchors_class_predictions": cls[b], "anchors_box_predictions": box[b],
                 "anchors_box_covar_predictions": network.fill_triangular_4(cov[b])}
-        ref = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64)
+        ref = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64, return_debug=True)
         got = eng.get_posterior(b)
         m = got["means"].shape[0]
         assert m > 50, "calibration should leave a few hundred anchors"
-        if not np.array_equal(np.nonzero(ref["keep"])[0], got["anchor_index"]):
-            continue                      # a draw on a float rounding boundary: covered in test_gpu_post
-        assert rel_err(got["means"], ref["means"][:, :, 0], 1.0) < REL_TOL
+        compare_posterior(got, ref, u, tol=REL_TOL, min_checked=50)     # anchors on a CDF rounding boundary masked, never skipped
         # stage 2: NMS on the device's posterior
         ref_idx, _ = nms.soft_nms(geometry.vuhw_to_vuvu(got["means"]), got["ranking"], 100, 0.5, 0.5)
         assert np.array_equal(eng.get_nms(b), ref_idx)
@@ -175,13 +173,12 @@ def test_fp32_pipeline_matches_oracle_end_to_end():
         km = lambda s, lid: philox.dropout_keep_mask(seed, b, s, lid, eng.P, 256, 0.3)
         pred = network.retinanet_forward(w, frames[b][None], n, 8, mode="literal", dtype=np.float64, keep_masks=km)
         u = philox.categorical_uniforms(seed, b, eng.A)
-        post = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64)
+        post = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64, return_debug=True)
         got = eng.get_posterior(b)
-        if not np.array_equal(np.nonzero(post["keep"])[0], got["anchor_index"]):
-            continue
-        assert rel_err(got["means"], post["means"][:, :, 0], 1.0) < REL_TOL
-        floor = np.abs(post["covs"]).reshape(len(post["covs"]), -1).max(axis=1)[:, None, None] * 1e-2
-        assert (np.abs(got["covs"] - post["covs"]) / (np.abs(post["covs"]) + floor)).max() < REL_TOL
+        # every image, boundary anchors masked (the class probabilities come from two forward passes that agree to ~1e-5)
+        _, same_set = compare_posterior(got, post, u, tol=REL_TOL, min_checked=50, boundary_eps=2e-4, max_ambiguous=5e-2)
+        if not same_set:
+            continue                       # the later stages need identical candidate lists
         corners = post["corners"].astype(np.float32)
         idx, _ = nms.soft_nms(corners, post["ranking"].astype(np.float32), 100, 0.5, 0.5)
         if not np.array_equal(idx, eng.get_nms(b)):
@@ -391,13 +388,10 @@ def test_model_without_covariance_head():
     assert cov is None or cov.size == 0 or not np.any(cov)
     pred = {"anchors_class_predictions": cls[0], "anchors_box_predictions": box[0]}
     u = philox.categorical_uniforms(21, 5, eng.A)
-    ref = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64)
+    ref = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64, return_debug=True)
     got = eng.get_posterior(0)
     assert got["means"].shape[0] > 50
-    if np.array_equal(np.nonzero(ref["keep"])[0], got["anchor_index"]):
-        assert rel_err(got["means"], ref["means"][:, :, 0], 1.0) < REL_TOL
-        scale = float(np.abs(ref["covs"]).max())
-        assert rel_err(got["covs"], ref["covs"], scale) < 5e-3
+    compare_posterior(got, ref, u, tol=REL_TOL, cov_tol=5e-3, min_checked=50)
     assert dets[0][0].shape[0] > 0 and np.isfinite(dets[0][2]).all()
 
 

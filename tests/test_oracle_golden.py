@@ -29,6 +29,21 @@ def test_clustering_oracle_equals_reference(golden_dir):
     assert 1 in sizes and any(s > 3 for s in sizes) and any(2 <= s <= 3 for s in sizes)
 
 
+def test_clustering_oracle_with_caller_affinity_equals_reference(golden_dir):
+    """affinity_matrix that is NOT the IoU of the means (inference_utils.py:290,316): reference outputs by import."""
+    from oracle import clustering
+    g = np.load(os.path.join(golden_dir, "clustering_affinity.npz"))
+    thr = float(g["affinity_threshold"])
+    assert int(g["n_cases"]) == 9 and thr == pytest.approx(0.6)
+    for i in range(int(g["n_cases"])):
+        t = "a%02d" % i
+        out = clustering.bayes_od_clustering(g[t + "_counts"], g[t + "_means"], g[t + "_covs"], g[t + "_centres"],
+                                             g[t + "_affinity"], thr, return_margins=True)
+        assert np.all(out[4] > 0)
+        for o, name in zip(out[:4], ("scores", "means", "covs", "counts")):
+            assert rel_err(o, g[t + "_out_" + name], 1e-9) < 1e-6, (t, name)
+
+
 def test_cluster_of_one_member_is_identity_times_70(golden_dir):
     from oracle import clustering
     g = np.load(os.path.join(golden_dir, "clustering.npz"))
