@@ -250,6 +250,40 @@ __global__ __launch_bounds__(256) void stem_pool_f32_kernel(const float* __restr
     *reinterpret_cast<float4*>(out + opix * 64 + cg * 4) = m;
 }
 
+// bf16x3 precision: fp32 stem output in, (hi, lo) bf16 pairs out -- 32 hi then 32 lo per 64-slot group of the 128-slot
+// pixel (conv_igemm.hip); the max itself is exact
+__global__ __launch_bounds__(256) void stem_pool_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
+                                                              int B, int ih, int iw, int oh, int ow, int out_pitch, int out_plane) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int total = B * oh * ow * 16;
+    if (gid >= total) return;
+    const int cg = gid & 15;
+    int p = gid >> 4;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        if (iy < 0 || iy >= ih) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx - 2;
+            if (ix < 0 || ix >= iw) continue;
+            const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * ih + iy) * iw + ix) * 64 + cg * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    const float v[4] = {m.x, m.y, m.z, m.w};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { hi[q] = f32_to_bf16_a(v[q]); lo[q] = f32_to_bf16_a(v[q] - bf16_to_f32_a(hi[q])); }
+    const size_t opix = (size_t)b * out_plane + (size_t)(oy + 1) * out_pitch + (ox + 1);
+    const int c = cg * 4, slot = (c >> 5) * 64 + (c & 31);
+    uint16_t* o = out + opix * 128 + slot;
+    *reinterpret_cast<uint2*>(o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+}
+
 // thread = (output pixel, 8-channel group); 16-byte loads/stores. Pads are zeros: inputs are
 // post-ReLU (>= 0) so a zero pad value is what ZeroPadding2D + max produces.
 __global__ __launch_bounds__(256) void stem_pool_kernel(const uint16_t* __restrict__ in,
@@ -291,9 +325,16 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const uint16_t* __restri
     *reinterpret_cast<uint4*>(out + opix * 64 + cg * 8) = o;
 }
 
-hipError_t launch_stem_pool(const void* in, void* out, int f32, int B, int ih, int iw, int oh, int ow,
+hipError_t launch_stem_pool(const void* in, void* out, int mode, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s) {
-    if (f32) {
+    if (mode == 2) {
+        const int total = B * oh * ow * 16;
+        hipLaunchKernelGGL(stem_pool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(in), reinterpret_cast<uint16_t*>(out), B, ih, iw, oh, ow,
+                           out_pitch, out_plane);
+        return hipGetLastError();
+    }
+    if (mode == 1) {
         const int total = B * oh * ow * 16;
         hipLaunchKernelGGL(stem_pool_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), B, ih, iw, oh, ow,

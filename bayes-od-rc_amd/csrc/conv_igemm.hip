@@ -22,6 +22,13 @@
 // Epilogue (bf16 outputs): bias (+residual) (+ReLU) (+Philox dropout) in registers, transposed
 // through LDS as a [pixel][cout] tile (chunk-swizzled), then stored as whole 16-byte pieces of
 // contiguous NHWC pixel rows (512 B per pixel at 256 channels) instead of 8-byte scatters.
+//
+// bf16x3 ("split") precision mode (ConvArgs.split, template flag SPLIT): every value is stored as TWO bf16, x = hi + lo
+// (exact to 2^-17 relative), 32 channels of hi followed by their 32 lo halves in every 64-slot (128-byte) group, for
+// activations and weights alike.  One K-tile row is then 32 channels and the staging code is untouched (cin and all
+// pixel strides are given in slots); the product is hi*hi + hi*lo + lo*hi on the same MFMA (fp32 accumulate, the
+// lo*lo term is below 2^-16), i.e. six k-steps per K-tile instead of four: three times the MFMA work of bf16 mode for
+// twice the bytes, and fp32-class results (end-to-end 1e-3 against the float64 oracle) on the bf16 matrix pipe.
 #include "kernels.h"
 #include "philox.h"
 #include <cstdlib>
@@ -149,6 +156,36 @@ struct KTilePipe {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // bf16x3: a K-tile row holds [hi 0..15 | hi 16..31 | lo 0..15 | lo 16..31] (k-steps 0..3 of the bf16 layout); per
+    // 16-channel half h the three products hi*lo, lo*hi, hi*hi (small terms first) go into the same accumulators.
+    __device__ __forceinline__ void run_split(f32x16 (&acc)[FC][FP]) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 Ah[FC], Al[FC], Bh[FP], Bl[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) { if (h == 0 && i < (FC == 4 ? 2 : FC)) Ah[i] = Ac[i]; else Ah[i] = ldA(i, h); }
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { if (h == 0) Bh[j] = Bc[j]; else Bh[j] = ldB(j, h); }
+#pragma unroll
+            for (int j = 0; j < FP; ++j) Bl[j] = ldB(j, 2 + h);
+#pragma unroll
+            for (int i = 0; i < FC; ++i) Al[i] = ldA(i, 2 + h);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
     __device__ __forceinline__ void run(f32x16 (&acc)[FC][FP]) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FC == 4 && FP == 2) {
@@ -203,8 +240,9 @@ struct KTilePipe {
     }
 };
 
-template <int BC, int BP, int WC, int WP, int ABL, bool XR>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
+    static_assert(!(SPLIT && XR) && !(SPLIT && ABL != 0), "the bf16x3 mode runs on the generic loop, production build only");
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = THREADS;            // threads that stage
@@ -506,7 +544,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             for (int j = 0; j < FP; ++j) pipe.xb[j] = cur * STAGE + W_BYTES + (wp * WTP + j * 32 + frow) * ROWB + a_c0;
             pipe.first_loads();
             if (more && ABL != 2 && loader) issue(cur ^ 1, ky, kx, cc);
-            pipe.run(acc);
+            if constexpr (SPLIT) pipe.run_split(acc); else pipe.run(acc);
             cur ^= 1;
         }
     }
@@ -601,6 +639,103 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         o[q] = accum ? o[q] + r : r;
                     }
                 }
+            }
+        }
+        return;
+    }
+
+    if constexpr (SPLIT) {
+        // ---- bf16x3 outputs: every value leaves as a (hi, lo) bf16 pair, 32 hi then 32 lo per 64-slot group of the NHWC
+        // pixel row.  Same route as the bf16 tile below -- registers -> chunk-swizzled [pixel][slot] LDS tile -> 16-byte
+        // stores of whole pixel rows -- but a pixel row is 4 bytes per channel, so the 256x256 tile goes in FP passes of
+        // one pixel fragment per wave (128 pixels x 1 KiB = the 128 KiB the staging buffers leave).
+        constexpr int EPASS = (BP * BC * 4 > Cfg::MAIN) ? FP : 1;
+        constexpr int JP = FP / EPASS;               // pixel fragments per wave per pass
+        constexpr int WPP = JP * 32;                 // pixels per wave per pass
+        constexpr int PPASS = WP * WPP;              // pixels per pass
+        constexpr int ROW2 = BC * 4;                 // bytes per pixel row of the tile
+        constexpr int CPR2 = ROW2 / 16;
+        static_assert(PPASS * ROW2 <= Cfg::MAIN, "split epilogue tile does not fit the staging area");
+        uint32_t rng_seed_lo = a.seed_lo, rng_seed_hi = a.seed_hi, rng_image_base = a.image_base;
+        if (a.dyn_rng) { rng_seed_lo = a.dyn_rng[0]; rng_seed_hi = a.dyn_rng[1]; rng_image_base = a.dyn_rng[2]; }
+        const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
+        const uint32_t thr_m1 = a.drop_threshold > 0 ? a.drop_threshold - 1u : 0u;
+        const uint32_t thr_m1_x2 = thr_m1 | (thr_m1 << 16);
+        uint16_t* out16 = reinterpret_cast<uint16_t*>(G.out);
+        __syncthreads();                              // all waves are done with the staging buffers
+        for (int n = 0; n < fan; ++n) {
+#pragma unroll
+            for (int pass = 0; pass < EPASS; ++pass) {
+#pragma unroll
+                for (int jj = 0; jj < JP; ++jj) {
+                    const int j = pass * JP + jj;
+                    const int pixl = wp * WTP + j * 32 + frow;
+                    const int lr = wp * WPP + jj * 32 + frow;
+                    char* prow = smem + lr * ROW2;
+                    const int2 rg = s_rng[pixl];
+                    const int ro = s_res[pixl];
+                    const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
+                    const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) {
+                        Philox4 rr{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
+                            const int slot = (col >> 5) * 64 + (col & 31);          // hi half; the lo half sits 32 slots on
+                            const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
+                            float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
+                                          __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
+                            if (G.res) {
+                                const uint16_t* rp = reinterpret_cast<const uint16_t*>(G.res) + (size_t)ro * a.res_cstride + bc0 * 2 + slot;
+                                const uint2 rh = *reinterpret_cast<const uint2*>(rp), rl = *reinterpret_cast<const uint2*>(rp + 32);
+                                v[0] += (bf16_to_f32(rh.x & 0xFFFFu) + bf16_to_f32(rl.x & 0xFFFFu)) * epi_scale;
+                                v[1] += (bf16_to_f32(rh.x >> 16) + bf16_to_f32(rl.x >> 16)) * epi_scale;
+                                v[2] += (bf16_to_f32(rh.y & 0xFFFFu) + bf16_to_f32(rl.y & 0xFFFFu)) * epi_scale;
+                                v[3] += (bf16_to_f32(rh.y >> 16) + bf16_to_f32(rl.y >> 16)) * epi_scale;
+                            }
+                            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                            uint2 hi, lo;
+                            hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+                            lo.x = pack_bf16x2(v[0] - bf16_to_f32(hi.x & 0xFFFFu), v[1] - bf16_to_f32(hi.x >> 16));
+                            lo.y = pack_bf16x2(v[2] - bf16_to_f32(hi.y & 0xFFFFu), v[3] - bf16_to_f32(hi.y >> 16));
+                            if (drop) {                       // dropout contract v2, as in the bf16 epilogue below
+                                if ((g4 & 1) == 0)
+                                    rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img,
+                                                       rng_seed_lo, rng_seed_hi);
+                                const uint32_t m0 = keep_mask_u16x2((g4 & 1) ? rr.z : rr.x, thr_m1_x2);
+                                const uint32_t m1 = keep_mask_u16x2((g4 & 1) ? rr.w : rr.y, thr_m1_x2);
+                                hi.x &= m0; lo.x &= m0; hi.y &= m1; lo.y &= m1;
+                            }
+                            const int ch = slot >> 3;
+                            *reinterpret_cast<uint2*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = hi;
+                            *reinterpret_cast<uint2*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = lo;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int q = tid; q < PPASS * (CPR2 / 2); q += THREADS) {       // a (hi chunk, lo chunk) pair per item
+                    const int lr = q / (CPR2 / 2), hc = q % (CPR2 / 2);
+                    const int ch = (hc >> 2) * 8 + (hc & 3);
+                    const int rem = lr % WPP;
+                    const int pixl = (lr / WPP) * WTP + (pass * JP + rem / 32) * 32 + (rem & 31);
+                    const int off = s_off[pixl];
+                    if (off < 0) continue;
+                    const char* prow = smem + lr * ROW2;
+                    const uint4 vh = *reinterpret_cast<const uint4*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4));
+                    const uint4 vl = *reinterpret_cast<const uint4*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4));
+                    const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 * 2 + ch * 8;
+                    *reinterpret_cast<uint4*>(out16 + e) = vh;
+                    *reinterpret_cast<uint4*>(out16 + e + 32) = vl;
+                    if (G.out_relu) {                 // relu(hi + lo): the pair survives iff hi is not negative
+                        auto keep = [](uint32_t h) { return ~(((h >> 15) & 0x00010001u) * 0xFFFFu); };
+                        const uint32_t k0 = keep(vh.x), k1 = keep(vh.y), k2 = keep(vh.z), k3 = keep(vh.w);
+                        uint16_t* o2 = reinterpret_cast<uint16_t*>(G.out_relu);
+                        *reinterpret_cast<uint4*>(o2 + e) = make_uint4(vh.x & k0, vh.y & k1, vh.z & k2, vh.w & k3);
+                        *reinterpret_cast<uint4*>(o2 + e + 32) = make_uint4(vl.x & k0, vl.y & k1, vl.z & k2, vl.w & k3);
+                    }
+                }
+                if (pass + 1 < EPASS || n + 1 < fan) __syncthreads();
             }
         }
         return;
@@ -812,7 +947,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 
 // One tile per workgroup.  XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous
 // range of pixel tiles so that neighbouring tiles (which share their 3x3 halo rows) share an L2.
-template <int BC, int BP, int WC, int WP, int ABL, bool XR>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bx = blockIdx.x;
@@ -820,7 +955,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    conv_tile<BC, BP, WC, WP, ABL, XR>(a, blockIdx.z, bx, blockIdx.y, smem);
+    conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, blockIdx.z, bx, blockIdx.y, smem);
 }
 
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
@@ -864,13 +999,13 @@ static hipError_t launch_xr_persistent(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BC, int BP, int WC, int WP, int ABL, bool XR = false>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR = false, bool SPLIT = false>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
     const int nx = (a.M + BP - 1) / BP, ny = a.cout_pad / BC;
-    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, XR>;
+    auto kern = conv_igemm_kernel<BC, BP, WC, WP, ABL, XR, SPLIT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -903,11 +1038,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     const RowEnt e = a.rows[m];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += G.bias[co + k];
+    const int slot = a.split ? (co >> 5) * 64 + (co & 31) : co;      // bf16x3: hi half of the (hi, lo) pair, lo 32 slots on
     if (G.res) {
-        const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)e.res_off * a.res_cstride + co);
+        const uint16_t* rp = reinterpret_cast<const uint16_t*>(G.res) + (size_t)e.res_off * a.res_cstride + slot;
+        const uint4 r = *reinterpret_cast<const uint4*>(rp);
         const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32(rw[k] & 0xFFFFu); v[2 * k + 1] += bf16_to_f32(rw[k] >> 16); }
+        if (a.split) {
+            const uint4 rl = *reinterpret_cast<const uint4*>(rp + 32);
+            const uint32_t lw[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32(lw[k] & 0xFFFFu); v[2 * k + 1] += bf16_to_f32(lw[k] >> 16); }
+        }
     }
     if (a.flags & CONV_RELU) {
 #pragma unroll
@@ -921,8 +1064,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     }
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-    const size_t off = (size_t)e.out_off * a.out_cstride + co;
+    const size_t off = (size_t)e.out_off * a.out_cstride + slot;
     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + off) = o;
+    if (a.split) {
+        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+        uint4 l;
+        uint32_t* lw = &l.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lw[k] = pack_bf16x2(v[2 * k] - bf16_to_f32(ow[k] & 0xFFFFu), v[2 * k + 1] - bf16_to_f32(ow[k] >> 16));
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + off + 32) = l;
+        if (G.out_relu) {
+            auto keep = [](uint32_t h) { return ~(((h >> 15) & 0x00010001u) * 0xFFFFu); };
+            const uint32_t k0 = keep(o.x), k1 = keep(o.y), k2 = keep(o.z), k3 = keep(o.w);
+            uint16_t* o2 = reinterpret_cast<uint16_t*>(G.out_relu);
+            *reinterpret_cast<uint4*>(o2 + off) = make_uint4(o.x & k0, o.y & k1, o.z & k2, o.w & k3);
+            *reinterpret_cast<uint4*>(o2 + off + 32) = make_uint4(l.x & k0, l.y & k1, l.z & k2, l.w & k3);
+        }
+        return;
+    }
     if (G.out_relu) {
         uint4 r;
         r.x = relu_bf16x2(o.x); r.y = relu_bf16x2(o.y); r.z = relu_bf16x2(o.z); r.w = relu_bf16x2(o.w);
@@ -979,15 +1138,26 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (forced == 128) big = false;
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
+    if (a.split) {                                   // bf16x3: generic loop only (no row reuse, no fused 1x1, no ablation builds)
+        if (a.xreuse || a.variant != 0 || a.cin % 128 != 0) return hipErrorInvalidValue;
+        for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
+    }
     if (a.ksplit > 1) {
         if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & CONV_DROPOUT) || a.variant != 0)
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
-        hipError_t e = a.cout_pad % 128 == 0 ? launch_cfg<128, 128, 2, 2, 0>(a, s) : launch_cfg<64, 128, 1, 4, 0>(a, s);
+        hipError_t e;
+        if (a.split) e = a.cout_pad % 128 == 0 ? launch_cfg<128, 128, 2, 2, 0, false, true>(a, s) : launch_cfg<64, 128, 1, 4, 0, false, true>(a, s);
+        else e = a.cout_pad % 128 == 0 ? launch_cfg<128, 128, 2, 2, 0>(a, s) : launch_cfg<64, 128, 1, 4, 0>(a, s);
         if (e != hipSuccess) return e;
         const long q = (long)a.M * (a.cout_pad / 8);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((q + 255) / 256), a.groups), dim3(256), 0, s, a);
         return hipGetLastError();
+    }
+    if (a.split) {
+        if (big) return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
+        if (a.cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2, 0, false, true>(a, s);
+        return launch_cfg<64, 128, 1, 4, 0, false, true>(a, s);
     }
     const int variant = a.variant;
     if (a.xreuse) {

@@ -87,7 +87,8 @@ struct bod_context {
     float* splitk_partial = nullptr; size_t splitk_elems = 0;        // fp32 partial sums of the split-K layers
     uint8_t* d_frames_u8 = nullptr; size_t frames_u8_cap = 0;     // staging for bod_upload_frames_u8 (plain hipMalloc, grows)
     char* stem_out = nullptr;
-    int es = 2;                                          // bytes per activation / weight element (2 = bf16, 4 = fp32)
+    int es = 2;                                          // bytes per activation / weight CHANNEL (2 = bf16; 4 = fp32, or a (hi, lo) bf16 pair)
+    bool split = false;                                  // bf16x3 precision: (hi, lo) bf16 pairs, three MFMA products (conv_igemm.hip)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
     char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
     char* head_act_t[3][4] = {{nullptr}};            // training: one buffer per tower layer
@@ -238,8 +239,9 @@ bod_status pack_conv(bod_context* h, const std::string& name, const std::string&
     pc.cout = cout; pc.taps = kh * kw; pc.kw = kw; pc.cin = cin;
     pc.cout_pad = ((cout + cout_pad_to - 1) / cout_pad_to) * cout_pad_to;
     const size_t nw = (size_t)pc.cout_pad * pc.taps * cin;
-    std::vector<uint16_t> w(h->es == 2 ? nw : 0, 0);
-    std::vector<float> w32(h->es == 4 ? nw : 0, 0.f);
+    const bool as_f32 = h->es == 4 && !h->split;
+    std::vector<uint16_t> w(as_f32 ? 0 : nw * (h->split ? 2 : 1), 0);
+    std::vector<float> w32(as_f32 ? nw : 0, 0.f);
     std::vector<float> bias(pc.cout_pad, 0.f);
     for (int o = 0; o < cout; ++o) {
         bias[o] = (float)shift[o];
@@ -247,12 +249,18 @@ bod_status pack_conv(bod_context* h, const std::string& name, const std::string&
             for (int c = 0; c < cin; ++c) {
                 const double v = (double)k->data[((size_t)t * cin + c) * cout + o] * scale[o];
                 const size_t idx = ((size_t)o * pc.taps + t) * cin + c;
-                if (h->es == 2) w[idx] = f2bf((float)v); else w32[idx] = (float)v;
+                if (h->split) {            // (hi, lo) pair of the fp32 weight: 32 hi then 32 lo per 64-slot group
+                    const float f = (float)v;
+                    const uint16_t hi = f2bf(f);
+                    const size_t slot = ((size_t)o * pc.taps + t) * 2 * cin + (size_t)(c >> 5) * 64 + (c & 31);
+                    w[slot] = hi; w[slot + 32] = f2bf(f - bf2f(hi));
+                } else if (h->es == 2) w[idx] = f2bf((float)v);
+                else w32[idx] = (float)v;
             }
     }
     BODCHK(h->dalloc(&pc.w, nw * h->es, false));
     BODCHK(h->dalloc(&pc.bias, bias.size(), false));
-    HIPCHK(h, hipMemcpyAsync(pc.w, h->es == 2 ? (const void*)w.data() : (const void*)w32.data(), nw * h->es,
+    HIPCHK(h, hipMemcpyAsync(pc.w, as_f32 ? (const void*)w32.data() : (const void*)w.data(), nw * h->es,
                              hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -268,6 +276,14 @@ ConvArgs base_args(const PackedConv& pc, const RowEnt* rows, int M, int in_cstri
     a.out_cstride = out_cstride; a.res_cstride = out_cstride; a.groups = 1;
     a.fan_count = 1; a.fan_stride = 0;
     return a;
+}
+
+// bf16x3 precision: the kernel counts (hi, lo) SLOTS wherever the bf16 mode counts channels of a pixel (kernels.h, ConvArgs::split)
+void to_split_args(ConvArgs* a) {
+    a->split = 1;
+    a->cin *= 2; a->in_cstride *= 2; a->res_cstride *= 2;
+    if (!(a->flags & CONV_OUT_F32)) a->out_cstride *= 2;
+    for (int g = 0; g < 3; ++g) a->g[g].in_coff *= 2;
 }
 
 // conv + folded BN (+residual) (+ReLU) between two planes
@@ -302,9 +318,9 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     // Split-K for layers with too few output tiles to fill the chip and a long reduction (P6 always; most of
     // stage 3-5 at batch 1): enough splits for >= ~256 workgroups, each keeping >= 4 K-tiles.
     static const bool splitk_on = [] { const char* e = getenv("BOD_CONV_SPLITK"); return !e || atoi(e) != 0; }();
-    if (splitk_on && h->es == 2) {
+    if (splitk_on && (h->es == 2 || h->split)) {
         const long tiles = (long)((op.conv.M + 127) / 128) * (pc.cout_pad % 128 == 0 ? pc.cout_pad / 128 : pc.cout_pad / 64);
-        const int chunks = pc.cin / 64;
+        const int chunks = pc.cin * (h->split ? 2 : 1) / 64;          // K-tiles per tap (bf16x3: 32 channels per K-tile)
         int S = 1;
         while (tiles * S < 256 && S * 2 <= 16 && chunks % (S * 2) == 0 && (long)pc.taps * (chunks / (S * 2)) >= 4) S *= 2;
         if (S > 1) {
@@ -544,7 +560,7 @@ bod_status build_plan(bod_context* h) {
     // Activation row reuse for the per-sample 3x3 tower layers: re-pack the rows into 256-slot tiles made
     // of runs of x-adjacent pixels and list each tile's extended input rows (kernels.h, ConvArgs::ext).
     RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
-    bool xreuse = h->es == 2 && !train_mode;
+    bool xreuse = h->es == 2 && !train_mode;          // (bf16x3 runs on the generic loop: es == 4 there)
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -664,6 +680,7 @@ bod_status build_plan(bod_context* h) {
         BODCHK(h->dalloc(&h->splitk_partial, h->splitk_elems));
         for (Op& o : h->ops) if (o.kind == Op::CONV && o.conv.ksplit > 1) o.conv.partial = h->splitk_partial;
     }
+    if (h->split) for (Op& o : h->ops) if (o.kind == Op::CONV) to_split_args(&o.conv);
     return BOD_OK;
 }
 
@@ -738,7 +755,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                                            c.image_w, h->sh, h->sw, h->stream));
                 break;
             case Op::POOL:
-                HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->es == 4, c.batch,
+                HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->split ? 2 : (h->es == 4 ? 1 : 0), c.batch,
                                            h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
                 break;
             case Op::CONV: {
@@ -752,7 +769,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
                     HIPCHK(h, hipEventRecord(e0, h->stream));
                 }
-                HIPCHK(h, h->es == 4 ? launch_conv_igemm_f32(op.conv, h->stream) : launch_conv_igemm(op.conv, h->stream));
+                HIPCHK(h, (h->es == 4 && !h->split) ? launch_conv_igemm_f32(op.conv, h->stream) : launch_conv_igemm(op.conv, h->stream));
                 if (timed) {
                     HIPCHK(h, hipEventRecord(e1, h->stream));
                     h->ev_head.emplace_back(e0, e1);
@@ -882,9 +899,10 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) return bail(h->fail(BOD_ERR_INVALID_ARG, "dropout_rate must be in [0,1)"));
     if (c.num_categorical_draws < 1 || c.num_categorical_draws > 1024) return bail(h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range"));
     if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
-    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32)
-        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0) or BOD_PRECISION_FP32 (1)"));
-    h->es = c.precision == BOD_PRECISION_FP32 ? 4 : 2;
+    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32 && c.precision != BOD_PRECISION_BF16X3)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0), BOD_PRECISION_FP32 (1) or BOD_PRECISION_BF16X3 (2)"));
+    h->es = c.precision == BOD_PRECISION_BF16 ? 2 : 4;
+    h->split = c.precision == BOD_PRECISION_BF16X3;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
@@ -1098,7 +1116,10 @@ bod_status bod_get_pyramid(bod_handle h, int32_t l, float* out) {
             for (int x = 0; x < ww; ++x) {
                 const size_t pix = ((size_t)b * h->Ppad + h->lvl_off[l] + (size_t)(y + 1) * pitch + (x + 1)) * 256;
                 float* d = out + (((size_t)b * hh + y) * ww + x) * 256;
-                if (h->es == 2) {
+                if (h->split) {
+                    const uint16_t* s = reinterpret_cast<const uint16_t*>(tmp.data()) + pix * 2;
+                    for (int ch = 0; ch < 256; ++ch) { const int slot = (ch >> 5) * 64 + (ch & 31); d[ch] = bf2f(s[slot]) + bf2f(s[slot + 32]); }
+                } else if (h->es == 2) {
                     const uint16_t* s = reinterpret_cast<const uint16_t*>(tmp.data()) + pix;
                     for (int ch = 0; ch < 256; ++ch) d[ch] = bf2f(s[ch]);
                 } else {
@@ -1386,8 +1407,9 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           int32_t round_output_bf16, int32_t precision, float* out) {
     bod_context ctx;                      // scratch context: owns the temporary device buffers
     bod_context* h = &ctx;
-    const bool f32 = precision == BOD_PRECISION_FP32;
-    h->es = f32 ? 4 : 2;
+    const bool f32 = precision == BOD_PRECISION_FP32, x3 = precision == BOD_PRECISION_BF16X3;
+    h->es = (f32 || x3) ? 4 : 2;
+    h->split = x3;
     auto done = [&](bod_status s) {
         if (s != BOD_OK) g_create_error = h->err;
         if (h->stream) hipStreamSynchronize(h->stream);
@@ -1398,7 +1420,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     };
     if (!x || !w || !out || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || stride > 2)
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad argument"));
-    if (precision != BOD_PRECISION_BF16 && !f32) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad precision"));
+    if (precision != BOD_PRECISION_BF16 && !f32 && !x3) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad precision"));
     if (f32 && round_output_bf16) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: round_output_bf16 is meaningless in fp32 precision"));
     if (Cin % 64 != 0 || ((round_output_bf16 || (dropout_rate > 0.f && !f32)) && Cout % 4 != 0))
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: Cin must be a multiple of 64 (and Cout of 4 for bf16 output); got %d, %d", Cin, Cout));
@@ -1420,30 +1442,38 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     auto run = [&]() -> bod_status {
         Plane in, res;
         BODCHK(new_plane(h, &in, B, H, W, Cin));
-        std::vector<uint16_t> hx(f32 ? 0 : (size_t)B * in.bstride * Cin, 0);
+        // bf16x3: a pixel holds 2 * C slots, channel c -> hi at (c / 32) * 64 + c % 32, lo 32 slots further on
+        auto put_split = [](std::vector<uint16_t>& dst, size_t pix_slot0, int c, float v) {
+            const uint16_t hi = f2bf(v);
+            const size_t slot = pix_slot0 + (size_t)(c >> 5) * 64 + (c & 31);
+            dst[slot] = hi; dst[slot + 32] = f2bf(v - bf2f(hi));
+        };
+        std::vector<uint16_t> hx(f32 ? 0 : (size_t)B * in.bstride * Cin * (x3 ? 2 : 1), 0);
         std::vector<float> hx32(f32 ? (size_t)B * in.bstride * Cin : 0, 0.f);
         for (int b = 0; b < B; ++b)
             for (int y = 0; y < H; ++y)
                 for (int xx = 0; xx < W; ++xx)
                     for (int c = 0; c < Cin; ++c) {
-                        const size_t di = ((size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1)) * Cin + c;
+                        const size_t pix = (size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1);
+                        const size_t di = pix * Cin + c;
                         const float v = x[(((size_t)b * H + y) * W + xx) * Cin + c];
-                        if (f32) hx32[di] = v; else hx[di] = f2bf(v);
+                        if (f32) hx32[di] = v; else if (x3) put_split(hx, pix * 2 * Cin, c, v); else hx[di] = f2bf(v);
                     }
         HIPCHK(h, hipMemcpyAsync(in.d, f32 ? (const void*)hx32.data() : (const void*)hx.data(),
                                  (size_t)B * in.bstride * Cin * h->es, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (residual) {
             BODCHK(new_plane(h, &res, B, OH, OW, Cout));
-            std::vector<uint16_t> hr(f32 ? 0 : (size_t)B * res.bstride * Cout, 0);
+            std::vector<uint16_t> hr(f32 ? 0 : (size_t)B * res.bstride * Cout * (x3 ? 2 : 1), 0);
             std::vector<float> hr32(f32 ? (size_t)B * res.bstride * Cout : 0, 0.f);
             for (int b = 0; b < B; ++b)
                 for (int y = 0; y < OH; ++y)
                     for (int xx = 0; xx < OW; ++xx)
                         for (int c = 0; c < Cout; ++c) {
-                            const size_t di = ((size_t)b * res.bstride + (size_t)(y + 1) * res.pitch + (xx + 1)) * Cout + c;
+                            const size_t pix = (size_t)b * res.bstride + (size_t)(y + 1) * res.pitch + (xx + 1);
+                            const size_t di = pix * Cout + c;
                             const float v = residual[(((size_t)b * OH + y) * OW + xx) * Cout + c];
-                            if (f32) hr32[di] = v; else hr[di] = f2bf(v);
+                            if (f32) hr32[di] = v; else if (x3) put_split(hr, pix * 2 * Cout, c, v); else hr[di] = f2bf(v);
                         }
             HIPCHK(h, hipMemcpyAsync(res.d, f32 ? (const void*)hr32.data() : (const void*)hr.data(),
                                      (size_t)B * res.bstride * Cout * h->es, hipMemcpyHostToDevice, h->stream));
@@ -1459,7 +1489,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         const size_t n_out = (size_t)B * OH * OW * Cout;
         float* d_out32 = nullptr; uint16_t* d_out16 = nullptr;
         const bool f32_out = f32 || (!round_output_bf16 && !drop);
-        if (f32_out) BODCHK(h->dalloc(&d_out32, n_out)); else BODCHK(h->dalloc(&d_out16, n_out));
+        if (f32_out) BODCHK(h->dalloc(&d_out32, n_out)); else BODCHK(h->dalloc(&d_out16, n_out * (x3 ? 2 : 1)));
         std::vector<RowEnt> rows((size_t)B * OH * OW);
         size_t r = 0;
         for (int b = 0; b < B; ++b)
@@ -1490,15 +1520,24 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                 BODCHK(h->dalloc(&a.partial, (size_t)S * a.M * a.cout_pad));
             }
         }
+        if (x3) to_split_args(&a);
         HIPCHK(h, f32 ? launch_conv_igemm_f32(a, h->stream) : launch_conv_igemm(a, h->stream));
         if (f32_out) {
             HIPCHK(h, hipMemcpyAsync(out, d_out32, n_out * 4, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
         } else {
-            std::vector<uint16_t> ho(n_out);
-            HIPCHK(h, hipMemcpyAsync(ho.data(), d_out16, n_out * 2, hipMemcpyDeviceToHost, h->stream));
+            std::vector<uint16_t> ho(n_out * (x3 ? 2 : 1));
+            HIPCHK(h, hipMemcpyAsync(ho.data(), d_out16, ho.size() * 2, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            for (size_t i = 0; i < n_out; ++i) out[i] = bf2f(ho[i]);
+            if (x3) {
+                for (size_t px = 0; px < n_out / Cout; ++px)
+                    for (int c = 0; c < Cout; ++c) {
+                        const size_t slot = px * 2 * Cout + (size_t)(c >> 5) * 64 + (c & 31);
+                        out[px * Cout + c] = bf2f(ho[slot]) + bf2f(ho[slot + 32]);
+                    }
+            } else {
+                for (size_t i = 0; i < n_out; ++i) out[i] = bf2f(ho[i]);
+            }
         }
         return BOD_OK;
     };

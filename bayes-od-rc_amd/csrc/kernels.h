@@ -81,6 +81,10 @@ struct ConvArgs {
     // recorded in a hipGraph (training step) can be replayed with a new dropout seed / image id (nullptr in inference).
     const uint32_t* dyn_rng;
     uint32_t sample_base;  // added to every MC sample index before it enters the dropout counter (sample sharding)
+    // bf16x3 precision mode: activations / weights / residuals are (hi, lo) bf16 pairs, 32 hi then 32 lo per 64-slot group
+    // (conv_igemm.hip); cin, in_cstride, res_cstride, in_coff and -- for non-fp32 outputs -- out_cstride count SLOTS (2 per
+    // channel), cout_pad / cout_valid stay in channels.
+    int32_t split;
 };
 constexpr int XR_EXT_ROWS = 320;
 
@@ -101,8 +105,9 @@ hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv
 // 7x7 s2 VALID conv (fp32 image, fp32 folded weights [7][7][3][64]) + bias + ReLU -> bf16 [B,oh,ow,64]
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s);
-// ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on bf16 [B,ih,iw,64] -> padded-plane bf16 output
-hipError_t launch_stem_pool(const void* in, void* out, int f32, int B, int ih, int iw, int oh, int ow,
+// ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on [B,ih,iw,64] -> padded-plane output.  mode 0: bf16 -> bf16; 1: fp32 -> fp32;
+// 2: fp32 -> (hi, lo) bf16 pairs (bf16x3 precision)
+hipError_t launch_stem_pool(const void* in, void* out, int mode, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,9 @@ from . import _lib
 from ._lib import BodConfig, BodSizes, as_f32, fptr, iptr
 
 _KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
+# bod_config.precision (include/bayesod.h): bf16 = throughput path; fp32 = exact-fp32 MFMA; bf16x3 = (hi, lo) bf16 pairs with
+# three MFMA products, the 1e-3 end-to-end parity mode on the bf16 matrix pipe
+PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2}
 
 
 def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
@@ -43,9 +46,9 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
     cfg.nms_variant = {'A': 0, 'B': 1}[nms_variant]
     cfg.num_categorical_draws = int(num_categorical_draws)
     cfg.has_covar_head = int(bool(has_covar_head))
-    if precision not in ('bf16', 'fp32'):
-        raise ValueError("precision must be 'bf16' or 'fp32'")
-    cfg.precision = int(precision == 'fp32')
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (sorted(PRECISIONS),))
+    cfg.precision = PRECISIONS[precision]
     cfg.mc_sample_base, cfg.mc_ensemble_size = int(mc_sample_base), int(mc_ensemble_size)
     cfg.training = int(bool(training))
     if int(backbone_depth) not in (50, 101):
@@ -398,7 +401,7 @@ def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=N
     residual = as_f32(residual) if residual is not None else None
     st = lib.bod_stage_conv(device, fptr(x), b, h, wd, cin, fptr(w), fptr(bias), kh, kw, cout, stride,
                             int(padding == "same"), int(relu), fptr(residual), float(dropout_rate), seed,
-                            layer_id, image_id, int(round_output_bf16), int(precision == 'fp32'), fptr(out))
+                            layer_id, image_id, int(round_output_bf16), PRECISIONS[precision], fptr(out))
     _lib.check(lib, None, st)
     return out
 

@@ -33,7 +33,7 @@ typedef enum {
 enum { BOD_RANK_SCORE = 0, BOD_RANK_JOINT_ENTROPY = 1 };
 enum { BOD_NMS_VARIANT_A = 0, BOD_NMS_VARIANT_B = 1 };      /* SURVEY.md App. A.8 */
 enum { BOD_HEAD_CLS = 0, BOD_HEAD_REG = 1, BOD_HEAD_COV = 2 };
-enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1 };
+enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1, BOD_PRECISION_BF16X3 = 2 };
 
 /* Mirrors model_config / testing_config of src/retina_net/configs/retinanet_bdd_covar.yaml
  * (:61-143) plus the geometry the reference derives at run time. */
@@ -60,9 +60,12 @@ typedef struct {
     int32_t has_covar_head;      /* 'regression_covar' in output_names (retinanet_model.py:50)        */
     float   kitti_scale_h, kitti_scale_w; /* orig/net size; 0 => dataset != 'kitti'
                                     (inference_utils.py:147-167)                                      */
-    int32_t precision;           /* BOD_PRECISION_BF16 (default, throughput path: bf16 storage + bf16 MFMA)
-                                    or BOD_PRECISION_FP32 (fp32 storage + exact-fp32 MFMA: matches the
-                                    reference's fp32 arithmetic end to end; ~1/10 of the speed)          */
+    int32_t precision;           /* BOD_PRECISION_BF16 (default, throughput path: bf16 storage + bf16 MFMA),
+                                    BOD_PRECISION_FP32 (fp32 storage + exact-fp32 MFMA: the reference's fp32
+                                    arithmetic end to end; ~1/10 of the speed) or BOD_PRECISION_BF16X3 (every value a
+                                    (hi, lo) bf16 pair, products hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32
+                                    accumulation: within 1e-3 of the float64 reference END TO END at about a third
+                                    of the bf16 rate -- the parity mode of the throughput path)                 */
     int32_t mc_sample_base;      /* index of this handle's first MC sample in the dropout RNG streams (default 0).
                                     A handle with mc_samples = n and base = r*n computes samples r*n .. r*n+n-1 of
                                     a larger ensemble bit-identically: the MC-sample-sharded multi-GPU mode

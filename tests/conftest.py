@@ -56,7 +56,7 @@ def rel_err(a, b, floor):
 
 
 def compare_posterior(got, ref, uniforms, tol=1e-3, mean_floor=1.0, cov_tol=None, exact_counts=True, min_checked=20,
-                      max_ambiguous=5e-3, boundary_eps=1e-5):
+                      max_ambiguous=2e-2, boundary_eps=1e-5):
     """Posterior of the device (`got` = Engine.get_posterior) against the oracle's (`ref` =
     bayes_od_posterior(..., return_debug=True)) WITHOUT an all-or-nothing guard on the kept set.
 
@@ -64,7 +64,8 @@ def compare_posterior(got, ref, uniforms, tol=1e-3, mean_floor=1.0, cov_tol=None
     the device (fp32 cumsum vs the oracle's dtype; `boundary_eps` is raised when the class probabilities themselves come
     from a different forward pass, e.g. the end-to-end tests); they are flagged `ambiguous` and excluded.  Every other anchor
     must agree on the background filter, and the anchors both sides keep are compared element-wise.  Returns the
-    number of anchors compared (asserted >= min_checked, so the test can never pass vacuously)."""
+    number of anchors compared (asserted >= min_checked, so the test can never pass vacuously).  The expected ambiguous
+    rate is draws x classes x 2 boundary_eps = 30 x 8 x 2e-5 = 0.5 % of the anchors at the default."""
     a = ref["keep"].shape[0]
     cdf = np.cumsum(ref["mean_probs"], axis=1)
     t = uniforms.astype(np.float64) * cdf[:, -1:]

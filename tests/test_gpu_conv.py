@@ -173,3 +173,67 @@ def test_split_k_matches_oracle_and_unsplit(monkeypatch, b, h, w, cin, cout, k, 
     # one bf16 ulp, plus the fp32 re-association error of the K-long sum where the result nearly cancels
     assert np.all(np.abs(got - plain)[mism] <= np.abs(plain[mism]) * 2.0 ** -7 + 1e-4 * rms)
     assert np.array_equal(got, network.bf16_round(got))
+
+
+# ---------------------------------------------------------------------------------------------- bf16x3 precision
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,padding", CASES)
+def test_bf16x3_conv_matches_oracle(b, h, w, cin, cout, k, stride, padding):
+    """bf16x3 precision: both operands as (hi, lo) bf16 pairs, products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16,
+    fp32 accumulate -- against float64 on the UNROUNDED fp32 operands.  Representation error 2^-17 per operand, the
+    dropped lo*lo term 2^-16 of a product: 1e-4 of the output RMS over up to K = 4608 terms (fp32 MFMA mode: 2e-5)."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(cin + 3 * cout + k + w)
+    x, wt, bias = _case(rng, b, h, w, cin, cout, k)
+    got = stage_conv(x, wt, bias, stride=stride, padding=padding, precision="bf16x3")
+    ref = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), stride, padding)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert got.shape == ref.shape
+    assert rel_err(got, ref, floor=rms) < 1e-4
+
+
+def test_bf16x3_residual_relu_dropout_and_pair_store():
+    """The (hi, lo) pair store of the bf16x3 epilogue (values leave as two bf16, exact to 2^-17), with shortcut + ReLU and
+    with the head-tower dropout (same Philox contract: dropped elements are exactly zero in both halves)."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network, philox
+    rng = np.random.default_rng(18)
+    b, h, w = 2, 9, 11
+    x, wt, bias = _case(rng, b, h, w, 128, 256, 3)
+    res = rng.normal(0, 1, (b, h, w, 256)).astype(np.float32)
+    conv = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same")
+    got = stage_conv(x, wt, bias, padding="same", relu=True, residual=res, precision="bf16x3", round_output_bf16=True)
+    ref = np.maximum(conv + res, 0)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    assert rel_err(got, ref, floor=rms) < 1e-4 and np.all(got >= 0)
+    got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=0.3, seed=11, layer_id=2, image_id=5, precision="bf16x3")
+    keep = np.stack([philox.dropout_keep_mask(11, 5, s, 2, h * w, 256, 0.3).reshape(h, w, 256) for s in range(b)])
+    ref = np.maximum(conv, 0) * np.float64(np.float32(1.0 / 0.7)) * keep
+    assert np.all(got[~keep] == 0)
+    assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 1e-4
+    # a 64-channel layer (one cout tile of the small configuration) and a strided 1x1 with shortcut
+    x, wt, bias = _case(rng, 1, 12, 10, 64, 64, 3)
+    got = stage_conv(x, wt, bias, padding="same", relu=True, precision="bf16x3", round_output_bf16=True)
+    ref = np.maximum(network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same"), 0)
+    assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 1e-4
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,padding,split,res", [
+    (2, 16, 16, 2048, 256, 3, 2, "same", 8, False),
+    (1, 8, 8, 1024, 512, 1, 1, "valid", 4, True),
+])
+def test_bf16x3_split_k(monkeypatch, b, h, w, cin, cout, k, stride, padding, split, res):
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(cin + cout + split + 1)
+    x, wt, bias = _case(rng, b, h, w, cin, cout, k)
+    oh = -(-h // stride) if padding == "same" else (h - k) // stride + 1
+    ow = -(-w // stride) if padding == "same" else (w - k) // stride + 1
+    residual = rng.normal(0, 1, (b, oh, ow, cout)).astype(np.float32) if res else None
+    monkeypatch.setenv("BOD_STAGE_KSPLIT", str(split))
+    got = stage_conv(x, wt, bias, stride=stride, padding=padding, relu=res, residual=residual, round_output_bf16=True, precision="bf16x3")
+    monkeypatch.delenv("BOD_STAGE_KSPLIT")
+    ref = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), stride, padding)
+    if res:
+        ref = np.maximum(ref + residual, 0)
+    assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 1e-4

@@ -101,9 +101,11 @@ def test_geometry_mismatch_is_rejected():
         Engine(make_config((100, 100), batch=1, mc_samples=2))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("hw,batch,n,depth", [((128, 128), 2, 3, 50), ((96, 160), 1, 1, 50), ((96, 96), 1, 2, 101)])
-def test_fp32_mode_end_to_end(hw, batch, n, depth):
-    """precision='fp32' (fp32 storage + exact-fp32 MFMA): the whole forward pass -- stem, 53 backbone
+def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
+    """precision='fp32' (fp32 storage + exact-fp32 MFMA) and precision='bf16x3' ((hi, lo) bf16 pairs, three products on the
+    bf16 MFMA: the parity mode of the throughput path): the whole forward pass -- stem, 53 backbone
     convs, FPN, MC-dropout heads -- agrees with the float64 oracle element-wise within the 1e-3 bar of
     BASELINE.json's north_star (observed ~1e-5, fp32 summation noise through ~50 layers)."""
     from bayes_od_rc_amd import synthetic
@@ -111,11 +113,12 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth):
     seed, first = 99, 3
     w = synthetic.make_weights(depth=depth)           # depth 101: the build's ResNet-101 option (BASELINE config 5)
     frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
-    eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision="fp32", backbone_depth=depth))
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision=precision, backbone_depth=depth))
     eng.load_weights(w)
     eng.forward(frames, seed=seed, first_image_id=first)
     cls, box, cov = eng.get_raw()
     pyr = [eng.get_pyramid(l) for l in range(5)]
+    worst = 0.0
     for b in range(batch):
         _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P)
         items = [("P%d" % (l + 3), pyr[l][b], f64["_pyramid"][l][0]) for l in range(5)]
@@ -124,12 +127,15 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth):
         for name, got, t in items:
             rms = _rms(t)
             err = float(np.max(np.abs(got - t) / (np.abs(t) + rms)))
+            worst = max(worst, err)
             assert err < 1e-3, (name, err)
             assert _rms(got - t) / rms < 1e-4, (name, _rms(got - t) / rms)
+    print("end-to-end forward, precision %s, %dx%d depth %d: max rel err %.2e" % (precision, hw[0], hw[1], depth, worst))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("hw", [(192, 624), (360, 640)])
-def test_non_square_and_odd_pyramids(hw):
+def test_non_square_and_odd_pyramids(hw, precision):
     """Half-scale versions of BASELINE config 4 (KITTI 384x1248 -> 192x624: odd level widths 78/39/20/10/5)
     and of the real BDD frame (720x1280 -> 360x640: 45->23->12->6->3, nearest up-sampling with a
     non-integer ratio, stride-2 SAME on odd sizes).  fp32 mode against the float64 oracle, 1e-3."""
@@ -138,7 +144,7 @@ def test_non_square_and_odd_pyramids(hw):
     n, seed = 2, 17
     w = synthetic.make_weights()
     frames = synthetic.make_frames(1, hw[0], hw[1], seed=9)
-    eng = Engine(make_config(hw, batch=1, mc_samples=n, precision="fp32"))
+    eng = Engine(make_config(hw, batch=1, mc_samples=n, precision=precision))
     eng.load_weights(w)
     eng.forward(frames, seed=seed, first_image_id=0)
     cls, box, cov = eng.get_raw()
@@ -150,6 +156,8 @@ def test_non_square_and_odd_pyramids(hw):
     for got, key in ((cls[0], "anchors_class_predictions"), (box[0], "anchors_box_predictions"), (cov[0], "_covar_params")):
         t = f64[key]
         assert float(np.max(np.abs(got - t) / (np.abs(t) + _rms(t)))) < 1e-3, key
+    if precision != "fp32":
+        return
     # and the bf16 path stays at its noise floor on the same geometry
     eng16 = Engine(make_config(hw, batch=1, mc_samples=n))
     eng16.load_weights(w)

@@ -148,8 +148,9 @@ def test_async_pipeline_equals_synchronous():
                 assert np.array_equal(a[key][img, :k], b[key][img, :k])
 
 
-def test_fp32_pipeline_matches_oracle_end_to_end():
-    """fp32 precision mode, whole pipeline against the float64 oracle run from the raw frame: same
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_fp32_pipeline_matches_oracle_end_to_end(precision):
+    """fp32 / bf16x3 precision modes, whole pipeline against the float64 oracle run from the raw frame: same
     kept anchors, same soft-NMS centres, detections within 1e-3 (images whose categorical draw or
     centre ordering sits on a float rounding boundary are skipped, they are covered stage-wise)."""
     from bayes_od_rc_amd import synthetic
@@ -161,7 +162,7 @@ def test_fp32_pipeline_matches_oracle_end_to_end():
     cfg = {"output_names": ["classification", "regression", "regression_covar"], "mc_dropout_samples": n,
            "header": {"dropout_rate": 0.3, "num_classes": 7, "anchors_per_location": 9}}
     w = synthetic.make_weights(cls_fg_bias=-1.0)
-    model = RetinaNetModel(cfg, precision="fp32")
+    model = RetinaNetModel(cfg, precision=precision)
     model.load_weights(w)
     anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
     pipe = BayesOdPipeline(model, hw, batch, BAYES_CFG, NMS_CFG, use_full_covar=True, anchors=anchors)
@@ -217,6 +218,65 @@ def test_run_inference_cli_writes_reference_layout(tmp_path, monkeypatch):
     assert isinstance(recs, list)
     for r in recs[:5]:
         assert set(r) == {"name", "timestep", "category", "bbox", "score"} and len(r["bbox"]) == 4
+
+
+def test_run_inference_processes_the_tail_frames(tmp_path, monkeypatch):
+    """5 frames at --batch 4: the reference's loop handles every frame (run_inference.py:137); the last one goes through a
+    batch-1 handle instead of being dropped."""
+    import os
+    monkeypatch.setenv("BAYESOD_DATA_DIR", str(tmp_path))
+    from bayes_od_rc_amd import run_inference
+    root = run_inference.main(["--gpu_device", "0", "--data_split", "test", "--synthetic", "5",
+                               "--image_size", "128", "128", "--batch", "4"])
+    for i in range(5):
+        assert os.path.exists(os.path.join(root, "mean", "%06d.npy" % i)), i
+
+
+def test_pipelines_sharing_an_engine_keep_their_own_kitti_scale():
+    """KITTI frames of 370x1224 and 375x1242 resize to the same network input, so their pipelines share one handle
+    (the model caches engines per network size / batch / N).  Each pipeline must re-apply its own S = orig / net factors
+    (inference_utils.py:147-167) before every batch: A, B, A interleaved gives A's result twice, and B = A rescaled."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.inference_utils import BayesOdPipeline
+    hw, n = (128, 416), 4
+    model = _model(n)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(1, hw[0], hw[1], seed=3)
+    pa = BayesOdPipeline(model, hw, 1, BAYES_CFG, NMS_CFG, dataset_name="kitti", orig_size=(370, 1224), anchors=anchors)
+    pb = BayesOdPipeline(model, hw, 1, BAYES_CFG, NMS_CFG, dataset_name="kitti", orig_size=(375, 1242), anchors=anchors)
+    assert pa.engine is pb.engine
+    a1 = pa(frames, seed=4, first_image_id=0)[0]
+    b1 = pb(frames, seed=4, first_image_id=0)[0]
+    a2 = pa(frames, seed=4, first_image_id=0)[0]
+    assert a1[1].shape[0] > 0
+    for x, y in zip(a1, a2):
+        assert np.array_equal(x, y)
+    assert a1[1].shape == b1[1].shape
+    ratio = np.asarray([375 / 370, 1242 / 1224] * 2, np.float32)
+    assert np.allclose(b1[1], a1[1] * ratio, rtol=1e-5)
+    assert not np.allclose(b1[1], a1[1], rtol=1e-4)
+
+
+def test_engine_loads_a_converted_checkpoint_without_the_unbuilt_reg_layer():
+    """A real TF checkpoint has no variables for RegHeader.conv_4 (never called): the converter's output therefore
+    lacks pyramid_regression_3, and the engine must load it and compute the same outputs."""
+    from bayes_od_rc_amd import convert_checkpoint as cc, synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    from test_convert_checkpoint import FakeReader, _fake_checkpoint
+    w = synthetic.make_weights()
+    conv = cc.convert(FakeReader(_fake_checkpoint(w)))
+    assert "pyramid_regression_3" not in conv
+    frames = synthetic.make_frames(1, 128, 128, seed=2)
+    outs = []
+    for weights in (w, conv):
+        eng = Engine(make_config((128, 128), batch=1, mc_samples=2))
+        eng.load_weights(weights)
+        eng.forward(frames, seed=3, first_image_id=0)
+        outs.append([x.copy() for x in eng.get_raw()])
+        eng.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("parts,batch", [(2, 1), (3, 2), (6, 1)])
