@@ -384,6 +384,7 @@ bod_status ensure_raw(bod_context* h) {
 }
 
 bod_status train_init(bod_context* h);          // train_impl.inc
+bod_status train_forward_only(bod_context* h, const float* dev, uint64_t seed, uint32_t first_image_id);
 const uint32_t* train_dyn_rng(bod_context* h);
 void train_destroy(bod_context* h);
 
@@ -1070,6 +1071,7 @@ bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uin
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const float* dev = nullptr;
     BODCHK(stage_images(h, images, on_device, &dev));
+    if (h->train) return train_forward_only(h, dev, seed, first_image_id);     // model(x, 'training'): dropout on, N = 1
     return run_forward(h, dev, seed, first_image_id);
 }
 

@@ -7,8 +7,8 @@
 
 The engine (device buffers, row tables, packed weights) is built on the first call for the
 image shape seen, like ``@tf.function`` tracing per input signature (inference_utils.py:13).
-Only 'testing' and 'validation' modes exist here: training is outside the hot path
-(SURVEY.md section 8f).
+'testing' = N MC-dropout samples, 'validation' = one deterministic sample, 'training' = one sample with dropout on
+(retinanet_model.py:113-147) through a training handle; the training STEP itself is run_training.Trainer.
 """
 import numpy as np
 
@@ -77,17 +77,18 @@ class RetinaNetModel(object):
         np.savez(path, **flat)
 
     # -- engine ----------------------------------------------------------------------------
-    def engine_for(self, image_hw, batch=None, mc_samples=None, **testing):
+    def engine_for(self, image_hw, batch=None, mc_samples=None, training=False, **testing):
         if self._weights is None:
             raise ValueError("no weights loaded: call model.load_weights(...) (the reference raises "
                              "ValueError for a missing checkpoint, run_inference.py:56-58)")
         batch = batch or self.batch
         n = mc_samples or self.mc_dropout_samples
-        key = (int(image_hw[0]), int(image_hw[1]), batch, n, self.precision, self.backbone_depth)
+        precision = 'bf16' if training else self.precision          # training handles are bf16 (include/bayesod.h)
+        key = (int(image_hw[0]), int(image_hw[1]), batch, n, precision, self.backbone_depth, bool(training))
         cfg = make_config(image_hw, batch=batch, mc_samples=n, num_classes=self.num_classes + 1,
                           anchors_per_location=self.anchors_per_location, device=self.device,
                           dropout_rate=self.dropout_rate, has_covar_head=self.compute_covar,
-                          precision=self.precision, backbone_depth=self.backbone_depth, **testing)
+                          precision=precision, backbone_depth=self.backbone_depth, training=training, **testing)
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(cfg)
@@ -105,10 +106,13 @@ class RetinaNetModel(object):
         x = np.asarray(input_tensor, dtype=np.float32)
         if x.ndim != 4 or x.shape[-1] != 3:
             raise ValueError("expected an NHWC image batch with 3 channels, got shape %s" % (x.shape,))
-        if train_val_test == 'training':
-            raise ValueError("training mode is outside the MI355X inference hot path")
+        if train_val_test not in ('training', 'validation', 'testing'):
+            raise ValueError("train_val_test must be 'training', 'validation' or 'testing', got %r" % (train_val_test,))
+        # 'training': no MC tiling, dropout ON (retinanet_model.py:113-129) -- a training handle's forward;
+        # 'validation': no tiling, dropout off (:130-147); 'testing': N tiled samples, dropout on iff N > 1 (:73-112)
+        training = train_val_test == 'training'
         n = self.mc_dropout_samples if train_val_test == 'testing' else 1
-        eng = self.engine_for(x.shape[1:3], batch=x.shape[0], mc_samples=n)
+        eng = self.engine_for(x.shape[1:3], batch=x.shape[0], mc_samples=n, training=training)
         seed = self.seed if seed is None else seed
         if image_id is None:
             image_id = self.image_counter

@@ -121,7 +121,9 @@ bod_status bod_set_anchors(bod_handle h, const float* anchors_vuhw, int32_t num_
 /* model(image, train_val_test='testing')  (retinanet_model.py:67-112).
  * images: [batch,H,W,3] fp32 normalised BGR (sample_dict['image_normalized']), host pointer or,
  * if images_on_device != 0, a device pointer already resident in HBM.
- * seed / first_image_id key the Philox dropout + categorical streams (DESIGN.md RNG contract). */
+ * seed / first_image_id key the Philox dropout + categorical streams (DESIGN.md RNG contract).
+ * On a handle created with training = 1 this is model(image, train_val_test='training') (retinanet_model.py:113-147):
+ * one sample with dropout ON, batch-norm frozen, the current (trained) master weights. */
 bod_status bod_forward(bod_handle h, const float* images, int32_t images_on_device,
                        uint64_t seed, uint32_t first_image_id);
 /* prediction_dict tensors (src/core/constants.py:61-63), copied to host:

@@ -258,6 +258,37 @@ def test_pipelines_sharing_an_engine_keep_their_own_kitti_scale():
     assert not np.allclose(b1[1], a1[1], rtol=1e-4)
 
 
+def test_model_call_modes_training_validation_testing():
+    """RetinaNetModel.call's three modes (retinanet_model.py:67-147): 'testing' tiles N samples with dropout, 'validation' is
+    one deterministic pass, 'training' is one pass with dropout ON -- the training handle's forward.  The training-mode
+    outputs are checked against the oracle's head towers with the Philox masks of sample 0 (bf16 noise floor)."""
+    from bayes_od_rc_amd import synthetic
+    from oracle import network, philox
+    n, hw, seed, img = 3, (128, 128), 17, 6
+    model = _model(n)
+    w = synthetic.make_weights(cls_fg_bias=-1.0)
+    x = synthetic.make_frames(1, hw[0], hw[1], seed=8)
+    val = {k: v.copy() for k, v in model(x, train_val_test='validation', seed=seed, image_id=img).items()}
+    tr = {k: v.copy() for k, v in model(x, train_val_test='training', seed=seed, image_id=img).items()}
+    te = model(x, train_val_test='testing', seed=seed, image_id=img)
+    key = "anchors_class_predictions"
+    assert val[key].shape[0] == 1 and tr[key].shape[0] == 1 and te[key].shape[0] == n
+    assert not np.array_equal(val[key], tr[key])                  # dropout is on in training mode
+    tr2 = model(x, train_val_test='training', seed=seed, image_id=img)
+    assert np.array_equal(tr[key], tr2[key])                      # and keyed by (seed, image id)
+    eng = model.engine_for(hw, batch=1, mc_samples=1, training=True)
+    nm = network.make_numerics(w, "literal", np.float64)
+    c5, c4, c3 = network.feature_extractor(nm, x[:1])
+    pyr = network.feature_decoder(nm, c5, c4, c3)
+    km = lambda s_, lid: philox.dropout_keep_mask(seed, img, s_, lid, eng.P, 256, 0.3)
+    for head, k, c in (("cls", "anchors_class_predictions", 8), ("reg", "anchors_box_predictions", 4)):
+        ref = network.head_tower(nm, pyr, head, 1, km, 0.3, c)
+        d = np.sqrt(((tr[k] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+        assert d < 2e-2, (head, d)
+    with pytest.raises(ValueError):
+        model(x, train_val_test='inference')
+
+
 def test_engine_loads_a_converted_checkpoint_without_the_unbuilt_reg_layer():
     """A real TF checkpoint has no variables for RegHeader.conv_4 (never called): the converter's output therefore
     lacks pyramid_regression_3, and the engine must load it and compute the same outputs."""
