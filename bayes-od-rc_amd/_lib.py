@@ -77,6 +77,8 @@ SIGNATURES = {
     "bod_collect": (C.c_int, [_H, C.c_int32, _I, _F, _F, _F, _F]),
     "bod_upload_images": (C.c_int, [_H, _F]),
     "bod_upload_frames_u8": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, _F, C.c_int32]),
+    "bod_upload_frames_u8_async": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, _F, C.c_int32, C.c_int32]),
+    "bod_device_images_buffer": (C.c_void_p, [_H, C.c_int32]),
     "bod_device_images": (C.c_void_p, [_H]),
     "bod_synchronize": (C.c_int, [_H]),
     "bod_stage_conv_wgrad": (C.c_int, [C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, C.c_int32, C.c_int32,

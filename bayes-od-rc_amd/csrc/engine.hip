@@ -86,6 +86,14 @@ struct bod_context {
     float* d_images = nullptr;
     float* splitk_partial = nullptr; size_t splitk_elems = 0;        // fp32 partial sums of the split-K layers
     uint8_t* d_frames_u8 = nullptr; size_t frames_u8_cap = 0;     // staging for bod_upload_frames_u8 (plain hipMalloc, grows)
+    // pipelined input path (bod_upload_frames_u8_async): two image buffers (0 = d_images), their uint8 staging, a copy stream;
+    // ev_img_ready: preprocess of a buffer finished (the forward waits on it); ev_img_free: the stem that read it finished
+    // (the next upload into the same buffer waits on it)
+    float* d_images_b[2] = {nullptr, nullptr}; uint8_t* d_u8_b[2] = {nullptr, nullptr}; size_t u8_cap_b[2] = {0, 0};
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_img_ready[2] = {nullptr, nullptr}, ev_img_free[2] = {nullptr, nullptr};
+    bool img_ready_pending[2] = {false, false}, img_free_pending[2] = {false, false};
+    int cur_img_buf = -1;
     char* stem_out = nullptr;
     int es = 2;                                          // bytes per activation / weight CHANNEL (2 = bf16; 4 = fp32, or a (hi, lo) bf16 pair)
     bool split = false;                                  // bf16x3 precision: (hi, lo) bf16 pairs, three MFMA products (conv_igemm.hip)
@@ -719,6 +727,7 @@ bod_status alloc_post(bod_context* h) {
     }
     h->select_slot(0);
     BODCHK(h->dalloc(&h->d_images, (size_t)c.batch * c.image_h * c.image_w * 3));
+    h->d_images_b[0] = h->d_images;
     return BOD_OK;
 }
 
@@ -754,6 +763,10 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
             case Op::STEM:
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, h->stream));
+                if (h->cur_img_buf >= 0 && !h->train) {           // the frames are consumed: the copy stream may refill this buffer
+                    HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], h->stream));
+                    h->img_free_pending[h->cur_img_buf] = true;
+                }
                 break;
             case Op::POOL:
                 HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->split ? 2 : (h->es == 4 ? 1 : 0), c.batch,
@@ -845,7 +858,19 @@ bod_status run_cluster(bod_context* h, hipStream_t st) {
 
 bod_status stage_images(bod_context* h, const float* images, int on_device, const float** dev) {
     if (!images) return h->fail(BOD_ERR_INVALID_ARG, "images is NULL");
-    if (on_device) { *dev = images; return BOD_OK; }
+    h->cur_img_buf = -1;
+    if (on_device) {
+        for (int k = 0; k < 2; ++k)
+            if (images == h->d_images_b[k] && h->d_images_b[k]) {
+                h->cur_img_buf = k;
+                if (h->img_ready_pending[k]) {           // filled by bod_upload_frames_u8_async on the copy stream
+                    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_img_ready[k], 0));
+                    h->img_ready_pending[k] = false;
+                }
+            }
+        *dev = images;
+        return BOD_OK;
+    }
     const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
     HIPCHK(h, hipMemcpyAsync(h->d_images, images, bytes, hipMemcpyHostToDevice, h->stream));
     *dev = h->d_images;
@@ -934,6 +959,12 @@ bod_status bod_destroy(bod_handle h) {
     if (h->iou_scratch) hipFree(h->iou_scratch);
     if (h->affinity) hipFree(h->affinity);
     if (h->d_frames_u8) hipFree(h->d_frames_u8);
+    if (h->copy) { hipStreamSynchronize(h->copy); hipStreamDestroy(h->copy); }
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_u8_b[k]) hipFree(h->d_u8_b[k]);
+        if (h->ev_img_ready[k]) hipEventDestroy(h->ev_img_ready[k]);
+        if (h->ev_img_free[k]) hipEventDestroy(h->ev_img_free[k]);
+    }
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1015,11 +1046,8 @@ bod_status bod_upload_images(bod_handle h, const float* host_images) {
     return BOD_OK;
 }
 
-bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
-                                int32_t aspect_resize) {
-    if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
+static bod_status preproc_geometry(bod_handle h, int32_t src_h, int32_t src_w, const float* rgb_means, int32_t aspect_resize, PreprocArgs* out) {
     const bod_config& c = h->cfg;
-    HIPCHK(h, hipSetDevice(c.device));
     PreprocArgs a{};
     a.B = c.batch; a.sh = src_h; a.sw = src_w; a.H = c.image_h; a.W = c.image_w; a.resize = aspect_resize ? 1 : 0;
     a.rh = src_h; a.rw = src_w;
@@ -1041,6 +1069,17 @@ bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h,
     a.pad_y = std::max(fdiv2(dh), 0); a.pad_x = std::max(fdiv2(dw), 0);
     a.vis_h = std::min(a.rh, c.image_h); a.vis_w = std::min(a.rw, c.image_w);
     for (int k = 0; k < 3; ++k) a.mean[k] = rgb_means[k];
+    *out = a;
+    return BOD_OK;
+}
+
+bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
+                                int32_t aspect_resize) {
+    if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
+    const bod_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    PreprocArgs a{};
+    BODCHK(preproc_geometry(h, src_h, src_w, rgb_means, aspect_resize, &a));
     const size_t bytes = (size_t)c.batch * src_h * src_w * 3;
     if (bytes > h->frames_u8_cap) {
         if (h->d_frames_u8) { HIPCHK(h, hipStreamSynchronize(h->stream)); hipFree(h->d_frames_u8); h->d_frames_u8 = nullptr; h->frames_u8_cap = 0; }
@@ -1055,10 +1094,52 @@ bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h,
     return BOD_OK;
 }
 
+bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
+                                      int32_t aspect_resize, int32_t buffer) {
+    if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
+    if (buffer < 0 || buffer > 1) return h->fail(BOD_ERR_INVALID_ARG, "bod_upload_frames_u8_async: buffer must be 0 or 1");
+    const bod_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    PreprocArgs a{};
+    BODCHK(preproc_geometry(h, src_h, src_w, rgb_means, aspect_resize, &a));
+    if (!h->copy) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_img_ready[k], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_img_free[k], hipEventDisableTiming));
+        }
+    }
+    if (!h->d_images_b[buffer]) BODCHK(h->dalloc(&h->d_images_b[buffer], (size_t)c.batch * c.image_h * c.image_w * 3));
+    const size_t bytes = (size_t)c.batch * src_h * src_w * 3;
+    if (bytes > h->u8_cap_b[buffer]) {
+        HIPCHK(h, hipStreamSynchronize(h->copy));
+        if (h->d_u8_b[buffer]) hipFree(h->d_u8_b[buffer]);
+        h->d_u8_b[buffer] = nullptr; h->u8_cap_b[buffer] = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_u8_b[buffer]), bytes) != hipSuccess)
+            return h->fail(BOD_ERR_OOM, "bod_upload_frames_u8_async: %zu bytes of staging", bytes);
+        h->u8_cap_b[buffer] = bytes;
+    }
+    // do not overwrite frames a forward pass still has to read (its stem records ev_img_free), nor frames of an upload
+    // nobody consumed yet (same stream: ordered)
+    if (h->img_free_pending[buffer]) { HIPCHK(h, hipStreamWaitEvent(h->copy, h->ev_img_free[buffer], 0)); h->img_free_pending[buffer] = false; }
+    else if (buffer == 0) HIPCHK(h, hipStreamSynchronize(h->stream));       // buffer 0 doubles as the synchronous d_images
+    a.src = h->d_u8_b[buffer]; a.dst = h->d_images_b[buffer];
+    HIPCHK(h, hipMemcpyAsync(h->d_u8_b[buffer], rgb, bytes, hipMemcpyHostToDevice, h->copy));
+    HIPCHK(h, launch_preprocess(a, h->copy));
+    HIPCHK(h, hipEventRecord(h->ev_img_ready[buffer], h->copy));
+    h->img_ready_pending[buffer] = true;
+    return BOD_OK;
+}
+
+const float* bod_device_images_buffer(bod_handle h, int32_t buffer) {
+    return (h && buffer >= 0 && buffer <= 1) ? h->d_images_b[buffer] : nullptr;
+}
+
 const float* bod_device_images(bod_handle h) { return h ? h->d_images : nullptr; }
 
 bod_status bod_synchronize(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    if (h->copy) HIPCHK(h, hipStreamSynchronize(h->copy));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->side));
     h->side_pending[0] = h->side_pending[1] = false;

@@ -143,6 +143,25 @@ class Engine(object):
         self._chk(self.lib.bod_upload_frames_u8(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[2],
                                                 fptr(m), int(bool(aspect_resize))))
 
+    def upload_frames_u8_async(self, frames_rgb_u8, buffer, means=None, aspect_resize=False):
+        """Pipelined upload (``bod_upload_frames_u8_async``): copy + preprocessing run on the handle's copy stream into
+        image buffer 0/1 and return at once; pass ``image_buffer=buffer`` to forward()/infer()/infer_async().  The array must
+        be C-contiguous uint8 (pinned host memory for a truly asynchronous copy) and stay alive until that batch is
+        collected."""
+        from . import constants
+        a = frames_rgb_u8
+        if a.dtype != np.uint8 or not a.flags['C_CONTIGUOUS'] or a.ndim != 4 or a.shape[0] != self.B or a.shape[3] != 3:
+            raise ValueError("expected C-contiguous uint8 frames of shape (%d, h, w, 3), got %s %s" % (self.B, a.dtype, a.shape))
+        m = np.ascontiguousarray(constants.MEANS_DICT['ImageNet'] if means is None else means, dtype=np.float32)
+        self._chk(self.lib.bod_upload_frames_u8_async(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[2],
+                                                      fptr(m), int(bool(aspect_resize)), int(buffer)))
+
+    def _device_images(self, image_buffer):
+        ptr = self.lib.bod_device_images(self.h) if image_buffer is None else self.lib.bod_device_images_buffer(self.h, int(image_buffer))
+        if not ptr:
+            raise ValueError("image buffer %r has not been filled" % (image_buffer,))
+        return ptr
+
     def get_images(self):
         """The device image buffer [B,H,W,3] float32 (normalised BGR) copied to the host."""
         import torch
@@ -152,28 +171,29 @@ class Engine(object):
                             device=torch.device("cuda", self.cfg.device))
         return t.cpu().numpy()
 
-    def forward(self, images=None, seed=0, first_image_id=0):
-        """images=None => use the device-resident buffer filled by upload_images()."""
+    def forward(self, images=None, seed=0, first_image_id=0, image_buffer=None):
+        """images=None => use the device-resident buffer filled by upload_images() (or buffer `image_buffer` of
+        upload_frames_u8_async)."""
         if images is None:
-            ptr = self.lib.bod_device_images(self.h)
+            ptr = self._device_images(image_buffer)
             self._chk(self.lib.bod_forward(self.h, ptr, 1, seed, first_image_id))
         else:
             a = self._img(images)
             self._chk(self.lib.bod_forward(self.h, a.ctypes.data, 0, seed, first_image_id))
 
-    def infer(self, images=None, seed=0, first_image_id=0):
+    def infer(self, images=None, seed=0, first_image_id=0, image_buffer=None):
         if images is None:
-            ptr = self.lib.bod_device_images(self.h)
+            ptr = self._device_images(image_buffer)
             self._chk(self.lib.bod_infer(self.h, ptr, 1, seed, first_image_id))
         else:
             a = self._img(images)
             self._chk(self.lib.bod_infer(self.h, a.ctypes.data, 0, seed, first_image_id))
 
-    def infer_async(self, images=None, seed=0, first_image_id=0):
+    def infer_async(self, images=None, seed=0, first_image_id=0, image_buffer=None):
         """Enqueue a whole pass; returns the slot ticket for collect()."""
         slot = C.c_int32(-1)
         if images is None:
-            ptr = self.lib.bod_device_images(self.h)
+            ptr = self._device_images(image_buffer)
             self._chk(self.lib.bod_infer_async(self.h, ptr, 1, seed, first_image_id, C.byref(slot)))
         else:
             a = self._img(images)

@@ -219,6 +219,16 @@ bod_status bod_upload_images(bod_handle h, const float* host_images);
  * (kitti_dataset_handler.py:120-148).  A quarter of the PCIe bytes of bod_upload_images. */
 bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w,
                                 const float* rgb_means, int32_t aspect_resize);
+/* Pipelined form of the same upload: the host->device copy of `rgb` (pinned host memory for a truly asynchronous copy)
+ * and the device preprocessing run on the handle's COPY stream into image buffer 0 or 1 and return at once, so the PCIe
+ * transfer of batch i+1 overlaps the convolutions of batch i (the reference gets the same overlap from tf.data's
+ * prefetch, run_inference.py:71-72).  Pass bod_device_images_buffer(h, buffer) with images_on_device = 1 to bod_forward /
+ * bod_infer / bod_infer_async: the forward waits for the upload, and the next upload into the same buffer waits until the
+ * stem of that forward has consumed the frames.  `rgb` must stay valid until that forward has been enqueued AND the copy
+ * has completed (bod_synchronize, or a later bod_collect of that batch).  Buffer 0 is bod_device_images(). */
+bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w,
+                                      const float* rgb_means, int32_t aspect_resize, int32_t buffer);
+const float* bod_device_images_buffer(bod_handle h, int32_t buffer);
 const float* bod_device_images(bod_handle h);
 bod_status bod_synchronize(bod_handle h);
 

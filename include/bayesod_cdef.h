@@ -92,6 +92,9 @@ bod_status bod_collect(bod_handle h, int32_t slot, int32_t* num_detections, floa
 bod_status bod_upload_images(bod_handle h, const float* host_images);
 bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w,
                                 const float* rgb_means, int32_t aspect_resize);
+bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w,
+                                      const float* rgb_means, int32_t aspect_resize, int32_t buffer);
+const float* bod_device_images_buffer(bod_handle h, int32_t buffer);
 const float* bod_device_images(bod_handle h);
 bod_status bod_synchronize(bod_handle h);
 bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin,

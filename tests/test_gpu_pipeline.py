@@ -258,6 +258,45 @@ def test_pipelines_sharing_an_engine_keep_their_own_kitti_scale():
     assert not np.allclose(b1[1], a1[1], rtol=1e-4)
 
 
+def test_pipelined_u8_upload_equals_synchronous_upload():
+    """bod_upload_frames_u8_async (copy stream, two image buffers, event hand-off to the forward and back) feeds the
+    pipelined inference path the same frames as the synchronous upload: identical detections, clip after clip, while
+    the upload of clip i+1 is enqueued under the convolutions of clip i."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, batch, n = (128, 128), 2, 3
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+    eng.load_weights(synthetic.make_weights(cls_fg_bias=-1.0))
+    eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3)))
+    rng = np.random.default_rng(3)
+    clips = [rng.integers(0, 256, size=(batch,) + hw + (3,), dtype=np.uint8) for _ in range(5)]
+    sync = []
+    for i, c in enumerate(clips):
+        eng.upload_frames_u8(c)
+        eng.infer(None, seed=2, first_image_id=batch * i)
+        sync.append({k: v.copy() for k, v in eng.get_detections_batch().items()})
+    got, pending = [], []
+    eng.upload_frames_u8_async(clips[0], 0)
+    for i in range(len(clips)):
+        pending.append(eng.infer_async(None, seed=2, first_image_id=batch * i, image_buffer=i & 1))
+        if i + 1 < len(clips):
+            eng.upload_frames_u8_async(clips[i + 1], (i + 1) & 1)
+        if len(pending) > 1:
+            got.append({k: v.copy() for k, v in eng.collect(pending.pop(0)).items()})
+    got.append({k: v.copy() for k, v in eng.collect(pending.pop(0)).items()})
+    assert len(got) == len(sync)
+    for a, b in zip(sync, got):
+        assert np.array_equal(a["num"], b["num"]) and a["num"].min() > 0
+        for img in range(batch):
+            k = a["num"][img]
+            for key in ("scores", "means", "covs", "counts"):
+                assert np.array_equal(a[key][img, :k], b[key][img, :k])
+    with pytest.raises(ValueError):
+        eng.upload_frames_u8_async(clips[0].astype(np.float32), 0)
+    eng.close()
+
+
 def test_model_call_modes_training_validation_testing():
     """RetinaNetModel.call's three modes (retinanet_model.py:67-147): 'testing' tiles N samples with dropout, 'validation' is
     one deterministic pass, 'training' is one pass with dropout ON -- the training handle's forward.  The training-mode
