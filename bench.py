@@ -10,12 +10,22 @@ only inter-GPU traffic is one RCCL gather of the final detection records per ste
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+The ONE JSON line carries, beside the headline (bf16, BASELINE config 3):
+  roofline       the dominant kernel's achieved TFLOP/s from HIP events inside the timed region
+  cpu_baseline   the CPU port timed on this host (rank 0, N=1 only)
+  parity_mode    the bf16x3 precision mode -- the throughput path's 1e-3 end-to-end mode -- timed in the same run, with
+                 its max relative error against the CPU port's fp32 forward of the same frame and Philox masks
+  secondary      BASELINE configs 2 (N=1 forward), 4's geometry (384x1248, N=30, one GPU) and 5 (ResNet-101 training step)
+  value_with_h2d the headline with the uint8 frames crossing PCIe every step (copy stream, overlapped with the convolutions)
 """
 import argparse
+import datetime
 import json
 import os
 import sys
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -23,7 +33,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 ANCHOR_CFG = {"layers": [3, 4, 5, 6, 7], "aspect_ratios": [[1.0, 1.0], [1.0, 2.0], [2.0, 1.0]],
-              "scales": [1.0, 1.26, 1.59]}
+              "scales": [1.0, 1.26, 1.59], "min_positive_iou": 0.5, "max_negative_iou": 0.4}
 BAYES_CFG = {"ranking_method": "score", "dirichlet_prior": {"type": "non_informative"},
              "gaussian_prior": {"type": "isotropic", "isotropic_variance": 100000.0}}
 NMS_CFG = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
@@ -33,23 +43,52 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # f32-in MFMA = fp32 vector rate (fp32 precis
 # cls foreground bias calibrated so that 500 <= M <= 1500 anchors survive the background filter
 # at 512x512 with synthetic.make_weights() (python bench.py --calibrate)
 CALIBRATED_FG_BIAS = -3.2
+METRIC = "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency"
+# conv FLOPs (2 MACs) of backbone + FPN per 512x512 image, linear in the pixel count
+BACKBONE_FPN_GFLOP_512 = {50: 49.05, 101: 49.05 + 17 * 2.0 * 1024 * (1024 * 256 + 2304 * 256 + 256 * 1024) / 1e9}
+
+
+def head_conv_flops(P):
+    return 2.0 * P * 256 * 2304          # one 3x3 256->256 head conv over one image's pyramid, one sample
+
+
+def head_out_flops(P):
+    return 2.0 * P * 256 * 9 * (8 + 4 + 10)     # the three 1x1 output convs (cls 9x8, box 9x4, cov 9x10 channels)
 
 
 def head_flops_per_image(P, N, dedup=True):
-    conv = 2.0 * P * 256 * 2304
+    conv = head_conv_flops(P)
     if dedup:
         return 3 * conv + N * 8 * conv
     return N * 11 * conv
 
 
-def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0):
+def image_gflop(hw, P, n, depth=50, dedup=True):
+    """De-duplicated conv GFLOP of one image through the whole network: backbone + FPN + heads."""
+    heads = (3 + 8 * n) * head_conv_flops(P) if (dedup and n > 1) else 11 * n * head_conv_flops(P)
+    return (BACKBONE_FPN_GFLOP_512[depth] * 1e9 * (hw[0] * hw[1]) / (512.0 * 512.0) + heads + n * head_out_flops(P)) / 1e9
+
+
+def _rel_errs(got, ref):
+    """(max |got-ref| / (|ref| + rms(ref)),  rms(got-ref) / rms(ref))"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    return float(np.max(np.abs(got - ref) / (np.abs(ref) + rms))), float(np.sqrt(((got - ref) ** 2).mean()) / rms)
+
+
+def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_raw=None, seed=0, first_image_id=0):
     """Reference-literal CPU timing with the oracle (kind='port'): PyTorch-CPU fp32 forward
-    (oracle/torch_ref.py) + NumPy posterior / soft-NMS / clustering, all host cores."""
+    (oracle/torch_ref.py) + NumPy posterior / soft-NMS / clustering, all host cores.
+
+    ``device_raw``: {mode name: (cls, box, cov)} raw head outputs the GPU produced for frame 0 with (seed, first_image_id).
+    The CPU forward of frame 0 then runs with the SAME Philox dropout masks, so the two are directly comparable: the
+    returned ``parity`` maps each mode to its max relative error / relative RMS distance against this CPU forward
+    (north_star: "outputs match the CPU reference within 1e-3 rel on identical inputs, CPU baseline timed in the same run")."""
     import torch
     from oracle import bayes_od, clustering, geometry, network, nms, philox, torch_ref
     tw = torch_ref.prepare(weights)
     # big hosts lose to thread oversubscription on these small convs: probe a few pool sizes on one
-    # head-tower conv and keep the fastest
+    # head-tower conv (median of 3 after a warm-up) and keep the fastest
     import torch.nn.functional as F
     ncpu = os.cpu_count() or 1
     probe_x = torch.randn(n, 256, hw[0] // 8, hw[1] // 8)
@@ -58,20 +97,36 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0):
         torch.set_num_threads(cand)
         with torch.no_grad():
             F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
-            t0 = time.perf_counter()
-            F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
-            dt = time.perf_counter() - t0
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
+                ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[1]
         if dt < best[0]:
             best = (dt, cand)
     threads = best[1]
     torch.set_num_threads(threads)
+    P = anchors.shape[0] // 9
+    masks0 = None
+    if device_raw:      # Philox masks of frame 0, generated before the clock starts (the reference draws its masks inside the op)
+        cache = {}
+
+        def masks0(s, lid):
+            if (s, lid) not in cache:
+                cache[(s, lid)] = philox.dropout_keep_mask(seed, first_image_id, s, lid, P, 256, 0.3)
+            return cache[(s, lid)]
+        for s in range(n):
+            for lid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11):
+                masks0(s, lid)
     done, t_total = 0, 0.0
     parts = {"forward": 0.0, "posterior": 0.0, "nms": 0.0, "cluster": 0.0}
+    parity = {}
     while done < len(frames) and (done == 0 or t_total < seconds_budget):
         t0 = time.perf_counter()
-        out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw)
+        out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw, keep_masks=masks0 if done == 0 else None)
         t1 = time.perf_counter()
-        u = philox.categorical_uniforms(0, done, anchors.shape[0])
+        u = philox.categorical_uniforms(seed, first_image_id + done, anchors.shape[0])
         post = bayes_od.bayes_od_posterior(out, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float32)
         t2 = time.perf_counter()
         corners = post["corners"].astype(np.float32)
@@ -84,12 +139,127 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0):
         parts["forward"] += t1 - t0; parts["posterior"] += t2 - t1
         parts["nms"] += t3 - t2; parts["cluster"] += t4 - t3
         t_total += t4 - t0
+        if done == 0 and device_raw:
+            for mode, (cls, box, cov) in device_raw.items():
+                errs = [_rel_errs(g, out[k]) for g, k in ((cls, "anchors_class_predictions"), (box, "anchors_box_predictions"),
+                                                          (cov, "_covar_params"))]
+                parity[mode] = {"max_rel_err": max(e[0] for e in errs), "rel_rms": max(e[1] for e in errs)}
         done += 1
-    return {"value": done / t_total, "unit": "images/sec", "cores": threads, "kind": "port",
+    base = {"value": done / t_total, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "%d frame(s) of %dx%d at N=%d, reference-literal (11*N head convs, no dedup), "
                       "torch %s fp32 CPU forward + NumPy Bayesian stages; seconds: %s" %
                       (done, hw[0], hw[1], n, torch.__version__,
                        {k: round(v, 2) for k, v in parts.items()})}
+    return base, parity
+
+
+def make_engine(hw, B, n, device, precision="bf16", weights=None, anchors=None, **kw):
+    from bayes_od_rc_amd.engine import Engine, make_config
+    eng = Engine(make_config(hw, batch=B, mc_samples=n, device=device, bayes_od_config=BAYES_CFG,
+                             nms_config=NMS_CFG, use_full_covar=True, precision=precision, **kw))
+    eng.load_weights(weights)
+    if anchors is not None:
+        eng.set_anchors(anchors)
+    return eng
+
+
+def raw_of_image0(eng):
+    """Raw head outputs of image 0 of the last forward (zero-copy device views, one small D2H)."""
+    from bayes_od_rc_amd import distributed as bdist
+    eng.synchronize()
+    v = bdist.raw_views(eng)
+    return tuple(v[k][0].cpu().numpy() for k in ("cls", "box", "cov"))
+
+
+def timed_pipeline(eng, steps, warmup, fwd_only, B, first_id=0, image_buffer=None):
+    """Single-rank pipelined loop (depth 2) over the device-resident batch: seconds for `steps` steps."""
+    pending, host = [], [None, None]
+
+    def step(i):
+        if fwd_only:
+            eng.forward(None, seed=0, first_image_id=first_id + i * B, image_buffer=image_buffer)
+            return
+        pending.append(eng.infer_async(None, seed=0, first_image_id=first_id + i * B, image_buffer=image_buffer))
+        if len(pending) > 1:
+            s = pending.pop(0)
+            host[s] = eng.collect(s, host[s])
+
+    def drain():
+        while pending:
+            s = pending.pop(0)
+            host[s] = eng.collect(s, host[s])
+        eng.synchronize()
+    for i in range(warmup):
+        step(i)
+    drain()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    drain()
+    return time.perf_counter() - t0
+
+
+def secondary_configs(device, weights, lo):
+    """BASELINE.json configs 2, 4 (its geometry on one GPU) and 5, each on its own handle, a few steps each."""
+    import torch
+    from bayes_od_rc_amd import constants, synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    from bayes_od_rc_amd.run_training import synthetic_samples
+    out = []
+
+    def entry(workload, ms, value, unit, gflop_per_unit, units_per_step, note=None):
+        ach = gflop_per_unit * units_per_step / ms          # GFLOP / ms = TFLOP/s
+        e = {"workload": workload, "ms_per_step": round(ms, 3), "value": round(value, 2), "unit": unit,
+             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "algorithmic_gflop_per_unit": round(gflop_per_unit, 1)}}
+        if note:
+            e["note"] = note
+        out.append(e)
+    gen = FpnAnchorGenerator(ANCHOR_CFG)
+    # ---- config 2: ResNet-50 RetinaNet, 512x512, N=1 (no MC): network forward only (raw head outputs)
+    hw, B, n = (512, 512), 256, 1
+    eng = make_engine(hw, B, n, device, weights=weights)
+    eng.upload_images(synthetic.make_frames(B, hw[0], hw[1], seed=lo))
+    steps = 8
+    dt = timed_pipeline(eng, steps, 2, True, B)
+    entry("BASELINE config 2: ResNet-50 RetinaNet, 512x512, N=1 (no MC), forward only (raw head outputs), %d frames/step" % B,
+          dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, 1), B)
+    eng.close()
+    # ---- config 4's geometry on ONE GPU: 384x1248 (KITTI), N=30, full pipeline
+    hw, B, n = (384, 1248), 16, 30
+    eng = make_engine(hw, B, n, device, weights=weights, anchors=gen.generate_all((hw[0], hw[1], 3)))
+    eng.upload_images(synthetic.make_frames(B, hw[0], hw[1], seed=lo))
+    steps = 6
+    dt = timed_pipeline(eng, steps, 2, False, B)
+    entry("BASELINE config 4 geometry on one GPU: ResNet-50 RetinaNet + covar head, N=30 MC-dropout, KITTI 384x1248, full BayesOD "
+          "pipeline, %d frames/step" % B, dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, 30), B)
+    eng.close()
+    # ---- config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (the yaml's minibatch of 3)
+    hw, B = (512, 512), 3
+    samples = synthetic_samples(B, hw, ANCHOR_CFG, 7)
+    eng = Engine(make_config(hw, batch=B, mc_samples=1, device=device, training=True, backbone_depth=101))
+    eng.load_weights(synthetic.make_weights(depth=101))
+    eng.set_anchors(np.asarray(samples[0][constants.ANCHORS_KEY], np.float32))
+    st = lambda k: np.stack([s[k] for s in samples])
+    eng.upload_images(st(constants.IMAGE_NORMALIZED_KEY))
+    targets = (st(constants.ANCHORS_CLASS_TARGETS_KEY), st(constants.ANCHORS_BOX_TARGETS_KEY),
+               st(constants.POSITIVE_ANCHORS_MASK_KEY), st(constants.NEGATIVE_ANCHOR_MASK_KEY))
+    for i in range(3):
+        eng.train_step(None, *targets, seed=1, first_image_id=i * B)
+    steps = 10
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = eng.train_step(None, *targets, seed=1, first_image_id=(3 + i) * B)
+    dt = time.perf_counter() - t0
+    # forward + input-gradient + weight-gradient GEMMs = 3 x the forward's conv FLOPs (no de-duplication at N=1)
+    entry("BASELINE config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (forward, backward, clip, Adam), "
+          "bf16, %d frames of 512x512 (the yaml's minibatch)" % B, dt / steps * 1e3, B * steps / dt, "images/sec",
+          3.0 * image_gflop(hw, eng.P, 1, depth=101, dedup=False), B,
+          note="algorithmic GFLOP = 3 x forward conv FLOPs (forward, dgrad, wgrad GEMMs); total_loss %.3f" % loss["total_loss"])
+    eng.close()
+    torch.cuda.synchronize()
+    return out
 
 
 def main():
@@ -103,13 +273,15 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip parity_mode / secondary / value_with_h2d (headline only)")
     ap.add_argument("--calibrate", action="store_true", help="print the cls foreground bias for M~1000")
     ap.add_argument("--fg-bias", type=float, default=CALIBRATED_FG_BIAS)
     ap.add_argument("--forward-only", action="store_true",
                     help="time RetinaNetModel.call only (BASELINE config 2: raw head outputs); implied by --mc 1, "
                          "where the Bayesian stages are undefined (sample covariance divides by N-1)")
-    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
-                    help="bf16 = throughput path (BASELINE.json north_star); fp32 = reference-exact arithmetic mode")
+    ap.add_argument("--precision", choices=("bf16", "fp32", "bf16x3"), default="bf16",
+                    help="bf16 = throughput path (BASELINE.json north_star); bf16x3 = its 1e-3 end-to-end parity mode; "
+                         "fp32 = exact-fp32 MFMA")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +289,6 @@ def main():
     from bayes_od_rc_amd import synthetic
     from bayes_od_rc_amd import distributed as bdist
     from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
-    from bayes_od_rc_amd.engine import Engine, make_config
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,24 +300,54 @@ def main():
     # BOD_BENCH_BACKEND=gloo + BOD_BENCH_SHARE_GPU=1: exercise the N>1 code path on a ONE-GPU box (all ranks on
     # device 0, records gathered through host memory) -- tests/test_gpu_pipeline.py; the driver's runs use RCCL.
     backend = os.environ.get("BOD_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if os.environ.get("BOD_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    if local_rank >= ndev:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, ndev))
+    print("# bench rank %d/%d: local_rank %d of %d visible GPU(s), backend %s" % (rank, world, local_rank, ndev, backend),
+          file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # every collective is bounded: a dead peer turns into an exception on the survivors, not a hang
+        timeout = datetime.timedelta(seconds=int(os.environ.get("BOD_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     hw, n, B = (args.height, args.width), args.mc, args.batch
     fwd_only = args.forward_only or n < 2
+    out = {"metric": METRIC, "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+           "data": "synthetic"}
+    try:
+        run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only)
+    except BaseException as exc:            # a peer died / a collective timed out / a HIP error: rank 0 still reports, non-zero exit
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            out["error"] = "%s: %s" % (type(exc).__name__, exc)
+            print(json.dumps(out), flush=True)
+        # never re-exec, never wait for the dead peer: leave without the collective teardown
+        os._exit(1)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
+    import torch
+    import torch.distributed as dist
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd import distributed as bdist
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+
     weights = synthetic.make_weights(cls_fg_bias=args.fg_bias)
     anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
-    eng = Engine(make_config(hw, batch=B, mc_samples=n, device=local_rank, bayes_od_config=BAYES_CFG,
-                             nms_config=NMS_CFG, use_full_covar=True, precision=args.precision))
-    eng.load_weights(weights)
-    eng.set_anchors(anchors)
+    eng = make_engine(hw, B, n, local_rank, precision=args.precision, weights=weights, anchors=anchors)
     # this rank's shard of a (world*B)-frame synthetic clip, resident in HBM before timing starts
     lo, hi = bdist.shard_range(world * B, world, rank)
     frames = synthetic.make_frames(hi - lo, hw[0], hw[1], seed=lo)
@@ -175,6 +376,9 @@ def main():
             allrec = bdist.gather_records(rec if backend == "nccl" else rec.cpu(), dst=0)
             if rank == 0:
                 gathered = allrec.cpu()
+            # the pack kernels read the engine's slot buffers on torch's stream: they must have finished before the engine's
+            # side stream may rewrite this slot (two infer_async calls from now)
+            torch.cuda.current_stream().synchronize()
         else:
             host_out[slot] = eng.collect(slot, host_out[slot])
 
@@ -213,14 +417,23 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     drain()
+    t_local = time.perf_counter() - t0          # this rank's own clock, before the closing barrier
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = [B * args.steps / t_local]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([per_rank[0]], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
     total_images = world * B * args.steps
     value = total_images / elapsed
+    out["value"] = round(value, 3)
+    out["ms_per_step"] = round(elapsed / args.steps * 1e3, 3)
     kept = [] if fwd_only else eng.num_kept()
 
     # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM): the launches of the timed region itself
@@ -235,8 +448,8 @@ def main():
             else:
                 eng.infer(None, seed=0, first_image_id=lo + i * world * B)
 
-    conv_flops = 2.0 * eng.P * 256 * 2304          # one 3x3 256->256 head conv over one image's pyramid, one sample
-    out_flops = 2.0 * eng.P * 256 * 9 * (8 + 4 + 10)     # the three 1x1 output convs (cls 9x8, box 9x4, cov 9x10 channels)
+    conv_flops = head_conv_flops(eng.P)
+    out_flops = head_out_flops(eng.P)
     prof_steps = args.steps
     prof = eng.profile_end()
     tower_only = prof["head_conv_launches"] > 0
@@ -247,13 +460,14 @@ def main():
         # they are separate small launches and are not counted here)
         algo_flops = n * 8 * conv_flops * B * prof_steps
         kernel_name = "conv_igemm_kernel<256,256,2,4,0,true> (head towers, 3x3 256->256, layers 1-3)"
-    else:                                # no row-reuse kernel in the plan (fp32 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
+    else:                                # no row-reuse kernel in the plan (fp32 / bf16x3 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))
         eng.profile_begin(which=0)
         more_steps(prof_steps)
         prof = eng.profile_end()
         algo_flops = head_flops_per_image(eng.P, n) * B * prof_steps
-        kernel_name = ("conv_igemm_f32_kernel" if args.precision == "fp32" else "conv_igemm_kernel") + " (head towers, 3x3 256->256)"
+        kernel_name = {"fp32": "conv_igemm_f32_kernel", "bf16x3": "conv_igemm_kernel<..., SPLIT> (3 MFMA products per MAC)",
+                       "bf16": "conv_igemm_kernel"}[args.precision] + " (head towers, 3x3 256->256)"
     if abs(prof["head_conv_flops"] - algo_flops) / algo_flops > 1e-6:       # the plan fused the 1x1 output convs into these launches
         algo_flops += n * out_flops * B * prof_steps
     launches = max(1, prof["head_conv_launches"])
@@ -271,32 +485,38 @@ def main():
                        "avg_launch_ms": round(fo["head_conv_ms"] / fo["head_conv_launches"], 4), "launches_per_step": 1}
         eng.profile_begin(which=0)
         eng.profile_end()
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    # algorithmic MFLOP per MAC-FLOP is 1 in every mode; the bf16x3 mode ISSUES three MFMA products per MAC, so its
+    # matrix-pipe work is 3 x `achieved` (reported as `mfma_issue_tflops`)
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes) when they were taken on this exact configuration, else null
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_head_conv_pmc.json")) as fp:
-            pmc = json.load(fp)
-        c = pmc["config"]
-        if (c["height"], c["width"], c["mc_samples"], c["batch"]) == (hw[0], hw[1], n, B) and args.precision == "bf16":
-            sel = [l for l in pmc["launches"] if ("true>" in l["kernel"]) == tower_only or not tower_only]
-            traffic = int(sum(l["hbm_read_bytes_corrected"] + l["hbm_write_bytes"] for l in sel) / len(sel))
-    except (OSError, KeyError, ValueError):
-        pass
+    for pmc_file in ("round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as fp:
+                pmc = json.load(fp)
+            c = pmc["config"]
+            if (c["height"], c["width"], c["mc_samples"], c["batch"]) == (hw[0], hw[1], n, B) and args.precision == "bf16":
+                sel = [l for l in pmc["launches"] if ("true>" in l["kernel"]) == tower_only or not tower_only]
+                traffic = int(sum(l["hbm_read_bytes_corrected"] + l["hbm_write_bytes"] for l in sel) / len(sel))
+                break
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
     roofline = {"bound": "mfma", "kernel": kernel_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(prof["head_conv_ms"] / launches, 4), "launches_per_step": launches // prof_steps,
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
+    if args.precision == "bf16x3":
+        roofline["mfma_issue_tflops"] = round(3 * achieved, 2)
     if fan_out:
         roofline["other_head_launch"] = fan_out
     # BASELINE.md section 3, "reported beside it": the whole pipeline's de-duplicated conv FLOPs per image x images/sec
     # (backbone + FPN 49.05 GFLOP at 512x512, linear in the pixel count; heads 3 + 8 N convs + N 1x1 sets)
-    image_gflop = (49.05e9 * (hw[0] * hw[1]) / (512.0 * 512.0) + (3 + 8 * n) * conv_flops + n * out_flops) / 1e9
-    roofline["pipeline"] = {"dedup_gflop_per_image": round(image_gflop, 1),
-                            "achieved": round(image_gflop * value / world / 1e3, 2), "unit": "TFLOP/s per GPU",
-                            "frac": round(image_gflop * value / world / 1e3 / peak, 4)}
+    img_gflop = image_gflop(hw, eng.P, n)
+    roofline["pipeline"] = {"dedup_gflop_per_image": round(img_gflop, 1),
+                            "achieved": round(img_gflop * value / world / 1e3, 2), "unit": "TFLOP/s per GPU",
+                            "frac": round(img_gflop * value / world / 1e3 / peak, 4)}
     # per-anchor latency of the aggregate / posterior stage (a9-a11): HIP events around the stage's launches of the timed
     # steps (main stream, between one batch's convolutions and the next)
     post_us_per_anchor = prof["posterior_ms"] * 1e3 / max(1, prof["posterior_launches"]) / (B * eng.A)
@@ -310,27 +530,93 @@ def main():
     known = sum(v for v in stages.values() if v)
     stages["stem_backbone_fpn_and_gaps"] = round(step_ms - known, 3) if tower_only else None
 
-    out = {"metric": "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency",
-           "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-           "data": "synthetic",
-           "config": {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, %s"
-                                  % (n, hw[0], hw[1], "forward only (raw head outputs, BASELINE config 2)" if fwd_only else
-                                     "full BayesOD pipeline (forward+posterior+soft-NMS+cluster-fuse)"),
-                      "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
-                      "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
-                      "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
-                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),
-                      "stages_ms_per_step": stages},
-           "roofline": roofline}
+    out["config"] = {"workload": "ResNet-50 RetinaNet + covar head, N=%d MC-dropout, %dx%d, %s"
+                                 % (n, hw[0], hw[1], "forward only (raw head outputs, BASELINE config 2)" if fwd_only else
+                                    "full BayesOD pipeline (forward+posterior+soft-NMS+cluster-fuse)"),
+                     "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
+                     "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
+                     "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
+                     "per_rank_images_per_sec": [round(v, 1) for v in per_rank],
+                     "visible_gpus": torch.cuda.device_count(),
+                     "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),
+                     "stages_ms_per_step": stages}
+    out["roofline"] = roofline
+
+    extras = rank == 0 and world == 1 and not args.no_secondary and not fwd_only and args.precision == "bf16"
+    device_raw = {}
+    if extras:
+        # ---- value_with_h2d: the same steps with the frames crossing PCIe EVERY step as uint8 (a quarter of the fp32 bytes),
+        # copy + device preprocessing on the handle's copy stream, overlapped with the previous step's convolutions
+        pinned = torch.empty((2, B, hw[0], hw[1], 3), dtype=torch.uint8).pin_memory()
+        rng = np.random.default_rng(lo)
+        pinned[0].numpy()[...] = rng.integers(0, 256, size=(B, hw[0], hw[1], 3), dtype=np.uint8)
+        pinned[1].copy_(pinned[0].flip(0))
+        clips = [pinned[0].numpy(), pinned[1].numpy()]
+        h2d_steps, pend, host2 = max(4, min(10, args.steps)), [], [None, None]
+        eng.upload_frames_u8_async(clips[0], 0)
+        for i in range(2):                                   # warm-up (allocates the second image buffer)
+            pend.append(eng.infer_async(None, seed=0, first_image_id=lo + i * B, image_buffer=i & 1))
+            eng.upload_frames_u8_async(clips[(i + 1) & 1], (i + 1) & 1)
+            if len(pend) > 1:
+                s = pend.pop(0); host2[s] = eng.collect(s, host2[s])
+        while pend:
+            s = pend.pop(0); host2[s] = eng.collect(s, host2[s])
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for i in range(h2d_steps):
+            pend.append(eng.infer_async(None, seed=0, first_image_id=lo + i * B, image_buffer=i & 1))
+            eng.upload_frames_u8_async(clips[(i + 1) & 1], (i + 1) & 1)     # next step's frames, under this step's convolutions
+            if len(pend) > 1:
+                s = pend.pop(0); host2[s] = eng.collect(s, host2[s])
+        while pend:
+            s = pend.pop(0); host2[s] = eng.collect(s, host2[s])
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        out["value_with_h2d"] = {"value": round(B * h2d_steps / dt, 2), "unit": "images/sec", "steps": h2d_steps,
+                                 "ms_per_step": round(dt / h2d_steps * 1e3, 3),
+                                 "input": "uint8 RGB frames from pinned host memory every step (%.0f MB/step), bod_upload_frames_u8_async: "
+                                          "copy stream + device preprocessing, overlapped with the previous step" % (B * hw[0] * hw[1] * 3 / 1e6)}
+        del pinned, clips
+        # raw head outputs of frame 0 with (seed 0, image id lo) for the parity figures of the CPU leg
+        eng.upload_images(frames)
+        eng.forward(None, seed=0, first_image_id=lo)
+        device_raw["bf16"] = raw_of_image0(eng)
+    eng.close()
+    del eng
+
+    if extras:
+        # ---- parity_mode: the bf16x3 precision mode ((hi, lo) bf16 pairs, three MFMA products per MAC) -- the mode in which the
+        # pipeline meets north_star's 1e-3 end to end -- timed in the same run on the same frames
+        Bp = max(1, B // 2)
+        engp = make_engine(hw, Bp, n, local_rank, precision="bf16x3", weights=weights, anchors=anchors)
+        engp.upload_images(frames[:Bp])
+        engp.forward(None, seed=0, first_image_id=lo)
+        device_raw["bf16x3"] = raw_of_image0(engp)
+        p_steps = 5
+        dt = timed_pipeline(engp, p_steps, 2, False, Bp, first_id=lo)
+        out["parity_mode"] = {"precision": "bf16x3", "images_per_sec": round(Bp * p_steps / dt, 2),
+                              "ms_per_step": round(dt / p_steps * 1e3, 3), "frames_per_step": Bp, "steps": p_steps,
+                              "fraction_of_headline": round(Bp * p_steps / dt / value, 4),
+                              "pipeline_tflops": round(image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
+                              "mfma_issue_tflops": round(3 * image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
+                              "max_rel_err": None}
+        engp.close()
+        del engp
+        out["secondary"] = secondary_configs(local_rank, weights, lo)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(hw, n, frames, weights, anchors)
-        out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        base, parity = cpu_baseline(hw, n, frames, weights, anchors, device_raw=device_raw, seed=0, first_image_id=lo)
+        out["cpu_baseline"] = base
+        out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+        if "bf16x3" in parity and "parity_mode" in out:
+            out["parity_mode"]["max_rel_err"] = float("%.3g" % parity["bf16x3"]["max_rel_err"])
+            out["parity_mode"]["rel_rms"] = float("%.3g" % parity["bf16x3"]["rel_rms"])
+            out["parity_mode"]["against"] = ("cpu_baseline's fp32 forward of frame 0 with the same Philox dropout masks: raw head outputs "
+                                             "(class logits, box deltas, covariance parameters), max |d| / (|ref| + rms(ref))")
+            out["parity_mode"]["speedup_vs_cpu_baseline"] = round(out["parity_mode"]["images_per_sec"] / base["value"], 1)
+        if "bf16" in parity:
+            out["config"]["headline_mode_distance_to_cpu_forward"] = {k: float("%.3g" % v) for k, v in parity["bf16"].items()}
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
