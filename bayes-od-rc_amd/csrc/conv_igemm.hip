@@ -240,6 +240,104 @@ struct KTilePipe {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// MC aggregation behind the fused 1x1 head output conv (ConvGroup.agg_kind; SURVEY.md section 7 step 4, north_star "Welford
+// covariance reduction in LDS").  The tile's fp32 head outputs sit in LDS as ytile[row][ystride], row = pixel_slot * N +
+// sample; one thread per (pixel slot, anchor) walks the N samples.  The arithmetic of AGG_CLS / AGG_COV is, operation for
+// operation, that of post_sample_kernel / post_fuse_kernel on the raw [B,N,A,.] tensors (post_kernels.hip), so the sums are
+// bit-identical to the unfused path; AGG_BOX is Welford's update of the mean and the co-moment matrix of the decoded boxes
+// (inference_utils.py:220-244 computes the same two-pass).
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+template <int C>
+__device__ __forceinline__ void agg_reduce_cls(const ConvGroup& G, const float* ytile, int ystride, const int* s_off, const int* s_off2,
+                                               int tid, int nthreads, int rows) {
+    const int N = G.agg_n, AN = G.cout2 / C, Q = rows / N;
+    for (int item = tid; item < Q * AN; item += nthreads) {
+        const int q = item / AN, an = item - q * AN, r0 = q * N;
+        if (s_off[r0] < 0) continue;
+        const int o0 = s_off2[r0];                       // (image * N + 0) * P + pixel
+        const int b = o0 / (N * G.agg_P), p = o0 - b * N * G.agg_P;
+        float mp[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) mp[j] = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* l = ytile + (size_t)(r0 + n) * ystride + an * C;
+            float v[C];
+#pragma unroll
+            for (int k = 0; k < C / 4; ++k) {
+                const float4 t = reinterpret_cast<const float4*>(l)[k];
+                v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+            }
+            float mx = v[0];
+#pragma unroll
+            for (int j = 1; j < C; ++j) mx = fmaxf(mx, v[j]);
+            float sden = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) { v[j] = expf(v[j] - mx); sden += v[j]; }
+#pragma unroll
+            for (int j = 0; j < C; ++j) mp[j] += v[j] / sden;
+        }
+        float* o = G.agg_out + (((size_t)b * G.agg_P + p) * AN + an) * C;
+#pragma unroll
+        for (int k = 0; k < C / 4; ++k) reinterpret_cast<float4*>(o)[k] = make_float4(mp[4 * k], mp[4 * k + 1], mp[4 * k + 2], mp[4 * k + 3]);
+    }
+}
+
+__device__ __forceinline__ void agg_reduce_box(const ConvGroup& G, const float* ytile, int ystride, const int* s_off, const int* s_off2,
+                                               int tid, int nthreads, int rows) {
+    const int N = G.agg_n, AN = G.cout2 / 4, Q = rows / N;
+    for (int item = tid; item < Q * AN; item += nthreads) {
+        const int q = item / AN, an = item - q * AN, r0 = q * N;
+        if (s_off[r0] < 0) continue;
+        const int o0 = s_off2[r0];
+        const int b = o0 / (N * G.agg_P), p = o0 - b * N * G.agg_P;
+        const float4 anc = reinterpret_cast<const float4*>(G.anchors)[(size_t)p * AN + an];
+        float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m2[k] = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float4 t = *reinterpret_cast<const float4*>(ytile + (size_t)(r0 + n) * ystride + an * 4);
+            // box_utils.box_from_anchor_and_target_bnms (:171-192), as post_kernels.hip decode_box
+            float x[4];
+            x[0] = anc.z * t.x / 10.0f + anc.x;
+            x[1] = anc.w * t.y / 10.0f + anc.y;
+            x[2] = anc.z * fminf(fmaxf(expf(t.z / 5.0f), 1e-4f), 1e4f);
+            x[3] = anc.w * fminf(fmaxf(expf(t.w / 5.0f), 1e-4f), 1e4f);
+            // Welford: d = x - mean; mean += d / k; M2[i][j] += d_i * (x_j - mean_j)
+            const float inv = 1.0f / (float)(n + 1);
+            float d[4], e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { d[i] = x[i] - mean[i]; mean[i] += d[i] * inv; e[i] = x[i] - mean[i]; }
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) m2[k++] += d[i] * e[j];
+        }
+        float* o = G.agg_out + (((size_t)b * G.agg_P + p) * AN + an) * 16;
+        reinterpret_cast<float4*>(o)[0] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+        reinterpret_cast<float4*>(o)[1] = make_float4(m2[0], m2[1], m2[2], m2[3]);
+        reinterpret_cast<float4*>(o)[2] = make_float4(m2[4], m2[5], m2[6], m2[7]);
+        reinterpret_cast<float4*>(o)[3] = make_float4(m2[8], m2[9], 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void agg_reduce_cov(const ConvGroup& G, const float* ytile, int ystride, const int* s_off, const int* s_off2,
+                                               int tid, int nthreads, int rows) {
+    const int N = G.agg_n, CH = G.cout2, Q = rows / N;
+    for (int item = tid; item < Q * CH; item += nthreads) {
+        const int q = item / CH, c = item - q * CH, r0 = q * N;
+        if (s_off[r0] < 0) continue;
+        const int o0 = s_off2[r0];
+        const int b = o0 / (N * G.agg_P), p = o0 - b * N * G.agg_P;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += ytile[(size_t)(r0 + n) * ystride + c];
+        G.agg_out[((size_t)b * G.agg_P + p) * CH + c] = acc;
+    }
+}
+#pragma clang fp contract(fast)
+
 template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
     static_assert(!(SPLIT && XR) && !(SPLIT && ABL != 0), "the bf16x3 mode runs on the generic loop, production build only");
@@ -953,6 +1051,54 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         phase_stamp<ABL>(tstamp, 3);        // Philox mask + LDS tile writes
         __syncthreads();
         phase_stamp<ABL>(tstamp, 4);        // barrier
+        if (fuse && G.agg_kind != AGG_NONE) {
+            // ---- fused 1x1 + MC aggregation: all of a wave's output fragments stay in registers until every wave has read
+            // the activation tile; its LDS then becomes the fp32 output tile [row][ystride] the reduction walks
+            f32x16 yy[HALFP];
+            if (fuse_active) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) w2f[ks] = *reinterpret_cast<const bf16x8*>(wp2 + ks * 16);
+#pragma unroll
+                for (int h4 = 0; h4 < HALFP; ++h4) {
+                    const int pixl = ((wave & 1) * HALFP + h4) * 32 + frow;
+                    const char* prow = smem + pixl * (BC * 2);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yy[h4][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(prow + ((((ks * 2 + fhalf) ^ pixl) & (CPR - 1)) << 4));
+                        yy[h4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ks], xb, yy[h4], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            const int ystride = ((G.cout2 + 31) & ~31) + 4;            // floats per row: = 4 mod 32, conflict-free 16-byte writes
+            float* ytile = reinterpret_cast<float*>(smem);
+            if (fuse_active) {
+#pragma unroll
+                for (int h4 = 0; h4 < HALFP; ++h4) {
+                    const int row = ((wave & 1) * HALFP + h4) * 32 + frow;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int co2 = f2 * 32 + g4 * 8 + fhalf * 4;
+                        if (co2 >= G.cout2) continue;
+                        const float4 b2 = *reinterpret_cast<const float4*>(G.bias2 + co2);
+                        *reinterpret_cast<float4*>(ytile + (size_t)row * ystride + co2) =
+                            make_float4(yy[h4][g4 * 4 + 0] + b2.x, yy[h4][g4 * 4 + 1] + b2.y, yy[h4][g4 * 4 + 2] + b2.z, yy[h4][g4 * 4 + 3] + b2.w);
+                    }
+                }
+            }
+            __syncthreads();
+            if (G.agg_kind == AGG_CLS) {
+                if (G.agg_C == 8) agg_reduce_cls<8>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+                else agg_reduce_cls<4>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+            } else if (G.agg_kind == AGG_BOX) {
+                agg_reduce_box(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+            } else {
+                agg_reduce_cov(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+            }
+            return;                                   // (fused groups never fan out: one pass, and `pk` dies here)
+        }
         if (fuse) {
             if (fuse_active) {
 #pragma unroll
@@ -985,7 +1131,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     }
                 }
             }
-            continue;                                 // the tile itself has no other consumer
+            return;                                   // the tile itself has no other consumer (fused groups never fan out)
         }
 #pragma unroll 4
         for (int q = tid; q < BP * CPR; q += THREADS) {

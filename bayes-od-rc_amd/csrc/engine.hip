@@ -47,7 +47,13 @@ struct Op {
     std::string name;
     std::string wname[3], bnname[3];     // per group: conv / batch-norm layer names (training: parameter lookup)
     bool same_geom = false;              // 3x3 stride-1 SAME with identically laid-out input / output planes (training: input gradient as a convolution)
+    // The last tower layers exist in two flavours when the MC aggregation is fused into their epilogue: FLAVOUR_RAW writes the
+    // per-sample head outputs [B,N,A,.] (bod_forward, sample sharding, parity tests), FLAVOUR_AGG reduces them over the
+    // samples inside the tile (bod_infer).  0 = the op belongs to both.
+    int flavour = 0;
+    int head[3] = {-1, -1, -1};          // per group: BOD_HEAD_* whose raw buffer the fused 1x1 writes (raw buffers are allocated lazily)
 };
+enum { FLAVOUR_BOTH = 0, FLAVOUR_RAW = 1, FLAVOUR_AGG = 2 };
 
 uint16_t f2bf(float f) {
     uint32_t u; std::memcpy(&u, &f, 4);
@@ -101,6 +107,11 @@ struct bod_context {
     char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
     char* head_act_t[3][4] = {{nullptr}};            // training: one buffer per tower layer
     float* raw[3] = {nullptr};                           // cls [B,N,P,9C] box [B,N,P,36] cov [B,N,P,90]
+    // MC aggregation fused into the last tower layers (ConvGroup.agg_kind): per-anchor statistics instead of raw[]
+    float* agg[3] = {nullptr};                           // sum softmax [B,A,C], Welford box [B,A,16], sum cov params [B,A,10]
+    bool agg_plan = false;                               // the plan holds FLAVOUR_AGG ops
+    bool raw_valid = false, agg_valid = false;           // which of the two the last forward produced
+    uint64_t last_seed = 0; uint32_t last_first_image = 0;
     std::map<std::string, RowEnt*> tables;
     std::vector<Op> ops;
     const float* cur_images = nullptr;
@@ -388,6 +399,11 @@ bod_status ensure_raw(bod_context* h) {
         if ((hd == 2 && !c.has_covar_head) || h->raw[hd]) continue;
         BODCHK(h->dalloc(&h->raw[hd], (size_t)c.batch * c.mc_samples * h->P * out_ch[hd]));
     }
+    // plans with the fused MC aggregation allocate the raw tensors on first use: point the raw-flavour ops at them
+    for (Op& o : h->ops)
+        if (o.kind == Op::CONV && o.flavour == FLAVOUR_RAW)
+            for (int g = 0; g < o.conv.groups; ++g)
+                if (o.conv.g[g].w2 && o.head[g] >= 0) o.conv.g[g].out2 = h->raw[o.head[g]];
     return BOD_OK;
 }
 
@@ -516,7 +532,6 @@ bod_status build_plan(bod_context* h) {
         BODCHK(h->dalloc(&h->head_act[hd][1], act_elems));
     }
     const int out_ch[3] = {c.anchors_per_location * c.num_classes, c.anchors_per_location * 4, c.anchors_per_location * 10};
-    BODCHK(ensure_raw(h));
     // row tables: layer 1 (pyramid -> N dropout variants), layers 2.. (per sample), output 1x1
     std::vector<RowEnt> t1((size_t)B * h->P), t2((size_t)B * N * h->P), t3((size_t)B * N * h->P);
     {
@@ -625,8 +640,66 @@ bod_status build_plan(bod_context* h) {
         probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
         fuse_out = fuse_out && conv_igemm_uses_full_cout_tile(probe);
     }
-    for (int layer = 0; layer < 4; ++layer) {
-        Op op; op.kind = Op::CONV; op.is_head3x3 = true;
+    // ---- MC aggregation fused into the last tower layers' epilogues (inference_utils.py:31-60,
+    // :220-244): a tile of those layers must hold ALL N samples of its pixels, so they get their own row table -- tiles of
+    // Q <= 256 / N pixel slots, row = slot * N + sample, made of runs of x-adjacent pixels whose extended rows (run + 2,
+    // once per sample) fit the 320 staged rows.  BOD_FUSE_AGGREGATION=0 keeps the raw tensors + the posterior's own loops.
+    bool agg = xreuse && fuse_out && N >= 2 && 256 / N >= 1 && 320 / N - 2 >= 1 && c.mc_ensemble_size <= N;
+    if (const char* e = getenv("BOD_FUSE_AGGREGATION")) agg = agg && atoi(e) != 0;
+    RowEnt* d2a = nullptr; int2* dexta = nullptr; int m2a = 0;
+    if (agg) {
+        const int Qmax = 256 / N;
+        std::vector<RowEnt> tiled;
+        std::vector<int2> ext;
+        RowEnt invalid = t2[0];
+        invalid.out_off = -1; invalid.pad0 = 0; invalid.pad1 = 0;
+        for (int b = 0; b < B; ++b) {
+            const size_t img0 = (size_t)b * N * h->P;               // t2 index of (b, sample 0, pixel 0); sample n: + n * P
+            int p = 0;
+            while (p < h->P) {
+                const size_t tile0 = tiled.size(), ext0 = ext.size();
+                tiled.resize(tile0 + 256, invalid);
+                int Q = 0, X = 0;
+                while (p < h->P && Q < Qmax) {
+                    int L = 1;                                      // maximal run of x-adjacent pixels starting at p
+                    while (p + L < h->P && t2[img0 + p + L].in_off == t2[img0 + p + L - 1].in_off + 1 &&
+                           t2[img0 + p + L].in_pitch == t2[img0 + p].in_pitch) ++L;
+                    const int take = std::min(std::min(L, Qmax - Q), (XR_EXT_ROWS - X) / N - 2);
+                    if (take < 1) break;
+                    for (int n = 0; n < N; ++n) {
+                        const RowEnt& first = t2[img0 + (size_t)n * h->P + p];
+                        for (int k = 0; k < take + 2; ++k) ext.push_back(int2{first.in_off + k, first.in_pitch});
+                        for (int k = 0; k < take; ++k) {
+                            RowEnt q = t2[img0 + (size_t)n * h->P + p + k];
+                            q.pad1 = X + n * (take + 2) + k;
+                            tiled[tile0 + (size_t)(Q + k) * N + n] = q;
+                        }
+                    }
+                    X += N * (take + 2); Q += take; p += take;
+                }
+                if (Q == 0) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: no pixel fits a tile (N = %d)", N);
+                while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(ext[ext0]);
+                for (size_t q = ext0; q < ext0 + XR_EXT_ROWS; ++q)
+                    if (ext[q].x < ext[ext0].x) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: extended rows out of order");
+            }
+        }
+        m2a = (int)tiled.size();
+        BODCHK(h->dalloc(&d2a, tiled.size(), false));
+        BODCHK(h->dalloc(&dexta, ext.size(), false));
+        HIPCHK(h, hipMemcpyAsync(d2a, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dexta, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const size_t BA = (size_t)B * h->A;
+        BODCHK(h->dalloc(&h->agg[0], BA * c.num_classes));
+        BODCHK(h->dalloc(&h->agg[1], BA * 16));
+        if (c.has_covar_head) BODCHK(h->dalloc(&h->agg[2], BA * 10));
+    } else {
+        BODCHK(ensure_raw(h));                 // the ops below reference the raw tensors directly
+    }
+    h->agg_plan = agg;
+    for (int layer = 0; layer < 4; ++layer)
+    for (int flav = (agg && layer >= 2) ? FLAVOUR_RAW : FLAVOUR_BOTH; flav <= ((agg && layer >= 2) ? FLAVOUR_AGG : FLAVOUR_BOTH); ++flav) {
+        Op op; op.kind = Op::CONV; op.is_head3x3 = true; op.flavour = flav;
         int g = 0; PackedConv pc0{};
         double fused_flops = 0;
         for (int hd = 0; hd < nheads; ++hd) {
@@ -647,6 +720,12 @@ bod_status build_plan(bod_context* h) {
                 if (po.cin != 256 || po.cout != out_ch[hd] || po.taps != 1)
                     return h->fail(BOD_ERR_INVALID_ARG, "head output conv %s must be 1x1 256->%d (got %d->%d)", kHeadPrefix[hd], out_ch[hd], po.cin, po.cout);
                 cg.w2 = po.w; cg.bias2 = po.bias; cg.out2 = h->raw[hd]; cg.cout2 = po.cout; cg.out2_cstride = out_ch[hd];
+                op.head[g] = hd;
+                if (flav == FLAVOUR_AGG) {             // reduce over the MC samples inside the tile instead of writing [B,N,A,.]
+                    cg.out2 = nullptr;
+                    cg.agg_kind = hd == 0 ? AGG_CLS : hd == 1 ? AGG_BOX : AGG_COV;
+                    cg.agg_n = N; cg.agg_P = h->P; cg.agg_C = c.num_classes; cg.agg_out = h->agg[hd]; cg.anchors = h->d_anchors;
+                }
                 fused_flops += 2.0 * ((double)B * N * h->P) * 256.0 * out_ch[hd];      // the 1x1 output conv runs inside this launch
             }
             op.conv.g[g] = cg;
@@ -663,11 +742,12 @@ bod_status build_plan(bod_context* h) {
         a.drop_threshold = thr; a.drop_scale = dscale;
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;
+            if (agg && layer >= 2) { a.rows = d2a; a.M = m2a; a.ext = dexta; }       // sample-complete tiles (both flavours)
             a.xreuse = 2;       // 32-bit activation offsets against the tile's first extended row: any buffer size
         }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g + fused_flops;
-        op.name = "head_tower_layer_" + std::to_string(layer);
+        op.name = "head_tower_layer_" + std::to_string(layer) + (flav == FLAVOUR_AGG ? "(aggregating)" : flav == FLAVOUR_RAW ? "(raw)" : "");
         op.same_geom = N == 1;            // pyramid [B][Ppad] and head planes [B*N][Ppad] coincide at N = 1
         h->ops.push_back(op);
     }
@@ -742,8 +822,13 @@ PostCfg post_cfg(bod_context* h, uint64_t seed, uint32_t first_image) {
     return p;
 }
 
-bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image) {
+// flavour: FLAVOUR_RAW = per-sample head outputs into raw[] (RetinaNetModel.call's tensors), FLAVOUR_AGG = MC statistics
+// reduced inside the last tower layers' tiles (plans with agg_plan only).  only_flavoured: run just the ops that differ
+// between the two (materialise_raw re-runs the raw flavour of the last layers on the activations still in HBM).
+bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image, int flavour = FLAVOUR_RAW,
+                       bool only_flavoured = false) {
     const bod_config& c = h->cfg;
+    if (flavour == FLAVOUR_RAW && !only_flavoured) BODCHK(ensure_raw(h));
     // BOD_TRACE_OPS=k: the k-th forward call is traced op by op (HIP events on the engine stream) and a table
     // is printed to stderr -- a development aid (tests/tools), off by default.
     static const int trace_call = getenv("BOD_TRACE_OPS") ? atoi(getenv("BOD_TRACE_OPS")) : 0;
@@ -759,11 +844,12 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
     for (Op& op : h->ops) {
         if (trace && op_i > 0) HIPCHK(h, hipEventRecord(tev[op_i], h->stream));
         ++op_i;
+        if ((op.flavour != FLAVOUR_BOTH && op.flavour != flavour) || (only_flavoured && op.flavour == FLAVOUR_BOTH)) continue;
         switch (op.kind) {
             case Op::STEM:
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, h->stream));
-                if (h->cur_img_buf >= 0 && !h->train) {           // the frames are consumed: the copy stream may refill this buffer
+                if (h->cur_img_buf >= 0 && h->copy && !h->train) {   // the frames are consumed: the copy stream may refill this buffer
                     HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], h->stream));
                     h->img_free_pending[h->cur_img_buf] = true;
                 }
@@ -807,7 +893,25 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         for (hipEvent_t& e : tev) hipEventDestroy(e);
     }
     h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    h->last_seed = seed; h->last_first_image = first_image;
+    if (flavour == FLAVOUR_AGG) { h->agg_valid = true; h->raw_valid = false; }
+    else { h->raw_valid = true; if (!only_flavoured) h->agg_valid = false; }
     return BOD_OK;
+}
+
+// The raw head outputs of the last forward, for callers that ask for them after an aggregating bod_infer: the last tower
+// layers' raw flavour is re-run on the activations still in HBM (same seed, same Philox streams: exactly the tensors a
+// raw-flavour forward would have produced).
+bod_status materialise_raw(bod_context* h) {
+    if (h->raw_valid || !h->agg_valid) { BODCHK(ensure_raw(h)); return BOD_OK; }
+    BODCHK(ensure_raw(h));
+    const bool prof = h->profiling;
+    h->profiling = false;
+    const bool fd = h->forward_done, pd = h->posterior_done, nd = h->nms_done, cd = h->cluster_done;
+    const bod_status st = run_forward(h, h->cur_images, h->last_seed, h->last_first_image, FLAVOUR_RAW, true);
+    h->profiling = prof;
+    h->forward_done = fd; h->posterior_done = pd; h->nms_done = nd; h->cluster_done = cd;
+    return st;
 }
 
 bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
@@ -817,6 +921,8 @@ bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
     PostCfg pc = post_cfg(h, seed, first_image);
     PostBuffers pb = h->pb;
     pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
+    pc.aggregated = (h->agg_valid && !h->raw_valid) ? 1 : 0;        // statistics from the conv epilogue, no [B,N,A,.] tensors
+    pb.agg_cls = h->agg[0]; pb.agg_box = h->agg[1]; pb.agg_cov = h->agg[2];
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
@@ -875,6 +981,14 @@ bod_status stage_images(bod_context* h, const float* images, int on_device, cons
     HIPCHK(h, hipMemcpyAsync(h->d_images, images, bytes, hipMemcpyHostToDevice, h->stream));
     *dev = h->d_images;
     return BOD_OK;
+}
+
+// bod_infer reduces over the MC samples inside the conv epilogue whenever the plan has that flavour and this handle holds the
+// whole ensemble (a handle computing a shard of a larger ensemble keeps the raw tensors: the exchange needs them)
+int infer_flavour(bod_context* h) {
+    const bod_config& c = h->cfg;
+    const bool whole = c.mc_sample_base == 0 && (c.mc_ensemble_size == 0 || c.mc_ensemble_size == c.mc_samples);
+    return (h->agg_plan && whole && h->anchors_ready) ? FLAVOUR_AGG : FLAVOUR_RAW;
 }
 
 template <typename T>
@@ -1152,6 +1266,7 @@ bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uin
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const float* dev = nullptr;
     BODCHK(stage_images(h, images, on_device, &dev));
+    h->cur_images = dev;
     if (h->train) return train_forward_only(h, dev, seed, first_image_id);     // model(x, 'training'): dropout on, N = 1
     return run_forward(h, dev, seed, first_image_id);
 }
@@ -1159,6 +1274,8 @@ bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uin
 bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* cov) {
     if (!h) return BOD_ERR_INVALID_ARG;
     if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    BODCHK(materialise_raw(h));
     const bod_config& c = h->cfg;
     const size_t n = (size_t)c.batch * c.mc_samples * h->A;
     BODCHK(d2h(h, cls, h->raw[0], n * c.num_classes));
@@ -1182,6 +1299,7 @@ bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const f
     if (cov && c.has_covar_head) HIPCHK(h, hipMemcpyAsync(h->raw[2], cov, n * 40, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    h->raw_valid = true; h->agg_valid = false;
     return BOD_OK;
 }
 
@@ -1224,6 +1342,7 @@ bod_status bod_validation_post(bod_handle h) {
     if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward / bod_set_raw has not run");
     if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    BODCHK(materialise_raw(h));
     for (int sidx = 0; sidx < 2; ++sidx)
         if (h->side_pending[sidx]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[sidx], 0));
     PostCfg pc = post_cfg(h, 0, 0);
@@ -1357,9 +1476,8 @@ bod_status bod_set_affinity(bod_handle h, int32_t img, const float* centre_colum
         return h->fail(BOD_ERR_INVALID_ARG, "bod_set_affinity: got %d columns of %d rows, the image has %d centres and %d boxes", k, m, kk, mm);
     if (!h->affinity && hipMalloc((void**)&h->affinity, (size_t)h->cfg.nms_max_output_size * h->A * 4) != hipSuccess)
         return h->fail(BOD_ERR_OOM, "bod_set_affinity: %zu bytes", (size_t)h->cfg.nms_max_output_size * h->A * 4);
-    if (k > 0 && m > 0)
-        HIPCHK(h, hipMemcpy2DAsync(h->affinity, (size_t)h->A * 4, centre_columns, (size_t)m * 4, (size_t)m * 4, (size_t)k,
-                                   hipMemcpyHostToDevice, h->stream));
+    for (int r = 0; r < k && m > 0; ++r)          // row r -> affinity[r][0..m): one plain copy per centre (k <= max_detections)
+        HIPCHK(h, hipMemcpyAsync(h->affinity + (size_t)r * h->A, centre_columns + (size_t)r * m, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->affinity_img = img;
     return BOD_OK;
@@ -1403,9 +1521,9 @@ bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, f
 bod_status bod_device_raw(bod_handle h, void** p, int32_t mark_ready) {
     if (!h || !p) return BOD_ERR_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    BODCHK(ensure_raw(h));
+    if (mark_ready) BODCHK(ensure_raw(h)); else BODCHK(materialise_raw(h));
     p[0] = h->raw[0]; p[1] = h->raw[1]; p[2] = h->cfg.has_covar_head ? h->raw[2] : nullptr;
-    if (mark_ready) { h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; }
+    if (mark_ready) { h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; h->raw_valid = true; h->agg_valid = false; }
     return BOD_OK;
 }
 
@@ -1423,7 +1541,8 @@ bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint6
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const float* dev = nullptr;
     BODCHK(stage_images(h, images, on_device, &dev));
-    BODCHK(run_forward(h, dev, seed, first_image_id));
+    h->cur_images = dev;
+    BODCHK(run_forward(h, dev, seed, first_image_id, infer_flavour(h)));
     BODCHK(run_posterior(h, seed, first_image_id));
     BODCHK(run_nms(h, h->stream));
     return run_cluster(h, h->stream);
@@ -1439,7 +1558,8 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
         return h->fail(BOD_ERR_NOT_READY, "slot %d still holds uncollected detections: call bod_collect first", sidx);
     const float* dev = nullptr;
     BODCHK(stage_images(h, images, on_device, &dev));
-    BODCHK(run_forward(h, dev, seed, first_image_id));
+    h->cur_images = dev;
+    BODCHK(run_forward(h, dev, seed, first_image_id, infer_flavour(h)));
     BODCHK(run_posterior(h, seed, first_image_id));           // waits for the side stream's previous readers
     HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
     h->select_slot(sidx);
@@ -1835,7 +1955,7 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int seen = 0; Op* op = nullptr;
-    for (Op& o : h->ops) if (o.is_head3x3 && seen++ == layer) { op = &o; break; }
+    for (Op& o : h->ops) if (o.is_head3x3 && o.flavour != FLAVOUR_RAW && seen++ == layer) { op = &o; break; }    // (layers 2, 3: the flavour bod_infer runs)
     if (!op) return h->fail(BOD_ERR_INVALID_ARG, "no head layer %d", layer);
     ConvArgs a = op->conv;
     a.variant = variant;

@@ -38,7 +38,19 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     float* out2;           // fp32 [rows][out2_cstride]; row index = RowEnt.pad0
     int32_t cout2;         // real output channels (A*C, A*4, A*10)
     int32_t out2_cstride;
+    // MC aggregation fused behind the 1x1 (inference_utils.py:31-60,220-244): when agg_kind != 0 the per-sample head outputs of
+    // a tile never leave the CU -- the tile holds ALL agg_n samples of its pixels (row = pixel_slot * agg_n + sample, see the
+    // "aggregated" row tables of engine.hip), the fp32 outputs go through LDS and one thread per (pixel, anchor) reduces over
+    // the samples: AGG_CLS sum_n softmax(logits) [B,A,C]; AGG_BOX Welford mean + M2 of the decoded boxes [B,A,16] (mean 4, lower
+    // triangle of M2 10, 2 pad); AGG_COV sum_n of the covariance parameters [B,A,10].  out2 is then unused.
+    int32_t agg_kind;
+    int32_t agg_n;         // MC samples per pixel in a tile
+    int32_t agg_P;         // pixels per image (RowEnt.pad0 = (image * agg_n + sample) * agg_P + pixel)
+    int32_t agg_C;         // classes (AGG_CLS) -- 4 or 8
+    float* agg_out;
+    const float* anchors;  // [A,4] (v,u,h,w): box decode of AGG_BOX
 };
+enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
 
 enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4,
                  CONV_ACCUM = 8 };     // with CONV_OUT_F32: out += result (input gradients of 1x1 layers accumulate in place)
@@ -119,6 +131,7 @@ struct PostCfg {
     float iso_var;
     float kitti_sh, kitti_sw;       // 0 => off
     uint32_t seed_lo, seed_hi, image_base;
+    int32_t aggregated;             // 1: the MC statistics come from the conv epilogue (PostBuffers.agg_*), not from raw [B,N,A,.]
 };
 
 struct PostBuffers {
@@ -127,6 +140,10 @@ struct PostBuffers {
     const float* box;       // [B,N,A,4]
     const float* cov;       // [B,N,A,10]
     const float* anchors;   // [A,4]
+    // PostCfg.aggregated: per-anchor MC statistics written by the last tower layers' epilogues (ConvGroup.agg_kind)
+    const float* agg_cls;   // [B,A,C]   sum over samples of softmax(logits)
+    const float* agg_box;   // [B,A,16]  Welford mean[4], lower triangle of M2[10], 2 pad
+    const float* agg_cov;   // [B,A,10]  sum over samples of the covariance parameters
     // dense per-anchor scratch
     uint8_t* keep;          // [B,A]
     float* d_counts;        // [B,A,C]   sampled counts (likelihood)

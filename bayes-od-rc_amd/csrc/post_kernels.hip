@@ -97,7 +97,12 @@ __global__ __launch_bounds__(POST_BLOCK) void post_sample_kernel(PostCfg c, Post
         float mp[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) mp[j] = 0.f;
-        for (int n = 0; n < c.N; ++n) {
+        if (c.aggregated) {                 // sum_n softmax from the head epilogue (conv_igemm.hip agg_reduce_cls: the loop below, fused)
+            const float* l = pb.agg_cls + ((size_t)b * c.A + a) * C;
+#pragma unroll
+            for (int j = 0; j < C; ++j) mp[j] = l[j];
+        }
+        for (int n = 0; n < (c.aggregated ? 0 : c.N); ++n) {
             const float* l = pb.cls + (((size_t)b * c.N + n) * c.A + a) * C;
             float v[C];
             if (C % 4 == 0) {
@@ -208,21 +213,32 @@ __global__ __launch_bounds__(POST_BLOCK) void post_fuse_kernel(PostCfg c, PostBu
     const float4 anc = reinterpret_cast<const float4*>(pb.anchors)[a];
     // ---- epistemic: two-pass mean / unbiased covariance over MC samples (:220-244)
     float mu[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < c.N; ++n) {
+    Mat4 epi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi.m[i][j] = 0.f;
+    const int n_raw = c.aggregated ? 0 : c.N;
+    if (c.aggregated) {                     // Welford mean and co-moment sums from the head epilogue (agg_reduce_box)
+        const float4* ab = reinterpret_cast<const float4*>(pb.agg_box) + ((size_t)b * c.A + a) * 4;
+        const float4 m = ab[0], q0 = ab[1], q1 = ab[2], q2 = ab[3];
+        mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w;
+        epi.m[0][0] = q0.x; epi.m[1][0] = q0.y; epi.m[1][1] = q0.z; epi.m[2][0] = q0.w;
+        epi.m[2][1] = q1.x; epi.m[2][2] = q1.y; epi.m[3][0] = q1.z; epi.m[3][1] = q1.w;
+        epi.m[3][2] = q2.x; epi.m[3][3] = q2.y;
+    }
+    for (int n = 0; n < n_raw; ++n) {
         const float4 t = reinterpret_cast<const float4*>(pb.box)[((size_t)b * c.N + n) * c.A + a];
         float bx[4];
         decode_box(anc, t, bx);
 #pragma unroll
         for (int i = 0; i < 4; ++i) mu[i] += bx[i];
     }
+    if (!c.aggregated) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) mu[i] = mu[i] / (float)c.N;
-    Mat4 epi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) epi.m[i][j] = 0.f;
-    for (int n = 0; n < c.N; ++n) {
+        for (int i = 0; i < 4; ++i) mu[i] = mu[i] / (float)c.N;
+    }
+    for (int n = 0; n < n_raw; ++n) {
         const float4 t = reinterpret_cast<const float4*>(pb.box)[((size_t)b * c.N + n) * c.A + a];
         float bx[4];
         decode_box(anc, t, bx);
@@ -249,7 +265,15 @@ __global__ __launch_bounds__(POST_BLOCK) void post_fuse_kernel(PostCfg c, PostBu
         float x[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) x[q] = 0.f;
-        for (int n = 0; n < c.N; ++n) {
+        if (c.aggregated) {                 // sum_n of the raw parameters from the head epilogue (agg_reduce_cov)
+            const float* p = pb.agg_cov + ((size_t)b * c.A + a) * 10;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float2 t = reinterpret_cast<const float2*>(p)[q];
+                x[2 * q] = t.x; x[2 * q + 1] = t.y;
+            }
+        }
+        for (int n = 0; n < n_raw; ++n) {
             const float* p = pb.cov + (((size_t)b * c.N + n) * c.A + a) * 10;
 #pragma unroll
             for (int q = 0; q < 5; ++q) {

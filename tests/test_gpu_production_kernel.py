@@ -98,6 +98,72 @@ def test_forced_tile_really_plans_the_production_kernel():
         assert expect in r.stdout, (forced, r.stdout[-500:])
 
 
+_AGG_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG
+from bayes_od_rc_amd import synthetic
+from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+from bayes_od_rc_amd.engine import Engine, make_config
+h, w, batch, n = (int(v) for v in sys.argv[3:7])
+eng = Engine(make_config((h, w), batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+eng.load_weights(synthetic.make_weights(cls_fg_bias=-1.0))
+eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((h, w, 3)))
+frames = synthetic.make_frames(batch, h, w, seed=31)
+eng.infer(frames, seed=77, first_image_id=5)
+out = {}
+for b in range(batch):
+    post = eng.get_posterior(b)
+    for k, v in post.items():
+        out["post%d_%s" % (b, k)] = v
+    for k, v in zip(("scores", "means", "covs", "counts"), eng.get_detections(b)):
+        out["det%d_%s" % (b, k)] = v
+raw_after_infer = [x.copy() for x in eng.get_raw()]          # after an aggregating infer: re-materialised
+eng.forward(frames, seed=77, first_image_id=5)                 # the raw flavour itself
+for name, a, b in zip(("cls", "box", "cov"), raw_after_infer, eng.get_raw()):
+    assert np.array_equal(a, b), "raw %s differs between materialise-after-infer and forward" % name
+    out["raw_" + name] = a
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.parametrize("h,w,batch,n", [(128, 160, 2, 5), (96, 160, 1, 30), (128, 128, 3, 2), (160, 160, 1, 10)])
+def test_fused_mc_aggregation_equals_the_raw_path(tmp_path, h, w, batch, n):
+    """The MC aggregation fused into the last tower layers' epilogues (sum of softmax, Welford box mean / co-moments, sum of
+    covariance parameters; sample-complete tiles) against the same pipeline with BOD_FUSE_AGGREGATION=0, i.e. raw
+    [B,N,A,.] tensors + the posterior kernels' own loops: identical kept set, Dirichlet counts and scores bit for bit
+    (the softmax sums are the same operations in the same order), box means / covariances to fp32 round-off (Welford
+    vs two-pass), identical soft-NMS centres; and the raw tensors re-materialised after an aggregating infer equal a
+    raw-flavour forward bit for bit."""
+    outs = []
+    for fuse in ("1", "0"):
+        path = str(tmp_path / ("agg%s.npz" % fuse))
+        env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_FUSE_AGGREGATION=fuse)
+        r = subprocess.run([sys.executable, "-c", _AGG_SCRIPT, ROOT, path, str(h), str(w), str(batch), str(n)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        z = np.load(path)
+        outs.append({k: z[k] for k in z.files})
+    fused, plain = outs
+    for k in ("raw_cls", "raw_box", "raw_cov"):
+        assert np.array_equal(fused[k], plain[k]), k               # the tiling of the last layers does not enter the arithmetic
+    for b in range(batch):
+        pre = "post%d_" % b
+        assert fused[pre + "means"].shape[0] > 30
+        assert np.array_equal(fused[pre + "anchor_index"], plain[pre + "anchor_index"])
+        assert np.array_equal(fused[pre + "counts"], plain[pre + "counts"])
+        assert np.array_equal(fused[pre + "score"], plain[pre + "score"])
+        assert np.max(np.abs(fused[pre + "means"] - plain[pre + "means"]) / (np.abs(plain[pre + "means"]) + 1.0)) < 1e-5
+        ref = plain[pre + "covs"]
+        floor = np.abs(ref).reshape(len(ref), -1).max(axis=1)[:, None, None] * 1e-2
+        assert (np.abs(fused[pre + "covs"] - ref) / (np.abs(ref) + floor)).max() < 1e-4
+        pre = "det%d_" % b
+        assert fused[pre + "means"].shape == plain[pre + "means"].shape
+        assert np.max(np.abs(fused[pre + "means"] - plain[pre + "means"]) / (np.abs(plain[pre + "means"]) + 1.0)) < 1e-4
+        assert np.allclose(fused[pre + "scores"], plain[pre + "scores"], rtol=1e-5, atol=1e-6)
+
+
 def _match(det_means, ref_means):
     """Greedy one-to-one matching of detections by IoU of their mean boxes (v,u,h,w) -> list of (i_det, i_ref, iou)."""
     from oracle import geometry
