@@ -591,23 +591,24 @@ bod_status build_plan(bod_context* h) {
         probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
         xreuse = xreuse && conv_igemm_uses_full_cout_tile(probe);
     }
-    if (xreuse) {
+    // rows -> 256-slot tiles of x-adjacent runs + each tile's extended input rows (kernels.h, ConvArgs::ext)
+    auto make_xr_tiles = [&](const std::vector<RowEnt>& src, RowEnt** d_rows, int2** d_ext, int* m_out) -> bod_status {
         std::vector<RowEnt> tiled;
         std::vector<int2> ext;
-        RowEnt invalid = t2[0];
+        RowEnt invalid = src[0];
         invalid.out_off = -1; invalid.pad0 = 0; invalid.pad1 = 0;
         size_t r = 0;
-        while (r < t2.size()) {
+        while (r < src.size()) {
             const size_t tile0 = tiled.size();
             const size_t ext0 = ext.size();
             int pix = 0, nx = 0;
-            while (r < t2.size() && pix < 256 && nx + 3 <= XR_EXT_ROWS) {
+            while (r < src.size() && pix < 256 && nx + 3 <= XR_EXT_ROWS) {
                 // maximal run of x-adjacent pixels starting at row r
                 size_t e = r + 1;
-                while (e < t2.size() && t2[e].in_off == t2[e - 1].in_off + 1 && t2[e].in_pitch == t2[r].in_pitch) ++e;
+                while (e < src.size() && src[e].in_off == src[e - 1].in_off + 1 && src[e].in_pitch == src[r].in_pitch) ++e;
                 int take = (int)std::min<size_t>(e - r, (size_t)std::min(256 - pix, XR_EXT_ROWS - nx - 2));
-                for (int k = 0; k < take + 2; ++k) ext.push_back(int2{t2[r].in_off + k, t2[r].in_pitch});
-                for (int k = 0; k < take; ++k) { RowEnt q = t2[r + k]; q.pad1 = nx + k; tiled.push_back(q); }
+                for (int k = 0; k < take + 2; ++k) ext.push_back(int2{src[r].in_off + k, src[r].in_pitch});
+                for (int k = 0; k < take; ++k) { RowEnt q = src[r + k]; q.pad1 = nx + k; tiled.push_back(q); }
                 nx += take + 2; pix += take; r += take;
             }
             while (tiled.size() < tile0 + 256) tiled.push_back(invalid);
@@ -617,13 +618,27 @@ bod_status build_plan(bod_context* h) {
             for (size_t q = ext0; q < ext0 + XR_EXT_ROWS; ++q)
                 if (ext[q].x < ext[ext0].x) return h->fail(BOD_ERR_INVALID_ARG, "row-reuse tiling: extended rows out of order");
         }
-        m2x = (int)tiled.size();
-        BODCHK(h->dalloc(&d2x, tiled.size(), false));
-        BODCHK(h->dalloc(&dext, ext.size(), false));
-        HIPCHK(h, hipMemcpyAsync(d2x, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(dext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        *m_out = (int)tiled.size();
+        BODCHK(h->dalloc(d_rows, tiled.size(), false));
+        BODCHK(h->dalloc(d_ext, ext.size(), false));
+        HIPCHK(h, hipMemcpyAsync(*d_rows, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(*d_ext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        return BOD_OK;
+    };
+    if (xreuse) BODCHK(make_xr_tiles(t2, &d2x, &dext, &m2x));
+    // the first tower layer (one convolution per image, N-way dropout fan-out epilogue) takes the row-reuse loop too once
+    // its launch is on the 256x256 tile (conv_igemm.hip: from 1 024 tiles on): activation reads x4.5 -> x1.2 of the
+    // algorithmic bytes (profiles/round1_head_conv_pmc.json, launch 0).  BOD_FAN_XREUSE=0: A/B aid.
+    RowEnt* d1x = nullptr; int2* dext1 = nullptr; int m1x = 0;
+    bool xreuse0 = xreuse && N > 1;
+    if (const char* e = getenv("BOD_FAN_XREUSE")) xreuse0 = xreuse0 && atoi(e) != 0;
+    {
+        ConvArgs probe{};
+        probe.M = B * h->P; probe.cout_pad = 256; probe.fan_count = N; probe.flags = CONV_RELU | CONV_DROPOUT; probe.groups = c.has_covar_head ? 3 : 2;
+        xreuse0 = xreuse0 && conv_igemm_uses_full_cout_tile(probe);
     }
+    if (xreuse0) BODCHK(make_xr_tiles(t1, &d1x, &dext1, &m1x));
 
     const bool mc = train_mode || std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77); training: dropout on (:113-129)
     const uint32_t thr = (uint32_t)std::floor((double)c.dropout_rate * 65536.0);
@@ -740,6 +755,7 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
+        if (xreuse0 && layer == 0) { a.rows = d1x; a.M = m1x; a.ext = dext1; a.xreuse = 2; }
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;
             if (agg && layer >= 2) { a.rows = d2a; a.M = m2a; a.ext = dexta; }       // sample-complete tiles (both flavours)
@@ -863,7 +879,8 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 op.conv.image_base = first_image;
                 op.conv.sample_base = (uint32_t)c.mc_sample_base;
                 op.conv.dyn_rng = train_dyn_rng(h);              // training: device copy of {seed, image id} (graph replay)
-                const bool timed = h->profiling && op.is_head3x3 && (h->prof_which == 0 || (h->prof_which == 1) == (op.conv.xreuse != 0));
+                const bool is_tower = op.conv.xreuse != 0 && op.conv.fan_count <= 1;        // per-sample tower launches (one kernel symbol)
+                const bool timed = h->profiling && op.is_head3x3 && (h->prof_which == 0 || (h->prof_which == 1) == is_tower);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {
                     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
@@ -1223,7 +1240,8 @@ bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t 
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_img_free[k], hipEventDisableTiming));
         }
     }
-    if (!h->d_images_b[buffer]) BODCHK(h->dalloc(&h->d_images_b[buffer], (size_t)c.batch * c.image_h * c.image_w * 3));
+    // (no zero fill: dalloc's memset would run on the main stream, behind the forward in flight, and land on the frames)
+    if (!h->d_images_b[buffer]) BODCHK(h->dalloc(&h->d_images_b[buffer], (size_t)c.batch * c.image_h * c.image_w * 3, false));
     const size_t bytes = (size_t)c.batch * src_h * src_w * 3;
     if (bytes > h->u8_cap_b[buffer]) {
         HIPCHK(h, hipStreamSynchronize(h->copy));

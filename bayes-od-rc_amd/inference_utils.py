@@ -108,7 +108,7 @@ def _standalone_engine(m, c, k):
     from .engine import Engine, make_config
     side = 64
     while True:
-        a = sum(-(-side // s) ** 2 for s in (8, 16, 32, 64, 128)) * 9
+        a = sum((-(-side // s)) ** 2 for s in (8, 16, 32, 64, 128)) * 9          # anchors of a side x side input
         if a >= m:
             break
         side *= 2

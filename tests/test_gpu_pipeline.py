@@ -177,7 +177,7 @@ def test_fp32_pipeline_matches_oracle_end_to_end(precision):
         post = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64, return_debug=True)
         got = eng.get_posterior(b)
         # every image, boundary anchors masked (the class probabilities come from two forward passes that agree to ~1e-5)
-        _, same_set = compare_posterior(got, post, u, tol=REL_TOL, min_checked=50, boundary_eps=2e-4, max_ambiguous=5e-2)
+        _, same_set = compare_posterior(got, post, u, tol=REL_TOL, min_checked=50, boundary_eps=5e-5, max_ambiguous=5e-2)
         if not same_set:
             continue                       # the later stages need identical candidate lists
         corners = post["corners"].astype(np.float32)
@@ -247,15 +247,18 @@ def test_pipelines_sharing_an_engine_keep_their_own_kitti_scale():
     pb = BayesOdPipeline(model, hw, 1, BAYES_CFG, NMS_CFG, dataset_name="kitti", orig_size=(375, 1242), anchors=anchors)
     assert pa.engine is pb.engine
     a1 = pa(frames, seed=4, first_image_id=0)[0]
+    post_a = pa.engine.get_posterior(0)["means"].copy()
     b1 = pb(frames, seed=4, first_image_id=0)[0]
+    post_b = pb.engine.get_posterior(0)["means"].copy()
     a2 = pa(frames, seed=4, first_image_id=0)[0]
     assert a1[1].shape[0] > 0
     for x, y in zip(a1, a2):
         assert np.array_equal(x, y)
-    assert a1[1].shape == b1[1].shape
+    # the per-anchor posterior is S mu exactly (the fused detections are not: cluster membership is an IoU test on the scaled boxes)
     ratio = np.asarray([375 / 370, 1242 / 1224] * 2, np.float32)
-    assert np.allclose(b1[1], a1[1] * ratio, rtol=1e-5)
-    assert not np.allclose(b1[1], a1[1], rtol=1e-4)
+    assert post_a.shape == post_b.shape and post_a.shape[0] > 50
+    assert np.allclose(post_b, post_a * ratio, rtol=1e-5)
+    assert not np.allclose(post_b, post_a, rtol=1e-4)
 
 
 def test_pipelined_u8_upload_equals_synchronous_upload():

@@ -10,6 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRODUCTION = [     # <BC, BP, WC, WP, ABL=0, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb0EE",     # head towers (row reuse)
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi5ELb1ELb0EE",     # first tower layer, N-way fan-out, on the row-reuse loop
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb0EE",     # backbone / FPN, big tile
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb0EE",     # fan-out layer, small layers, split-K
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb0EE",

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the head-tower conv kernel on the bench geometry (B=8, N=10, 512x512).
-usage: bench_head_conv.py [variant[:layer]...]   e.g.  bench_head_conv.py 0 82 0:2 82:2 90
-(variant 0 = production, 82 = production build with the workgroup-wide epilogue, 90 = phase clock, see conv_igemm.hip)"""
+usage: bench_head_conv.py [variant[:layer]...]   e.g.  bench_head_conv.py 0 0:2 0:3 90
+(variant 0 = production, 90 = phase clock, 1 / 2 / 4 / 30 / 31 = ablation builds, see conv_igemm.hip)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
