@@ -94,6 +94,8 @@ SIGNATURES = {
     "bod_train_gradients": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "bod_train_apply": (C.c_int, [_H, C.c_float, C.POINTER(C.c_double)]),
     "bod_train_get": (C.c_int, [_H, C.c_char_p, C.c_int32, C.c_int32, _F, C.c_int64]),
+    "bod_train_set": (C.c_int, [_H, C.c_char_p, C.c_int32, C.c_int32, _F, C.c_int64]),
+    "bod_train_step_count": (C.c_int, [_H, C.POINTER(C.c_int64), C.c_int64]),
     "bod_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F, _F, _F, _F, _F, _F,
                                     C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_float,
                                     C.c_float, C.c_float, C.POINTER(C.c_double), _F, _F, _F]),

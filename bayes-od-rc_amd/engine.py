@@ -284,6 +284,19 @@ class Engine(object):
         self._chk(self.lib.bod_train_get(self.h, layer.encode(), kinds[kind], whats[what], fptr(out), out.size))
         return out
 
+    def train_set_moment(self, layer, kind, what, value):
+        """Restore an Adam moment (what: 'adam_m' | 'adam_v') of a trainable tensor (checkpoint resume)."""
+        kinds = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3}
+        whats = {"adam_m": 2, "adam_v": 3}
+        a = as_f32(value)
+        self._chk(self.lib.bod_train_set(self.h, layer.encode(), kinds[kind], whats[what], fptr(a), a.size))
+
+    def train_step_count(self, set_to=None):
+        """Number of optimizer updates applied (enters Adam's bias correction); ``set_to`` restores it."""
+        got = C.c_int64(0)
+        self._chk(self.lib.bod_train_step_count(self.h, C.byref(got), -1 if set_to is None else int(set_to)))
+        return int(got.value)
+
     def validation_post(self):
         """validation_utils.post_process_predictions up to the NMS input (softmax, background filter, ranking)."""
         self._chk(self.lib.bod_validation_post(self.h))

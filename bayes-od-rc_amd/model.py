@@ -63,6 +63,8 @@ class RetinaNetModel(object):
             z = np.load(weights)
             d = {}
             for k in z.files:
+                if k.startswith('__optimizer__/'):          # run_training checkpoints carry the Adam state beside the weights
+                    continue
                 layer, field = k.rsplit('/', 1)
                 d.setdefault(layer, {})[field] = z[k]
             weights = d

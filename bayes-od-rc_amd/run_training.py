@@ -82,6 +82,31 @@ class Trainer(object):
             loss_dict['covariance_loss'] = out['covariance_loss']
         return out['total_loss'], loss_dict
 
+    def optimizer_state(self):
+        """{'<layer>/<field>/adam_m' | '.../adam_v': array} + 'optimizer/step', 'trainer/step' -- what tf.train.Checkpoint(step,
+        optimizer, net) stores beside the weights (run_training.py:68-82)."""
+        out = {'optimizer/step': np.asarray(self.engine.train_step_count(), np.int64), 'trainer/step': np.asarray(self.step, np.int64)}
+        for layer, fields in self._init.items():
+            for f, a in fields.items():
+                if a is None or f not in ('kernel', 'bias', 'gamma', 'beta'):
+                    continue
+                try:
+                    for what in ('adam_m', 'adam_v'):
+                        out['%s/%s/%s' % (layer, f, what)] = self.engine.train_get(layer, f, np.asarray(a).shape, what=what)
+                except ValueError:
+                    pass                                 # not a variable of the model (RegHeader's never-called conv_4)
+        return out
+
+    def restore_optimizer_state(self, state):
+        """Inverse of optimizer_state(): Adam moments, the update counter (bias correction) and the trainer's own step (dropout
+        image ids, learning-rate schedule)."""
+        for key, a in state.items():
+            parts = key.split('/')
+            if len(parts) == 3 and parts[2] in ('adam_m', 'adam_v'):
+                self.engine.train_set_moment(parts[0], parts[1], parts[2], a)
+        self.engine.train_step_count(set_to=int(state['optimizer/step']))
+        self.step = int(state['trainer/step'])
+
     def weights(self):
         """Current weights in the ``load_weights`` schema: trained tensors from the device, everything the step does not
         train (batch-norm moving statistics; RegHeader's never-called conv_4) as loaded."""
@@ -137,17 +162,36 @@ def train(config, args):
         z = np.load(weights)
         d = {}
         for k in z.files:
+            if k.startswith(OPT_PREFIX):
+                continue
             layer, field = k.rsplit('/', 1)
             d.setdefault(layer, {})[field] = z[k]
         weights = d
-    trainer = Trainer(config, hw, weights, device=int(args.gpu_device), seed=args.seed)
     ckpt_dir = os.path.join(config_utils.data_dir(), 'outputs', config['checkpoint_name'], 'checkpoints')
     os.makedirs(ckpt_dir, exist_ok=True)
+    # ckpt.restore(manager.latest_checkpoint) (run_training.py:75-82): resume weights, Adam moments and the step counter
+    latest, opt_state = latest_checkpoint(ckpt_dir), None
+    if latest is not None and not getattr(args, 'no_resume', False):
+        z = np.load(latest)
+        weights, opt_state = {}, {}
+        for k in z.files:
+            if k.startswith(OPT_PREFIX):
+                opt_state[k[len(OPT_PREFIX):]] = z[k]
+            else:
+                layer, field = k.rsplit('/', 1)
+                weights.setdefault(layer, {})[field] = z[k]
+        print('Restored from {}'.format(latest))
+    else:
+        print('Initializing from scratch.')
+    trainer = Trainer(config, hw, weights, device=int(args.gpu_device), seed=args.seed)
+    if opt_state:
+        trainer.restore_optimizer_state(opt_state)
     total_steps = args.steps or epoch_size * int(training_config['max_epochs'])
     ckpt_every = max(int(epoch_size * training_config['checkpoint_interval']), 1)
+    keep = int(training_config.get('max_checkpoints_to_keep', 10000))
     last = time.time()
     history = []
-    for step in range(total_steps):
+    for step in range(trainer.step, total_steps):
         lo = (step * mb) % max(len(samples) - mb + 1, 1)
         total_loss, loss_dict = trainer.train_single_step(samples[lo:lo + mb], lr(step))
         history.append(total_loss)
@@ -155,10 +199,31 @@ def train(config, args):
             print('Step {}, Total Loss {:0.3f}, Time Elapsed {:0.3f} s'.format(step, total_loss, time.time() - last))
             last = time.time()
         if (step + 1) % ckpt_every == 0 or step + 1 == total_steps:
-            from .model import RetinaNetModel
-            path = os.path.join(ckpt_dir, 'ckpt-%d.npz' % (step + 1))
-            RetinaNetModel.save_weights_npz(trainer.weights(), path)
+            save_checkpoint(trainer, os.path.join(ckpt_dir, 'ckpt-%d.npz' % (step + 1)))
+            for old in sorted_checkpoints(ckpt_dir)[:-keep]:          # CheckpointManager(max_to_keep) (run_training.py:72-74)
+                os.remove(old)
     return history, ckpt_dir
+
+
+OPT_PREFIX = '__optimizer__/'
+
+
+def sorted_checkpoints(ckpt_dir):
+    files = [f for f in os.listdir(ckpt_dir) if f.startswith('ckpt-') and f.endswith('.npz')]
+    return [os.path.join(ckpt_dir, f) for f in sorted(files, key=lambda f: int(f[5:-4]))]
+
+
+def latest_checkpoint(ckpt_dir):
+    c = sorted_checkpoints(ckpt_dir) if os.path.isdir(ckpt_dir) else []
+    return c[-1] if c else None
+
+
+def save_checkpoint(trainer, path):
+    """Weights in the schema RetinaNetModel.load_weights reads (keys '<layer>/<field>') + the optimizer state under
+    '__optimizer__/...' (ignored by load_weights' consumers: the inference handle only looks weights up by layer name)."""
+    flat = {"%s/%s" % (l, f): a for l, e in trainer.weights().items() for f, a in e.items() if a is not None}
+    flat.update({OPT_PREFIX + k: v for k, v in trainer.optimizer_state().items()})
+    np.savez(path, **flat)
 
 
 def main(argv=None):
@@ -173,6 +238,7 @@ def main(argv=None):
     ap.add_argument('--image_size', type=int, nargs=2, default=[256, 256])
     ap.add_argument('--steps', type=int, default=0)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--no_resume', action='store_true', help='ignore existing checkpoints of this run')
     args = ap.parse_args(argv)
     config = config_utils.setup(config_utils.load_yaml(args.yaml_path), args)
     return train(config, args)

@@ -282,6 +282,12 @@ bod_status bod_train_apply(bod_handle h, float learning_rate, double* grad_norm)
 /* Read a trainable tensor of a training handle back: layer = Keras layer name (conv or batch-norm), kind 0 kernel
  * (HWIO) / 1 bias / 2 gamma / 3 beta, what 0 value / 1 gradient of the last step / 2, 3 Adam moments. */
 bod_status bod_train_get(bod_handle h, const char* layer, int32_t kind, int32_t what, float* out, int64_t n);
+/* Checkpoint / resume of the optimizer (tf.train.Checkpoint(step, optimizer, net) + ckpt.restore(manager.latest_checkpoint),
+ * run_training.py:68-82): bod_train_set writes an Adam moment (what = 2 first, 3 second) of a trainable tensor back -- the
+ * values themselves are restored through bod_load_weight before bod_finalize_weights -- and bod_train_step_count reads
+ * (get != NULL) and / or sets (set >= 0) the number of updates applied so far, which enters Adam's bias correction. */
+bod_status bod_train_set(bod_handle h, const char* layer, int32_t kind, int32_t what, const float* data, int64_t n);
+bod_status bod_train_step_count(bod_handle h, int64_t* get, int64_t set);
 
 /* model.get_loss(sample_dict, prediction_dict) forward (retinanet_model.py:151-328, core/losses.py:30-61;
  * BASELINE config 5's loss, forward only).  Host arrays: cls/cls_targets [B,A,C], box/box_targets [B,A,4],

@@ -113,6 +113,8 @@ bod_status bod_train_step(bod_handle h, const float* images, int32_t images_on_d
 bod_status bod_train_gradients(bod_handle h, void** device_ptr, int64_t* count);
 bod_status bod_train_apply(bod_handle h, float learning_rate, double* grad_norm);
 bod_status bod_train_get(bod_handle h, const char* layer, int32_t kind, int32_t what, float* out, int64_t n);
+bod_status bod_train_set(bod_handle h, const char* layer, int32_t kind, int32_t what, const float* data, int64_t n);
+bod_status bod_train_step_count(bod_handle h, int64_t* get, int64_t set);
 bod_status bod_loss_forward(int32_t device, int32_t B, int32_t A, int32_t C, const float* cls,
                             const float* cls_targets, const float* box, const float* box_targets,
                             const float* covar_params, const float* anchors, const uint8_t* positive_mask,
