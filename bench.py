@@ -227,7 +227,7 @@ def secondary_configs(device, weights, lo):
           dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, 1), B)
     eng.close()
     # ---- config 4's geometry on ONE GPU: 384x1248 (KITTI), N=30, full pipeline
-    hw, B, n = (384, 1248), 16, 30
+    hw, B, n = (384, 1248), 32, 30
     eng = make_engine(hw, B, n, device, weights=weights, anchors=gen.generate_all((hw[0], hw[1], 3)))
     eng.upload_images(synthetic.make_frames(B, hw[0], hw[1], seed=lo))
     steps = 6
@@ -409,6 +409,10 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     for i in range(args.warmup):
         step(i)
     drain()
+    # fault injection for tests/test_gpu_pipeline.py: the named rank dies here, after the warm-up -- the survivors' next collective
+    # must turn into an error report (rank 0 prints the JSON line with "error", every rank exits non-zero), never a hang
+    if os.environ.get("BOD_BENCH_FAULT_RANK") == str(rank):
+        os._exit(17)
     fence()
     # HIP events around every head-tower launch (and every posterior) of the timed steps, recorded on the streams the
     # kernels run on; read back after the closing fence
@@ -480,7 +484,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         more_steps(3)
         fo = eng.profile_end()
         if fo["head_conv_launches"] > 0:
-            fan_out = {"kernel": "conv_igemm_kernel<..., false> (tower layer 0, %d-way dropout fan-out)" % n,
+            fan_out = {"kernel": "conv_igemm_kernel<256,256,2,4,5,true> (tower layer 0, %d-way dropout fan-out)" % n,
                        "achieved": round(fo["head_conv_flops"] / (fo["head_conv_ms"] * 1e-3) / 1e12, 2),
                        "avg_launch_ms": round(fo["head_conv_ms"] / fo["head_conv_launches"], 4), "launches_per_step": 1}
         eng.profile_begin(which=0)

@@ -488,6 +488,34 @@ def test_bench_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in rec
 
 
+def test_bench_reports_a_dead_peer_instead_of_hanging():
+    """Multi-GPU hardening: rank 1 dies after the warm-up (BOD_BENCH_FAULT_RANK); every collective is bounded
+    (BOD_BENCH_COLLECTIVE_TIMEOUT_S), so rank 0 leaves its barrier with an error, still prints the ONE JSON line -- with an
+    "error" field and no throughput claim -- and the job exits non-zero within the timeout."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BOD_BENCH_BACKEND="gloo", BOD_BENCH_SHARE_GPU="1", BOD_BENCH_FAULT_RANK="1", BOD_BENCH_COLLECTIVE_TIMEOUT_S="20")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert time.time() - t0 < 300
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(line[0])
+    assert "error" in rec and rec["value"] is None and rec["n_gpus"] == 2
+
+
 def test_sample_sharded_two_ranks_on_one_gpu():
     """The MC-sample-sharded mode with a real process group (2 ranks, both on this box's GPU, gloo): every rank computes
     3 of 6 samples, the all-gather rebuilds the ensemble, detections equal the single-handle run bit for bit."""
