@@ -3,7 +3,8 @@
 (one --pmc FETCH_SIZE, one --pmc WRITE_SIZE; MI355X_MICROARCH.md: separate passes, FETCH_SIZE is in KiB and
 under-counts wide coalesced reads by 2x on gfx950, WRITE_SIZE in KiB).
 
-usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> B N H W > profiles/roundX_head_conv_pmc.json
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> B N H W [raw] > profiles/roundX_head_conv_pmc.json
+("raw": the plan without the fused MC aggregation, BOD_FUSE_AGGREGATION=0 -- the last layers then write the fp32 [B,N,A,.] tensors)
 
 The head launches of a step are the four conv_igemm dispatches that precede post_sample_kernel."""
 import csv, json, sys
@@ -37,11 +38,15 @@ assert steps >= 1, "no post_sample_kernel dispatch found"
 act = lambda rows, heads: rows * 256 * 2 * heads
 wts = lambda heads: 9 * 256 * 256 * 2 * heads
 raw = {"cls": B * N * A * 8 * 4, "box": B * N * A * 4 * 4, "cov": B * N * A * 10 * 4}
+agg = {"cls": B * A * 8 * 4, "box": B * A * 16 * 4, "cov": B * A * 10 * 4}       # per-anchor MC statistics (fused aggregation)
+fused_agg = not (len(sys.argv) > 7 and sys.argv[7] == "raw")
+out = agg if fused_agg else raw
+tail = "fused 1x1 + MC aggregation -> per-anchor statistics" if fused_agg else "fused 1x1 -> fp32 [B,N,A,.] outputs"
 algo = [  # (label, read bytes, write bytes)
     ("head layer 0 (de-duplicated, %d-way dropout fan-out)" % N, act(B * P, 1) + wts(3), act(B * N * P, 3)),
     ("head layer 1", act(B * N * P, 3) + wts(3), act(B * N * P, 3)),
-    ("head layer 2 (regression tower ends: fused 1x1 -> fp32 box output)", act(B * N * P, 3) + wts(3), act(B * N * P, 2) + raw["box"]),
-    ("head layer 3 (cls + cov, fused 1x1 -> fp32 outputs)", act(B * N * P, 2) + wts(2), raw["cls"] + raw["cov"]),
+    ("head layer 2 (regression tower ends: %s)" % tail, act(B * N * P, 3) + wts(3), act(B * N * P, 2) + out["box"]),
+    ("head layer 3 (cls + cov: %s)" % tail, act(B * N * P, 2) + wts(2), out["cls"] + out["cov"]),
 ]
 launches = []
 for k in range(4):
@@ -53,7 +58,8 @@ for k in range(4):
                      "algorithmic_read_bytes": algo[k][1], "algorithmic_write_bytes": algo[k][2]})
 tot = sum(l["hbm_read_bytes_corrected"] + l["hbm_write_bytes"] for l in launches)
 print(json.dumps({
-    "what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary",
+    "mc_aggregation_fused": fused_agg,
     "config": {"height": H, "width": W, "mc_samples": N, "batch": B},
     "correction": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide coalesced reads), WRITE_SIZE x 1024",
     "steps_averaged": steps, "launches": launches,
