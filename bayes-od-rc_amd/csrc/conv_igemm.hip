@@ -1095,12 +1095,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int bx = blockIdx.x;
+    int bx = blockIdx.x, gz = blockIdx.z;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, blockIdx.z, bx, blockIdx.y, smem);
+    // Groups that READ THE SAME INPUT (the first tower layer: three heads on one pyramid) are launched interleaved in x --
+    // grid (tiles * groups, ny, 1), work item = tile * groups + group -- so that a pixel tile's three workgroups run back to
+    // back on one XCD and the second and third find the pyramid rows in that XCD's L2 (grid.z-major order re-read the
+    // 0.78 GB pyramid from HBM once per head: 3.2 GB fetched for 0.72 GB algorithmic, profiles/round2_head_conv_pmc.json)
+    if (gridDim.z == 1 && a.groups > 1 && a.ksplit <= 1) { gz = bx % a.groups; bx = bx / a.groups; }
+    conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, gz, bx, blockIdx.y, smem);
 }
 
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
@@ -1158,6 +1163,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(nx, ny, a.groups * (a.ksplit > 1 ? a.ksplit : 1));
+    if (ABL == 5 && a.groups > 1 && a.ksplit <= 1) grid = dim3(nx * a.groups, ny, 1);      // shared-input groups, interleaved (see the kernel)
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::LDS, s, a);
     return hipGetLastError();
 }

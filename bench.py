@@ -501,7 +501,9 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                 pmc = json.load(fp)
             c = pmc["config"]
             if (c["height"], c["width"], c["mc_samples"], c["batch"]) == (hw[0], hw[1], n, B) and args.precision == "bf16":
-                sel = [l for l in pmc["launches"] if ("true>" in l["kernel"]) == tower_only or not tower_only]
+                # the per-sample tower launches = the row-reuse kernel's production symbol <256,256,2,4,0,true,...>
+                is_tower = lambda l: "4, 0, true" in l["kernel"] or l["kernel"].rstrip().endswith("true>(ConvArgs)") and ", 5, true" not in l["kernel"]
+                sel = [l for l in pmc["launches"] if is_tower(l) == tower_only or not tower_only]
                 traffic = int(sum(l["hbm_read_bytes_corrected"] + l["hbm_write_bytes"] for l in sel) / len(sel))
                 break
         except (OSError, KeyError, ValueError, ZeroDivisionError):
