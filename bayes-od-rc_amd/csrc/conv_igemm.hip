@@ -186,6 +186,32 @@ struct KTilePipe {
         }
     }
 
+    // The same products in the same order per accumulator with a smaller live set (B fragments of the half + one A pair at a
+    // time: 32 fragment registers instead of 48) for the row-reuse loop, whose staging state leaves fewer registers.
+    __device__ __forceinline__ void run_split_lean(f32x16 (&acc)[FC][FP]) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 Bh[FP], Bl[FP];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { if (h == 0) Bh[j] = Bc[j]; else Bh[j] = ldB(j, h); }
+#pragma unroll
+            for (int j = 0; j < FP; ++j) Bl[j] = ldB(j, 2 + h);
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                bf16x8 Ah, Al;
+                if (h == 0 && i < (FC == 4 ? 2 : FC)) Ah = Ac[i]; else Ah = ldA(i, h);
+                Al = ldA(i, 2 + h);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
     __device__ __forceinline__ void run(f32x16 (&acc)[FC][FP]) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FC == 4 && FP == 2) {
@@ -340,7 +366,7 @@ __device__ __forceinline__ void agg_reduce_cov(const ConvGroup& G, const float* 
 
 template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
-    static_assert(!(SPLIT && XR) && !(SPLIT && ABL != 0), "the bf16x3 mode runs on the generic loop, production build only");
+    static_assert(!(SPLIT && ABL != 0), "the bf16x3 mode exists as production build only");
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = THREADS;            // threads that stage
@@ -519,6 +545,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
                 for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
                 pipe.first_loads();
+                if constexpr (SPLIT) {
+                    // bf16x3 on the row-reuse staging: the next tile's pieces go out under the first fragment loads, then the
+                    // six k-steps of the (hi, lo) products (compiler-scheduled: three times the MFMAs per staged tile)
+                    if (wnext) {
+#pragma unroll
+                        for (int i = 0; i < NW; ++i) {
+                            int off = woff + i * wrs;
+                            asm volatile("" : "+s"(off));
+                            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + wdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                        }
+                    }
+                    if (xnext) {
+#pragma unroll
+                        for (int i = 0; i < NXE; ++i)
+                            if (i == 2 * kxc || i == 2 * kxc + 1) {
+                                xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
+                                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]), LDS_PTR(smem + xdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                            }
+                    }
+                    pipe.run_split_lean(acc);
+                    continue;
+                }
                 bf16x8 A23[2], Bn[2];
 #define MFMA_ROW(I, AF) \
     acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, pipe.Bc[0], acc[I][0], 0, 0, 0); \
@@ -808,6 +856,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             const int ch = slot >> 3;
                             *reinterpret_cast<uint2*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = hi;
                             *reinterpret_cast<uint2*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = lo;
+                            __builtin_amdgcn_sched_barrier(0);           // one 4-channel run at a time (register pressure)
                         }
                     }
                 }
@@ -1289,8 +1338,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (forced == 128) big = false;
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
-    if (a.split) {                                   // bf16x3: generic loop only (no row reuse, no fused 1x1, no ablation builds)
-        if (a.xreuse || a.variant != 0 || a.cin % 128 != 0) return hipErrorInvalidValue;
+    if (a.split) {                                   // bf16x3: no fused 1x1, no ablation builds, no fan-out on the row-reuse loop
+        if (a.variant != 0 || a.cin % 128 != 0 || (a.xreuse && (a.xreuse != 2 || a.fan_count > 1))) return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
     }
     if (a.ksplit > 1) {
@@ -1306,6 +1355,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         return hipGetLastError();
     }
     if (a.split) {
+        if (a.xreuse) {
+            if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
+            return launch_cfg<256, 256, 2, 4, 0, true, true>(a, s);
+        }
         if (big) return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
         if (a.cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2, 0, false, true>(a, s);
         return launch_cfg<64, 128, 1, 4, 0, false, true>(a, s);

@@ -584,7 +584,7 @@ bod_status build_plan(bod_context* h) {
     // Activation row reuse for the per-sample 3x3 tower layers: re-pack the rows into 256-slot tiles made
     // of runs of x-adjacent pixels and list each tile's extended input rows (kernels.h, ConvArgs::ext).
     RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
-    bool xreuse = h->es == 2 && !train_mode;          // (bf16x3 runs on the generic loop: es == 4 there)
+    bool xreuse = (h->es == 2 || h->split) && !train_mode;      // bf16 and bf16x3 (the per-sample tower layers; the fan-out layer of bf16x3 stays on the generic loop)
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -631,7 +631,7 @@ bod_status build_plan(bod_context* h) {
     // its launch is on the 256x256 tile (conv_igemm.hip: from 1 024 tiles on): activation reads x4.5 -> x1.2 of the
     // algorithmic bytes (profiles/round1_head_conv_pmc.json, launch 0).  BOD_FAN_XREUSE=0: A/B aid.
     RowEnt* d1x = nullptr; int2* dext1 = nullptr; int m1x = 0;
-    bool xreuse0 = xreuse && N > 1;
+    bool xreuse0 = xreuse && N > 1 && !h->split;
     if (const char* e = getenv("BOD_FAN_XREUSE")) xreuse0 = xreuse0 && atoi(e) != 0;
     {
         ConvArgs probe{};
