@@ -196,9 +196,11 @@ def test_fused_head_output_equals_separate_launches():
         assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max())), k
 
 
-def test_activation_row_reuse_is_bit_identical():
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_activation_row_reuse_is_bit_identical(precision):
     """Row-reuse staging of the 3x3 tower layers (extended rows shared by the three kx taps) changes
-    only how activations reach LDS, not a single bit of the result."""
+    only how activations reach LDS, not a single bit of the result -- in the bf16 mode and in the bf16x3 mode (whose
+    row-reuse loop issues the same (hi, lo) products in the same order per accumulator as the generic loop)."""
     import os
     import subprocess
     import sys
@@ -207,11 +209,11 @@ def test_activation_row_reuse_is_bit_identical():
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bayes_od_rc_amd import synthetic\n"
             "from bayes_od_rc_amd.engine import Engine, make_config\n"
-            "eng = Engine(make_config((96, 160), batch=2, mc_samples=3))\n"
+            "eng = Engine(make_config((96, 160), batch=2, mc_samples=3, precision=%r))\n"
             "eng.load_weights(synthetic.make_weights())\n"
             "eng.forward(synthetic.make_frames(2, 96, 160, seed=8), seed=5, first_image_id=1)\n"
             "c, b, v = eng.get_raw()\n"
-            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % root)
+            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % (root, precision))
     outs = []
     for xr in ("1", "0"):
         with tempfile.TemporaryDirectory() as d:
