@@ -475,6 +475,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     phase_stamp<ABL>(tstamp, 0);            // tile set-up (row table, bias, pointers)
     if (loader && !XR) issue(0, 0, 0, 0);
     int cur = 0;
+    // Dropout decisions drawn INSIDE the main loop (row-reuse tower kernel, per-sample layers): the 16 Philox calls of a lane's
+    // tile -- their counters are known before the first K-tile -- run one round at a time in the MFMA shadows of the first 8
+    // (chunk, ky) groups and leave 128 keep bits (call q = j*8 + i*2 + p -> one byte); the epilogue only expands them.
+    // Same generator, same counters, same threshold test: bit-identical to drawing them in the epilogue.
+    uint32_t ph_bits[4] = {0u, 0u, 0u, 0u};
+    bool ph_inloop = false;
     if constexpr (XR && ABL != 81) {
         // Row-reuse loop, second generation: (a) compact staging state -- one weight pointer plus scalar
         // row strides, 32-bit activation offsets against the group's base pointer, advanced incrementally
@@ -519,6 +525,27 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0 (k-step ks: ^ (ks << 5))
         const int a_row = (wc * WTC + frow) * ROWB + a_c0;
         const int NG = KT / 3;
+        constexpr bool PH_BUILD = !SPLIT && FP == 2 && (ABL == 0 || ABL == 90 || ABL == 30 || ABL == 31 || ABL == 1 || ABL == 2);
+        const bool ph_on = PH_BUILD && (a.flags & CONV_DROPOUT) && !(a.flags & CONV_OUT_F32) && a.fan_count <= 1 && NG >= 8 && bc0 == 0 &&
+                           a.drop_threshold >= 1 && a.variant != 83;            // (variant 83: decisions drawn in the epilogue, A/B)
+        ph_inloop = ph_on;
+        int2 prg[2] = {make_int2(0, 0), make_int2(0, 0)};
+        uint32_t ph_k0 = a.seed_lo, ph_k1 = a.seed_hi, ph_img = a.image_base, ph_byte_a = 0u;
+        PhiloxState ph{0u, 0u, 0u, 0u, 0u, 0u};
+        if (ph_on) {
+            if (a.dyn_rng) { ph_k0 = a.dyn_rng[0]; ph_k1 = a.dyn_rng[1]; ph_img = a.dyn_rng[2]; }
+            prg[0] = s_rng[wp * WTP + frow];                                 // (written before the barrier above)
+            prg[1] = s_rng[wp * WTP + 32 + frow];
+        }
+        const uint32_t ph_thr = a.drop_threshold;
+        auto ph_compress = [&]() -> uint32_t {                               // 8 keep bits: (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi, w.lo, w.hi)
+            const uint32_t w[4] = {ph.c0, ph.c1, ph.c2, ph.c3};
+            uint32_t b = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                b |= (((w[k] & 0xFFFFu) >= ph_thr) ? 1u : 0u) << (2 * k) | (((w[k] >> 16) >= ph_thr) ? 1u : 0u) << (2 * k + 1);
+            return b;
+        };
         // One (chunk, ky) group = three K-tiles (kx = 0,1,2, unrolled so the staged piece indices are compile-time).
         // The next tile's LDS-DMA pieces are NOT issued in a burst after the barrier (both waves of a SIMD would
         // sit in that burst together with the matrix pipe idle) but one at a time in MFMA shadows: W pieces after
@@ -527,6 +554,30 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             const bool xnext = g + 1 < NG;
             const bool next_row = ky + 1 < 3;
             const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
+            // group g < 8 draws calls q = 2g (slots 0..9) and 2g + 1 (slots 9..19): (j, i, p) = (g >> 2, g & 3, c)
+            const bool ph_act = ph_on && g < 8;
+            auto ph_slot = [&](int sidx) {
+                if (!PH_BUILD || !ph_act || sidx > 19) return;
+                if (sidx == 0 || sidx == 9) {
+                    if (sidx == 9) { philox_rounds(ph, 1); ph_byte_a = ph_compress(); }
+                    const int2 r = (g >> 2) ? prg[1] : prg[0];
+                    ph.c0 = (uint32_t)r.x;
+                    ph.c1 = (uint32_t)((wc * 4 + (g & 3)) * 4 + (sidx == 9 ? 2 : 0) + fhalf);       // dropout_group8(col), bc0 = 0
+                    ph.c2 = (a.sample_base + ((uint32_t)r.y & 0xFFFFu)) | ((uint32_t)G.layer_id << 16);
+                    ph.c3 = ph_img + ((uint32_t)r.y >> 16);
+                    ph.k0 = ph_k0; ph.k1 = ph_k1;
+                    if (sidx == 0) philox_rounds(ph, 1);
+                    return;
+                }
+                philox_rounds(ph, 1);
+                if (sidx == 19) {
+                    const uint32_t n16 = (ph_byte_a << 8) | ph_compress();
+                    ph_bits[3] = (ph_bits[3] << 16) | (ph_bits[2] >> 16);
+                    ph_bits[2] = (ph_bits[2] << 16) | (ph_bits[1] >> 16);
+                    ph_bits[1] = (ph_bits[1] << 16) | (ph_bits[0] >> 16);
+                    ph_bits[0] = (ph_bits[0] << 16) | n16;
+                }
+            };
 #pragma unroll
             for (int kxc = 0; kxc < 3; ++kxc) {
                 const int kt = g * 3 + kxc;
@@ -583,18 +634,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0) { DMA_W(0) } else if (ks == 1) { DMA_W(2) } else { DMA_X(2 * kxc) }
+                    ph_slot(kxc * 7 + ks * 2);
                     __builtin_amdgcn_sched_barrier(0);
                     pipe.Ac[0] = pipe.ldA(0, ks + 1); pipe.Ac[1] = pipe.ldA(1, ks + 1);
                     MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
                     SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks == 0) { DMA_W(1) } else if (ks == 1) { DMA_W(3) } else { DMA_X(2 * kxc + 1) }
+                    ph_slot(kxc * 7 + ks * 2 + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     pipe.Bc[0] = Bn[0]; pipe.Bc[1] = Bn[1];
                 }
                 A23[0] = pipe.ldA(2, 3); A23[1] = pipe.ldA(3, 3);
                 MFMA_ROW(0, pipe.Ac[0]) MFMA_ROW(1, pipe.Ac[1])
                 SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(1); SGB_DSRD(1); SGB_MFMA(2);
+                __builtin_amdgcn_sched_barrier(0);
+                ph_slot(kxc * 7 + 6);
+                __builtin_amdgcn_sched_barrier(0);
                 MFMA_ROW(2, A23[0]) MFMA_ROW(3, A23[1])
                 SGB_MFMA(4);
 #undef MFMA_ROW
@@ -1015,7 +1071,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
                     uint2 o = pk[i][j][g4];
-                    if (drop) {
+                    if (drop && ph_inloop) {
+                        // decisions drawn in the main loop: call q = j*8 + i*2 + (g4>>1) left its byte at a fixed bit position
+                        const int q = j * 8 + i * 2 + (g4 >> 1);
+                        const int bitpos = (7 - (q >> 1)) * 16 + ((q & 1) ? 0 : 8) + (g4 & 1) * 4;      // 4 bits: (w0.lo, w0.hi, w1.lo, w1.hi)
+                        const uint32_t word = ph_bits[bitpos >> 5];
+                        const int sh = bitpos & 31;
+                        auto bit_mask = [](uint32_t v, int pos) { return (uint32_t)((int32_t)(v << (31 - pos)) >> 31); };    // 0 or ~0
+                        o.x &= __builtin_amdgcn_perm(bit_mask(word, sh + 1), bit_mask(word, sh), 0x07060100u);
+                        o.y &= __builtin_amdgcn_perm(bit_mask(word, sh + 3), bit_mask(word, sh + 2), 0x07060100u);
+                    } else if (drop) {
                         // dropout contract v2: one Philox call decides 8 channels with 16-bit words -- the lane's
                         // channel groups g4 = 2p and 2p+1 share the call keyed by (col>>5, p, fhalf)
                         if ((g4 & 1) == 0) {
@@ -1377,7 +1442,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         if (a.variant == 90) return launch_cfg<256, 256, 2, 4, 90, true>(a, s);   // phase clock
         if (a.variant == 96) return launch_xr_persistent<0>(a, s);                                      // persistent, one workgroup per CU
         if (a.variant == 31) return launch_cfg<256, 256, 2, 4, 31, true>(a, s);   // epilogue ends after bias/ReLU/pack
-        if (a.variant != 0) return hipErrorInvalidValue;
+        if (a.variant != 0 && a.variant != 83) return hipErrorInvalidValue;       // 83: production build, dropout decisions drawn in the epilogue (A/B)
         // the N-way fan-out launch of the first tower layer is its own kernel symbol (ABL = 5: the production code, of which
         // it runs the loop and the register-resident fan-out epilogue), so that a kernel trace lists the per-sample tower
         // launches -- the roofline kernel of bench.py -- and the fan-out launch separately
