@@ -36,6 +36,7 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -138,6 +139,16 @@ void conv_igemm_phase_cycles(unsigned long long* out16, bool reset) {
 // one read is slotted per MFMA, so the only exposed LDS wait is the first fragment set after the block barrier.
 #define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define SGB_DSRD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+// D = C tied in place: with the builtin the register allocator renames the 32 four-register accumulators of the 16x16x32 loop
+// through fresh tuples on every MFMA and runs out of registers; the tied form keeps each accumulator where it is.  The
+// instruction stream is then the program order (volatile), which is how the loop below is written anyway.  (Same-accumulator
+// MFMAs are 32 instructions apart; the epilogue's first read of an accumulator comes after s_nops + a workgroup barrier.)
+__device__ __forceinline__ void mfma16_inplace(f32x4& c, const bf16x8& a, const bf16x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+
 template <int FC, int FP, int ROWB>
 struct KTilePipe {
     const char* smem; int wa; int xb[FP];
@@ -466,6 +477,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         for (int j = 0; j < FP; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // M16: the row-reuse tower kernel multiplies with v_mfma_f32_16x16x32_bf16.  Under the power limit of a launch that
+    // keeps all 1 024 matrix pipes busy on random data, a register-resident loop of that instruction sustains 2.1 PF/s on
+    // MI355X, the 32x32x16 form 1.3 PF/s (tests/tools/mfma_power.hip) -- the rate at which the 32x32 loop and the vendor
+    // library's GEMMs level off.  Same LDS image, same swizzle (conflict-free for the 16-row fragments too), same bytes per
+    // FLOP (wave tile 128 x 64 = 8 x 4 fragments of 16 x 16): a lane then holds, per fragment, 4 consecutive couts
+    // (fc*16 + (lane>>4)*4 + r) of pixel fp*16 + (lane & 15).
+    constexpr bool M16 = XR && !SPLIT && ABL != 81 && BC == 256 && BP == 256 && WC == 2 && WP == 4;
+    constexpr int FC16 = M16 ? 8 : 1, FP16 = M16 ? 4 : 1;
+    f32x4 acc4[FC16][FP16];
+#pragma unroll
+    for (int i = 0; i < FC16; ++i)
+#pragma unroll
+        for (int j = 0; j < FP16; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, q4 = lane >> 4;
 
     const int frow = lane & 31;
     const int fswz = (frow >> 1) & 7;
@@ -507,6 +532,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         int xrow[FP];
 #pragma unroll
         for (int j = 0; j < FP; ++j) xrow[j] = a.rows[bp0 + wp * WTP + j * 32 + frow].pad1;
+        int xrow16[FP16];                                                    // M16: extended-row index of the lane's pixel in each 16-pixel fragment
+#pragma unroll
+        for (int j = 0; j < FP16; ++j) xrow16[j] = M16 ? a.rows[bp0 + wp * WTP + j * 16 + l15].pad1 : 0;
         auto issue_wx = [&](int stage, int ky_, int kx_, int cc_) {
             const int woff = ((ky_ * 3 + kx_) * a.cin + cc_ * BK) * 2;
 #pragma unroll
@@ -534,8 +562,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         PhiloxState ph{0u, 0u, 0u, 0u, 0u, 0u};
         if (ph_on) {
             if (a.dyn_rng) { ph_k0 = a.dyn_rng[0]; ph_k1 = a.dyn_rng[1]; ph_img = a.dyn_rng[2]; }
-            prg[0] = s_rng[wp * WTP + frow];                                 // (written before the barrier above)
-            prg[1] = s_rng[wp * WTP + 32 + frow];
+            if (!M16) {
+                prg[0] = s_rng[wp * WTP + frow];                             // (written before the barrier above)
+                prg[1] = s_rng[wp * WTP + 32 + frow];
+            }
         }
         const uint32_t ph_thr = a.drop_threshold;
         auto ph_compress = [&]() -> uint32_t {                               // 8 keep bits: (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi, w.lo, w.hi)
@@ -560,9 +590,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 if (!PH_BUILD || !ph_act || sidx > 19) return;
                 if (sidx == 0 || sidx == 9) {
                     if (sidx == 9) { philox_rounds(ph, 1); ph_byte_a = ph_compress(); }
-                    const int2 r = (g >> 2) ? prg[1] : prg[0];
+                    int2 r;
+                    if constexpr (M16) {
+                        // 16x16 accumulator layout: call index 2g + c = fp*4 + t decides the 8 channels {16(2t)+4(q4&1).., +8..} of pixel
+                        // fragment fp; the lane pair (l, l^32) needs both calls of t's two cout fragments: the lower half draws the one
+                        // of fragment 2t, the upper half that of 2t+1, and they swap bytes after the loop (same counters as ever)
+                        r = s_rng[wp * WTP + (g >> 1) * 16 + l15];
+                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);    // dropout_group8(wc*128 + (2t + (q4>>1))*16 + (q4&1)*4)
+                    } else {
+                        r = (g >> 2) ? prg[1] : prg[0];
+                        ph.c1 = (uint32_t)((wc * 4 + (g & 3)) * 4 + (sidx == 9 ? 2 : 0) + fhalf);   // dropout_group8(col), bc0 = 0
+                    }
                     ph.c0 = (uint32_t)r.x;
-                    ph.c1 = (uint32_t)((wc * 4 + (g & 3)) * 4 + (sidx == 9 ? 2 : 0) + fhalf);       // dropout_group8(col), bc0 = 0
                     ph.c2 = (a.sample_base + ((uint32_t)r.y & 0xFFFFu)) | ((uint32_t)G.layer_id << 16);
                     ph.c3 = ph_img + ((uint32_t)r.y >> 16);
                     ph.k0 = ph_k0; ph.k1 = ph_k1;
@@ -593,6 +632,61 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 pipe.smem = smem;
                 pipe.wa = (kt & 1) * WST + a_row;
                 const int xbase = 2 * WST + (g & 1) * XBUF;
+                if constexpr (M16) {
+                    // ---- 16x16x32 body: two k-steps of 32, per k-step 8 A fragments x 4 B fragments = 32 MFMAs.  A fragments in a
+                    // ring of four (loaded two cout fragments ahead), the next k-step's B fragments while the first four cout
+                    // fragments multiply; one ds_read_b128 slotted per MFMA or two; DMA pieces and Philox rounds after every
+                    // second cout fragment.
+                    const int wa16 = (kt & 1) * WST + (wc * WTC + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4);
+                    int xb16[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = xrow16[j] + kxc; xb16[j] = xbase + r * ROWB + ((q4 ^ ((r >> 1) & 7)) << 4); }
+                    auto ldA16 = [&](int fc, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((wa16 ^ (ks << 6)) + fc * 16 * ROWB)); };
+                    auto ldB16 = [&](int fp, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (xb16[fp] ^ (ks << 6))); };
+                    bf16x8 Ar[3], Bc[4];                     // A ring of three (the fragment in use and the next two); ONE set of B fragments:
+                    // the second k-step's replace the first's one by one behind the last cout fragment's MFMAs (no second register set)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Bc[j] = ldB16(j, 0);
+                    Ar[0] = ldA16(0, 0); Ar[1] = ldA16(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#define DMA_W(I) if (wnext) { int off = woff + (I) * wrs; asm volatile("" : "+s"(off)); \
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + wdst + ((I) * THREADS + wave * 64) * 16), 16, 0, 0); }
+#define DMA_X(I) if ((I) < NXE && xnext && ABL != 2) { xo[(I) < NXE ? (I) : 0] += next_row ? (uint32_t)xp[(I) < NXE ? (I) : 0] : (uint32_t)(BK * 2 - 2 * xp[(I) < NXE ? (I) : 0]); \
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[(I) < NXE ? (I) : 0]), LDS_PTR(smem + xdst + (((I) < NXE ? (I) : 0) * THREADS + wave * 64) * 16), 16, 0, 0); }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int fc = 0; fc < 8; ++fc) {
+                            int reads = 0;
+                            const int seq = ks * 8 + fc;             // fragment sequence number 0..15 -> ring slot seq % 3
+                            if (fc + 2 < 8) { Ar[(seq + 2) % 3] = ldA16(fc + 2, ks); ++reads; }
+                            else if (ks == 0) { Ar[(seq + 2) % 3] = ldA16(fc + 2 - 8, 1); ++reads; }
+                            if (ks == 0 && fc == 7) {
+                                // last cout fragment of k-step 0: B fragment j is dead once its MFMA has issued -> its k-step-1 value follows
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    mfma16_inplace(acc4[fc][j], Ar[seq % 3], Bc[j]);
+                                    Bc[j] = ldB16(j, 1);
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) mfma16_inplace(acc4[fc][j], Ar[seq % 3], Bc[j]);
+                            }
+                            (void)reads;
+                            if ((fc & 1) && !(ks == 1 && fc == 7)) {                 // 7 slots per K-tile, after 8, 16, ... 56 MFMAs
+                                const int slot = ks * 4 + (fc >> 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (slot == 0) { DMA_W(0) } else if (slot == 1) { DMA_W(1) } else if (slot == 2) { DMA_W(2) } else if (slot == 3) { DMA_W(3) }
+                                else if (slot == 4) { DMA_X(2 * kxc) } else if (slot == 5) { DMA_X(2 * kxc + 1) }
+                                ph_slot(kxc * 7 + slot);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+#undef DMA_W
+#undef DMA_X
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
                 pipe.first_loads();
@@ -751,8 +845,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
     }
 
+    if constexpr (M16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last in-place MFMAs have retired before any VALU reads an accumulator
+#endif
+    }
     phase_stamp<ABL>(tstamp, 1);            // main loop
     if (ABL == 1) {
+#pragma unroll
+        for (int i = 0; i < FC16; ++i)
+#pragma unroll
+            for (int j = 0; j < FP16; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(acc4[i][j]));
+#endif
+            }
 #pragma unroll
         for (int i = 0; i < FC; ++i)
 #pragma unroll
@@ -958,9 +1065,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     }
     // phase A: finish the arithmetic and pack to bf16 (halves the live registers before the RNG):
     // rounding(x*scale) then zeroing == zeroing then rounding, so the mask is applied on packed words
+    uint2 pk16[FC16][FP16];                           // M16: (cout fragment, pixel fragment) -> the lane's 4 packed channels
+    if constexpr (M16) {
+#pragma unroll
+        for (int fp = 0; fp < FP16; ++fp)
+#pragma unroll
+            for (int fc = 0; fc < FC16; ++fc) {
+                const float4 bv = *reinterpret_cast<const float4*>(s_bias + wc * WTC + fc * 16 + q4 * 4);
+                pk16[fc][fp].x = pack_bf16x2(__builtin_fmaf(acc4[fc][fp][0], epi_scale, bv.x), __builtin_fmaf(acc4[fc][fp][1], epi_scale, bv.y));
+                pk16[fc][fp].y = pack_bf16x2(__builtin_fmaf(acc4[fc][fp][2], epi_scale, bv.z), __builtin_fmaf(acc4[fc][fp][3], epi_scale, bv.w));
+                if (relu) { pk16[fc][fp].x = relu_bf16x2_pk(pk16[fc][fp].x); pk16[fc][fp].y = relu_bf16x2_pk(pk16[fc][fp].y); }
+            }
+    }
     uint2 pk[FC][FP][4];
 #pragma unroll
-    for (int j = 0; j < FP; ++j) {
+    for (int j = 0; j < (M16 ? 0 : FP); ++j) {
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
 #pragma unroll
@@ -1015,8 +1134,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // through LDS ONCE; each thread then keeps (pixel, 16-channel group) items in registers and, per sample, draws
         // the group's two Philox calls (contract v2: a call decides channels {x..x+3, x+8..x+11}), masks and stores
         // 2 x 16 bytes -- no LDS traffic and no barrier inside the sample loop.
+        if constexpr (M16) {
 #pragma unroll
-        for (int j = 0; j < FP; ++j) {
+            for (int fp = 0; fp < FP16; ++fp) {
+                const int pixl = wp * WTP + fp * 16 + l15;
+                char* prow = smem + pixl * (BC * 2);
+#pragma unroll
+                for (int fc = 0; fc < FC16; ++fc) {
+                    const int col = wc * WTC + fc * 16 + q4 * 4;
+                    *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = pk16[fc][fp];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (M16 ? 0 : FP); ++j) {
             const int pixl = wp * WTP + j * 32 + frow;
             char* prow = smem + pixl * (BC * 2);
 #pragma unroll
@@ -1057,9 +1188,50 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
         return;
     }
-    for (int n = 0; n < fan; ++n) {
+    // M16: the partner lane (l ^ 32) drew the calls of the other cout fragment of each pair: fetch its 128 keep bits once
+    uint32_t ph_oth[4] = {0u, 0u, 0u, 0u};
+    if constexpr (M16) {
+        if (drop && ph_inloop) {
 #pragma unroll
-        for (int j = 0; j < FP; ++j) {
+            for (int k = 0; k < 4; ++k) ph_oth[k] = (uint32_t)__shfl_xor((int)ph_bits[k], 32, 64);
+        }
+    }
+    for (int n = 0; n < fan; ++n) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int fp = 0; fp < FP16; ++fp) {
+                const int pixl = wp * WTP + fp * 16 + l15;
+                char* prow = smem + pixl * (BC * 2);
+                const int2 rg = s_rng[pixl];
+                const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
+                const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
+#pragma unroll
+                for (int fc = 0; fc < FC16; ++fc) {
+                    const int col = wc * WTC + fc * 16 + q4 * 4;
+                    uint2 o = pk16[fc][fp];
+                    if (drop && ph_inloop) {
+                        // call idx = fp*4 + (fc>>1) left its byte at a fixed position; the lane's nibble is decisions (q4>>1)*4 .. +3
+                        const int idx = fp * 4 + (fc >> 1);
+                        const int bitpos = (7 - (idx >> 1)) * 16 + ((idx & 1) ? 0 : 8);
+                        const uint32_t src = ((fc & 1) == (q4 >> 1)) ? ph_bits[bitpos >> 5] : ph_oth[bitpos >> 5];
+                        const uint32_t nib = src >> ((bitpos & 31) + (q4 >> 1) * 4);
+                        auto bit_mask = [](uint32_t v, int pos) { return (uint32_t)((int32_t)(v << (31 - pos)) >> 31); };    // 0 or ~0
+                        o.x &= __builtin_amdgcn_perm(bit_mask(nib, 1), bit_mask(nib, 0), 0x07060100u);
+                        o.y &= __builtin_amdgcn_perm(bit_mask(nib, 3), bit_mask(nib, 2), 0x07060100u);
+                    } else if (drop) {
+                        // decisions drawn here: the call of this lane's own fragment (its partner lane draws the same one)
+                        Philox4 rr;
+                        if (ABL == 4) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rg.x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
+                        else rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
+                        o.x &= keep_mask_u16x2((q4 >> 1) ? rr.z : rr.x, thr_m1_x2);
+                        o.y &= keep_mask_u16x2((q4 >> 1) ? rr.w : rr.y, thr_m1_x2);
+                    }
+                    *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (M16 ? 0 : FP); ++j) {
             const int pixl = wp * WTP + j * 32 + frow;
             char* prow = smem + pixl * (BC * 2);
             const uint32_t img = rng_image_base + ((uint32_t)rng[j].y >> 16);
