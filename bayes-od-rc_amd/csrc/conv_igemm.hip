@@ -676,8 +676,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             if ((fc & 1) && !(ks == 1 && fc == 7)) {                 // 7 slots per K-tile, after 8, 16, ... 56 MFMAs
                                 const int slot = ks * 4 + (fc >> 1);
                                 __builtin_amdgcn_sched_barrier(0);
+                                // next K-tile's weights (L2-resident) first; the next GROUP's extended rows (HBM / Infinity Cache: a microsecond
+                                // under load) as early in the group as possible -- pieces 0..2 in its first K-tile, 3..4 in the second -- so that
+                                // every piece has more than a K-tile to land before the vmcnt(0) that precedes its first reader
                                 if (slot == 0) { DMA_W(0) } else if (slot == 1) { DMA_W(1) } else if (slot == 2) { DMA_W(2) } else if (slot == 3) { DMA_W(3) }
-                                else if (slot == 4) { DMA_X(2 * kxc) } else if (slot == 5) { DMA_X(2 * kxc + 1) }
+                                else if (kxc == 0) { DMA_X(slot - 4) } else if (kxc == 1 && slot < 6) { DMA_X(slot - 1) }
                                 ph_slot(kxc * 7 + slot);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
