@@ -617,6 +617,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     ph_bits[0] = (ph_bits[0] << 16) | n16;
                 }
             };
+            bf16x8 Bc16[4];          // M16: the B fragments live across the K-tiles of a group (see the body below)
 #pragma unroll
             for (int kxc = 0; kxc < 3; ++kxc) {
                 const int kt = g * 3 + kxc;
@@ -643,10 +644,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     for (int j = 0; j < 4; ++j) { const int r = xrow16[j] + kxc; xb16[j] = xbase + r * ROWB + ((q4 ^ ((r >> 1) & 7)) << 4); }
                     auto ldA16 = [&](int fc, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((wa16 ^ (ks << 6)) + fc * 16 * ROWB)); };
                     auto ldB16 = [&](int fp, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (xb16[fp] ^ (ks << 6))); };
-                    bf16x8 Ar[3], Bc[4];                     // A ring of three (the fragment in use and the next two); ONE set of B fragments:
-                    // the second k-step's replace the first's one by one behind the last cout fragment's MFMAs (no second register set)
+                    bf16x8 Ar[3];                            // A ring of three (the fragment in use and the next two); ONE set of B fragments
+                    bf16x8 (&Bc)[4] = Bc16;                  // (Bc16): the next k-step's replace the current one's one by one behind the last cout
+                    // fragment's MFMAs -- also across the K-tiles of a group, whose extended rows are all in LDS since the group's first
+                    // barrier: only the weights' fragments (and, in a group's first K-tile, the activations') wait behind the barrier
+                    if (kxc == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bc[j] = ldB16(j, 0);
+                        for (int j = 0; j < 4; ++j) Bc[j] = ldB16(j, 0);
+                    }
                     Ar[0] = ldA16(0, 0); Ar[1] = ldA16(1, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #define DMA_W(I) if (wnext) { int off = woff + (I) * wrs; asm volatile("" : "+s"(off)); \
@@ -667,6 +672,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 for (int j = 0; j < 4; ++j) {
                                     mfma16_inplace(acc4[fc][j], Ar[seq % 3], Bc[j]);
                                     Bc[j] = ldB16(j, 1);
+                                }
+                            } else if (ks == 1 && fc == 7 && kxc < 2) {
+                                // last cout fragment of the K-tile: the next K-tile of the group reads the same staged rows one extended row further
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    mfma16_inplace(acc4[fc][j], Ar[seq % 3], Bc[j]);
+                                    const int r = xrow16[j] + kxc + 1;
+                                    Bc[j] = *reinterpret_cast<const bf16x8*>(smem + xbase + r * ROWB + ((q4 ^ ((r >> 1) & 7)) << 4));
                                 }
                             } else {
 #pragma unroll
