@@ -595,7 +595,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         // 16x16 accumulator layout: call index 2g + c = fp*4 + t decides the 8 channels {16(2t)+4(q4&1).., +8..} of pixel
                         // fragment fp; the lane pair (l, l^32) needs both calls of t's two cout fragments: the lower half draws the one
                         // of fragment 2t, the upper half that of 2t+1, and they swap bytes after the loop (same counters as ever)
-                        r = s_rng[wp * WTP + (g >> 1) * 16 + l15];
+                        // read by hand: the compiler puts an s_waitcnt vmcnt(0) in front of a plain LDS load that follows an LDS-DMA issue
+                        // (it cannot tell the table from the staging buffers) -- a full L2 round trip with the matrix pipe idle, twice per group
+                        long long rr;
+                        const uint32_t ra = (uint32_t)(uintptr_t)LDS_PTR(&s_rng[wp * WTP + (g >> 1) * 16 + l15]);
+                        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(ra) : "memory");
+                        r.x = (int)(uint32_t)rr; r.y = (int)(uint32_t)((unsigned long long)rr >> 32);
                         ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);    // dropout_group8(wc*128 + (2t + (q4>>1))*16 + (q4&1)*4)
                     } else {
                         r = (g >> 2) ? prg[1] : prg[0];
@@ -621,8 +626,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
             for (int kxc = 0; kxc < 3; ++kxc) {
                 const int kt = g * 3 + kxc;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // This K-tile needs its weights and, in a group's first K-tile, the group's extended rows -- NOT the extended rows of
+                // the next group that went out behind the weights during the previous K-tile (HBM / Infinity Cache: they land a
+                // microsecond later).  Loads retire in order, so the wait leaves exactly those pieces outstanding: the three issued in
+                // the group's first K-tile (kxc 0 -> 1) or the two of its second (kxc 1 -> 2; the first three are older than that
+                // K-tile's weights and long landed).
+                if (M16 && ABL != 2 && xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (M16 && ABL != 2 && xnext && kxc == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (bare s_barrier: __syncthreads() is a fence, before which the compiler waits for every outstanding load.  What the
+                // barrier orders here is LDS-DMA landings, waited for just above, against LDS reads whose data the MFMAs have consumed.)
+                if constexpr (M16) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } else __syncthreads();
                 const bool wnext = kt + 1 < KT && ABL != 2;
                 // weight tile kt+1 = tap (ky, kxc+1) of this chunk, or tap (ky+1 | 0, 0) of the next group's chunk
                 int woff;
