@@ -526,7 +526,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
         for (int i = 0; i < NXE; ++i) {
             const int2 e = a.ext[(size_t)bx * XR_EXT_ROWS + i * (THREADS / 8) + (tid >> 3)];
-            xo[i] = ((uint32_t)(e.x - ext_first) * (uint32_t)a.in_cstride + ldchunk * 8) * 2u;
+            // M16: the extended rows are chunk-ROTATED -- physical chunk = (chunk + (row & 6)) & 7 -- not XOR-swizzled: a B fragment's 16
+            // rows start at ANY extended row, and the rotation keeps every ds_read_b128 lane group (16 lanes = rows {0-3,12-15} at chunk
+            // c and rows {4-11} at c+1, or the reverse) on 16 distinct 4-bank slots for every start row; the XOR form only does for
+            // starts that are multiples of 16 (20 % of the LDS cycles of the loop were bank conflicts, profiles/round2_head_conv_counters.json)
+            const int xchunk = M16 ? ((ltid & 7) - ((ltid >> 3) & 6)) & 7 : ldchunk;
+            xo[i] = ((uint32_t)(e.x - ext_first) * (uint32_t)a.in_cstride + xchunk * 8) * 2u;
             xp[i] = e.y * a.in_cstride * 2;
         }
         int xrow[FP];
@@ -655,7 +660,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     const int wa16 = (kt & 1) * WST + (wc * WTC + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4);
                     int xb16[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const int r = xrow16[j] + kxc; xb16[j] = xbase + r * ROWB + ((q4 ^ ((r >> 1) & 7)) << 4); }
+                    for (int j = 0; j < 4; ++j) { const int r = xrow16[j] + kxc; xb16[j] = xbase + r * ROWB + (((q4 + (r & 6)) & 7) << 4); }
                     auto ldA16 = [&](int fc, int ks) { return *reinterpret_cast<const bf16x8*>(smem + ((wa16 ^ (ks << 6)) + fc * 16 * ROWB)); };
                     auto ldB16 = [&](int fp, int ks) { return *reinterpret_cast<const bf16x8*>(smem + (xb16[fp] ^ (ks << 6))); };
                     bf16x8 Ar[3];                            // A ring of three (the fragment in use and the next two); ONE set of B fragments
@@ -693,7 +698,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 for (int j = 0; j < 4; ++j) {
                                     mfma16_inplace(acc4[fc][j], Ar[seq % 3], Bc[j]);
                                     const int r = xrow16[j] + kxc + 1;
-                                    Bc[j] = *reinterpret_cast<const bf16x8*>(smem + xbase + r * ROWB + ((q4 ^ ((r >> 1) & 7)) << 4));
+                                    Bc[j] = *reinterpret_cast<const bf16x8*>(smem + xbase + r * ROWB + (((q4 + (r & 6)) & 7) << 4));
                                 }
                             } else {
 #pragma unroll
