@@ -1,0 +1,196 @@
+// Anatomy of the tower kernel's K-tile loop: the same per-wave work -- 64 x v_mfma_f32_16x16x32_bf16 per K-tile on a 128 x 64 wave tile,
+// 8 waves per CU -- rebuilt from its parts, which are switched on one at a time: the K-tile barrier, the 24 ds_read_b128 of the A/B
+// fragments, the 6 LDS-DMA pieces per wave (4 weight + 2 activation), and Philox-like integer VALU work in the MFMA shadows.
+// Prints per configuration: time per K-tile per CU, the shader clock (s_memtime cycles / s_memrealtime ticks) and the MFMA duty
+// (2048 matrix-pipe cycles per K-tile per SIMD / measured cycles).  No results are checked: this is a timing instrument.
+// usage (GPU box): hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tests/tools/loop_anatomy.hip -o /tmp/loop_anatomy && /tmp/loop_anatomy
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+enum { F_BAR = 1, F_LDS = 2, F_DMA = 4, F_VALU = 8, F_DMA_DWORD = 16, F_DMA_BURST = 32, F_DMA_NOWAIT = 64, F_PRIO = 128, F_RING5 = 256, F_MIDBAR = 512, F_AGPR = 1024 };
+constexpr int ROWB = 128, WST = 256 * ROWB, XROWS = 320, XBUF = XROWS * ROWB, LDS_BYTES = 2 * WST + 2 * XBUF;
+
+template <bool AGPR>
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));      // accumulators in AGPRs
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+__device__ unsigned long long g_cycles[4];
+
+template <int F>
+__global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc, const char* __restrict__ xsrc, float* __restrict__ out, int ktiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 2, wp = wave & 3, l15 = lane & 15, q4 = lane >> 4;
+    // fill LDS with the (random) source once: every stage holds real data
+    for (int i = tid; i < LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(wsrc)[i];
+    __syncthreads();
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int RN = (F & F_RING5) ? 5 : 3;          // A ring: RN - 1 fragments ahead
+    bf16x8 Ar[RN], Bc[4];
+    #pragma unroll
+    for (int i = 0; i < RN; ++i) Ar[i] = reinterpret_cast<const bf16x8*>(smem)[i * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bc[j] = reinterpret_cast<const bf16x8*>(smem)[(4 + j) * 64 + lane];
+    const uint32_t wlane = (uint32_t)(((tid >> 3) * 2304 + (tid & 7) * 8) * 2);      // a weight row is 2304 elements; 64 rows per piece
+    const uint32_t xlane = (uint32_t)(tid * 16);
+    uint32_t ph0 = tid * 2654435761u, ph1 = tid ^ 0x9E3779B9u, ph2 = 12345u, ph3 = tid + 77u;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    constexpr int AHEAD = RN - 1, BS = (F & F_MIDBAR) ? 16 - AHEAD : 0;      // the barrier sits in front of step BS of the K-tile's 16
+    auto a_addr = [&](int kt_, int st) {          // A fragment of step st (= ks * 8 + fc) of K-tile kt_
+        const int wa = (kt_ & 1) * WST + (wc * 128 + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4);
+        return smem + ((wa ^ ((st >> 3) << 6)) + (st & 7) * 16 * ROWB);
+    };
+    auto b_addr = [&](int kt_, int j, int ks) {
+        const int kxc = kt_ % 3, xb = (kt_ / 3) & 1;
+        const int r = wp * 64 + j * 16 + l15 + kxc;
+        return smem + ((2 * WST + xb * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4)) ^ (ks << 6));
+    };
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int stage = kt & 1, kxc = kt % 3, xb = (kt / 3) & 1;
+        const char* wg = wsrc + (size_t)((kt % 36) * 64) * 2;                        // K-tile kt of the 256 x 2304 weight matrix (L2-resident)
+        const char* xg = xsrc + (size_t)(blockIdx.x % 64) * 65536 + (size_t)(kt % 12) * 40960;
+        const int wdst = (stage ^ 1) * WST, xdst = 2 * WST + (xb ^ 1) * XBUF;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int ks = st >> 3, fc = st & 7;
+            if (st == BS) {
+                if (F & F_DMA) { if (!(F & F_DMA_NOWAIT)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                if ((F & F_MIDBAR) && (F & F_LDS)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage's last readers have their data
+                if (F & F_BAR) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+                if (!(F & F_MIDBAR) && (F & F_LDS)) {
+                    if (kxc == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 0));
+                    }
+#pragma unroll
+                    for (int i = 0; i < AHEAD; ++i) Ar[i] = *reinterpret_cast<const bf16x8*>(a_addr(kt, i));
+                }
+                if ((F & F_DMA) && (F & F_DMA_BURST)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const char* p = wg + (size_t)i * 64 * 2304 * 2; uint32_t wl = wlane; asm volatile("" : "+s"(p), "+v"(wl));
+                        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + wl), LDS_PTR(smem + wdst + (i * 512 + wave * 64) * 16), 16, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const char* p = xg + (size_t)i * 8192; uint32_t xl = xlane; asm volatile("" : "+s"(p), "+v"(xl));
+                        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + xl), LDS_PTR(smem + xdst + (i * 512 + wave * 64) * 16), 16, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (F & F_LDS) {
+                if (st + AHEAD < 16) Ar[(st + AHEAD) % RN] = *reinterpret_cast<const bf16x8*>(a_addr(kt, st + AHEAD));
+                else if (F & F_MIDBAR) Ar[(st + AHEAD) % RN] = *reinterpret_cast<const bf16x8*>(a_addr(kt + 1, st + AHEAD - 16));
+            }
+            if (F & F_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mfma16<(F & F_AGPR) != 0>(acc[fc][j], Ar[st % RN], Bc[j]);
+                if ((F & F_LDS) && st == 7) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 1));
+                if ((F & F_LDS) && st == 15 && (kxc < 2 || (F & F_MIDBAR))) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt + 1, j, 0));
+            }
+            if (F & F_PRIO) __builtin_amdgcn_s_setprio(0);
+            if ((fc & 1) && st != 15) {
+                const int slot = st >> 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if ((F & F_DMA) && !(F & F_DMA_BURST)) {
+                    if (slot < 4) {
+                        const char* p = wg + (size_t)slot * 64 * 2304 * 2; uint32_t wl = wlane; asm volatile("" : "+s"(p), "+v"(wl));
+                        if (F & F_DMA_DWORD) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + wl), LDS_PTR(smem + wdst + (slot * 512 + wave * 64) * 16), 4, 0, 0);
+                        else __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + wl), LDS_PTR(smem + wdst + (slot * 512 + wave * 64) * 16), 16, 0, 0);
+                    } else if (slot < 6) {
+                        const char* p = xg + (size_t)(slot - 4) * 8192; uint32_t xl = xlane; asm volatile("" : "+s"(p), "+v"(xl));
+                        if (F & F_DMA_DWORD) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + xl), LDS_PTR(smem + xdst + ((slot - 4) * 512 + wave * 64) * 16), 4, 0, 0);
+                        else __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + xl), LDS_PTR(smem + xdst + ((slot - 4) * 512 + wave * 64) * 16), 16, 0, 0);
+                    }
+                }
+                if (F & F_VALU) {
+                    // one Philox4x32 round
+                    const unsigned long long p0 = (unsigned long long)ph0 * 0xD2511F53u, p1 = (unsigned long long)ph2 * 0xCD9E8D57u;
+                    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ph1 ^ 0x12345u, n2 = (uint32_t)(p0 >> 32) ^ ph3 ^ 0x6789u;
+                    ph1 = (uint32_t)p1; ph3 = (uint32_t)p0; ph0 = n0; ph2 = n2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (tid == 0) {
+        atomicAdd(&g_cycles[0], __builtin_amdgcn_s_memtime() - t0);
+        atomicAdd(&g_cycles[1], __builtin_amdgcn_s_memrealtime() - r0);
+    }
+    float s = (float)(ph0 ^ ph1 ^ ph2 ^ ph3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int F>
+static void run(const char* name, const char* w, const char* x, float* o, int ktiles) {
+    auto kern = loop_kernel<F>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double best = 1e30; unsigned long long c[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 4; ++rep) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_cycles), z, sizeof z);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, x, o, ktiles);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cycles), sizeof c);
+        if (rep > 0 && ms < best) { best = ms; memcpy(cb, c, sizeof c); }
+    }
+    const double cyc = (double)cb[0] / 256 / ktiles, ghz = (double)cb[0] / (double)cb[1] * 0.1;
+    const double tf = 256.0 * 8 * ktiles * 64 * 16384 / (best * 1e-3) / 1e12;
+    printf("%-58s %7.3f us/K-tile  %6.0f cycles/K-tile  clock %.3f GHz  MFMA duty %.3f  %6.0f TFLOP/s\n", name, best * 1e3 / ktiles, cyc, ghz, 2048.0 / cyc, tf);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+int main() {
+    const int ktiles = 3600;
+    const size_t wbytes = (size_t)256 * 2304 * 2 + (1 << 20), xbytes = (size_t)64 * 65536 + 12 * 40960 + (1 << 20);
+    std::vector<unsigned short> h((wbytes + xbytes) / 2);
+    srand(1);
+    for (auto& v : h) { float f = (rand() % 100 < 50) ? 0.f : ((rand() % 2001) - 1000) / 1000.0f; unsigned u; memcpy(&u, &f, 4); v = u >> 16; }
+    char* d; float* o;
+    hipMalloc(&d, wbytes + xbytes); hipMalloc(&o, 256 * 512 * 4);
+    hipMemcpy(d, h.data(), wbytes + xbytes, hipMemcpyHostToDevice);
+    const char* w = d; const char* x = d + wbytes;
+    run<0>("MFMA only (operands in registers)", w, x, o, ktiles);
+    run<F_AGPR>("MFMA only, accumulators in AGPRs", w, x, o, ktiles);
+    run<F_BAR>("+ barrier per K-tile", w, x, o, ktiles);
+    run<F_LDS | F_BAR>("+ 24 ds_read_b128 + barrier", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_RING5>("   same, A ring of five (four fragments ahead)", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_PRIO>("   same, s_setprio 1 around the MFMAs", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_AGPR>("   same, AGPR accumulators", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_MIDBAR>("   same, barrier two steps before the K-tile's end", w, x, o, ktiles);
+    run<F_DMA | F_BAR>("+ 6 LDS-DMA pieces + barrier (no ds_read)", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA>("+ ds_read + barrier + 6 LDS-DMA pieces in slots", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_DMA_NOWAIT>("   same, DMA never waited for", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_DMA_DWORD>("   same, 4-byte pieces (same instruction count)", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_DMA_BURST>("   same, pieces in a burst after the barrier", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_VALU>("+ ds_read + barrier + 7 Philox rounds", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU>("+ ds_read + barrier + DMA + 7 Philox rounds (= the loop)", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU | F_AGPR>("   the loop, AGPR accumulators", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU | F_PRIO>("   the loop, s_setprio", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU | F_MIDBAR>("   the loop, barrier two steps early", w, x, o, ktiles);
+    return 0;
+}
