@@ -520,9 +520,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const int ext_first = __builtin_amdgcn_readfirstlane(a.ext[(size_t)bx * XR_EXT_ROWS].x);
         const char* in_base = reinterpret_cast<const char*>(G.in) + ((size_t)ext_first * a.in_cstride + G.in_coff) * 2;
         const char* wbase = wsrc[0];
-        // M16: weights addressed as (uniform 64-bit base in SGPRs) + (the lane's 32-bit byte offset): the saddr form of global_load_lds,
-        // one address VGPR and no 64-bit vector add per piece (the asm barriers in DMA_W keep the compiler from folding the lane
-        // offset into a loop-invariant 64-bit vector pointer again)
+        // M16: the LDS-DMA pieces of the loop are buffer_load_dwordx4 ... lds, not global_load_lds_dwordx4: a buffer resource in SGPRs
+        // (weights: one for the tile + a scalar byte offset per piece; extended rows: the tile's first row), the lane's 32-bit byte
+        // offset in one VGPR.  Same bytes, same landing -- but the issue parks the wave for fewer cycles: tests/tools/loop_anatomy.hip,
+        // 3404 -> 3111 cycles per K-tile (profiles/round2_loop_anatomy.txt)
         const char* wuni;
         {
             const uint64_t wu = (uint64_t)(uintptr_t)(reinterpret_cast<const char*>(G.w) + ((size_t)bc0 * wrow + c_begin * BK) * 2);
@@ -530,6 +531,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wu)));
         }
         const uint32_t wlane = (uint32_t)((ldrow * wrow + ldchunk * 8) * 2);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wuni), 0, -1, 0x00020000);      // raw, unbounded
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_base), 0, -1, 0x00020000);
         const int wrs = RPI * wrow * 2;                                     // bytes between the rows of two weight pieces
         uint32_t xo[NXE];
         int xp[NXE];
@@ -683,10 +686,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     }
                     Ar[0] = ldA16(0, 0); Ar[1] = ldA16(1, 0);
                     __builtin_amdgcn_sched_barrier(0);
-#define DMA_W(I) if (wnext) { const char* wp_ = wuni + (woff + (I) * wrs); uint32_t wl_ = wlane; asm volatile("" : "+s"(wp_), "+v"(wl_)); \
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wp_ + wl_), LDS_PTR(smem + wdst + ((I) * THREADS + wave * 64) * 16), 16, 0, 0); }
+#define DMA_W(I) if (wnext) { int so_ = woff + (I) * wrs; asm volatile("" : "+s"(so_)); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + wdst + ((I) * THREADS + wave * 64) * 16), 16, (int)wlane, so_, 0, 0); }
 #define DMA_X(I) if ((I) < NXE && xnext && ABL != 2) { xo[(I) < NXE ? (I) : 0] += next_row ? (uint32_t)xp[(I) < NXE ? (I) : 0] : (uint32_t)(BK * 2 - 2 * xp[(I) < NXE ? (I) : 0]); \
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[(I) < NXE ? (I) : 0]), LDS_PTR(smem + xdst + (((I) < NXE ? (I) : 0) * THREADS + wave * 64) * 16), 16, 0, 0); }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(smem + xdst + (((I) < NXE ? (I) : 0) * THREADS + wave * 64) * 16), 16, (int)xo[(I) < NXE ? (I) : 0], 0, 0, 0); }
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll

@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-enum { F_BAR = 1, F_LDS = 2, F_DMA = 4, F_VALU = 8, F_DMA_DWORD = 16, F_DMA_BURST = 32, F_DMA_NOWAIT = 64, F_PRIO = 128, F_RING5 = 256, F_MIDBAR = 512, F_AGPR = 1024 };
+enum { F_BAR = 1, F_LDS = 2, F_DMA = 4, F_VALU = 8, F_DMA_DWORD = 16, F_DMA_BURST = 32, F_DMA_NOWAIT = 64, F_PRIO = 128, F_RING5 = 256, F_MIDBAR = 512, F_AGPR = 1024, F_DMA_ASYM = 2048, F_DMA_BUF = 4096 };
 constexpr int ROWB = 128, WST = 256 * ROWB, XROWS = 320, XBUF = XROWS * ROWB, LDS_BYTES = 2 * WST + 2 * XBUF;
 
 template <bool AGPR>
@@ -108,7 +108,26 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc
             if ((fc & 1) && st != 15) {
                 const int slot = st >> 1;
                 __builtin_amdgcn_sched_barrier(0);
-                if ((F & F_DMA) && !(F & F_DMA_BURST)) {
+                if ((F & F_DMA) && (F & F_DMA_ASYM)) {
+                    // all pieces issued by waves 0..3 (one per SIMD), two per slot: their SIMD partners (waves 4..7) never sit in a DMA issue
+                    if (wave < 4 && slot < 6) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int pc = slot * 2 + h;                      // 0..7 weight half-pieces, 8..11 activation half-pieces
+                            const char* p = pc < 8 ? wg + (size_t)pc * 32 * 2304 * 2 : xg + (size_t)(pc - 8) * 4096;
+                            uint32_t vl = pc < 8 ? (uint32_t)((((tid & 255) >> 3) * 2304 + (tid & 7) * 8) * 2) : (uint32_t)((tid & 255) * 16);
+                            asm volatile("" : "+s"(p), "+v"(vl));
+                            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + vl), LDS_PTR(smem + (pc < 8 ? wdst : xdst - 8 * 4096) + (pc * 256 + wave * 64) * 16), 16, 0, 0);
+                        }
+                    }
+                } else if ((F & F_DMA) && (F & F_DMA_BUF)) {
+                    if (slot < 6) {
+                        const char* p = slot < 4 ? wg + (size_t)slot * 64 * 2304 * 2 : xg + (size_t)(slot - 4) * 8192;
+                        asm volatile("" : "+s"(p));
+                        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (slot < 4 ? wdst + slot * 8192 : xdst + (slot - 4) * 8192) + wave * 1024), 16, slot < 4 ? wlane : xlane, 0, 0, 0);
+                    }
+                } else if ((F & F_DMA) && !(F & F_DMA_BURST)) {
                     if (slot < 4) {
                         const char* p = wg + (size_t)slot * 64 * 2304 * 2; uint32_t wl = wlane; asm volatile("" : "+s"(p), "+v"(wl));
                         if (F & F_DMA_DWORD) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p + wl), LDS_PTR(smem + wdst + (slot * 512 + wave * 64) * 16), 4, 0, 0);
@@ -187,10 +206,14 @@ int main() {
     run<F_LDS | F_BAR | F_DMA | F_DMA_NOWAIT>("   same, DMA never waited for", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_DMA_DWORD>("   same, 4-byte pieces (same instruction count)", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_DMA_BURST>("   same, pieces in a burst after the barrier", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_DMA_ASYM>("   same, all pieces issued by one wave per SIMD", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_DMA_BUF>("   same, buffer_load ... lds instead of global_load_lds", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_VALU>("+ ds_read + barrier + 7 Philox rounds", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU>("+ ds_read + barrier + DMA + 7 Philox rounds (= the loop)", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_AGPR>("   the loop, AGPR accumulators", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_PRIO>("   the loop, s_setprio", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_MIDBAR>("   the loop, barrier two steps early", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU | F_DMA_BUF>("   the loop, buffer_load ... lds", w, x, o, ktiles);
+    run<F_LDS | F_BAR | F_DMA | F_VALU | F_DMA_BUF | F_MIDBAR>("   the loop, buffer_load ... lds + barrier two steps early", w, x, o, ktiles);
     return 0;
 }
