@@ -2,7 +2,8 @@
 // 8 waves per CU -- rebuilt from its parts, which are switched on one at a time: the K-tile barrier, the 24 ds_read_b128 of the A/B
 // fragments, the 6 LDS-DMA pieces per wave (4 weight + 2 activation), and Philox-like integer VALU work in the MFMA shadows.
 // Prints per configuration: time per K-tile per CU, the shader clock (s_memtime cycles / s_memrealtime ticks) and the MFMA duty
-// (2048 matrix-pipe cycles per K-tile per SIMD / measured cycles).  No results are checked: this is a timing instrument.
+// (2048 matrix-pipe cycles per K-tile per SIMD / measured cycles), and a hash of the output (configurations that read the same
+// LDS contents in the same order must agree: the mid-tile-barrier form equals the top-barrier form without DMA).
 // usage (GPU box): hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tests/tools/loop_anatomy.hip -o /tmp/loop_anatomy && /tmp/loop_anatomy
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int RN = (F & F_RING5) ? 5 : 3;          // A ring: RN - 1 fragments ahead
+    constexpr int RN = (F & F_RING5) ? 5 : (F & F_MIDBAR) ? 4 : 3;      // A ring (across K-tiles: 16 % RN must be 0)
     bf16x8 Ar[RN], Bc[4];
     #pragma unroll
     for (int i = 0; i < RN; ++i) Ar[i] = reinterpret_cast<const bf16x8*>(smem)[i * 64 + lane];
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc
     uint32_t ph0 = tid * 2654435761u, ph1 = tid ^ 0x9E3779B9u, ph2 = 12345u, ph3 = tid + 77u;
     unsigned long long t0 = 0, r0 = 0;
     if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr int AHEAD = RN - 1, BS = (F & F_MIDBAR) ? 16 - AHEAD : 0;      // the barrier sits in front of step BS of the K-tile's 16
+    constexpr int AHEAD = (F & F_RING5) ? 4 : 2, BS = (F & F_MIDBAR) ? 16 - AHEAD : 0;      // the barrier sits in front of step BS of the K-tile's 16
     auto a_addr = [&](int kt_, int st) {          // A fragment of step st (= ks * 8 + fc) of K-tile kt_
         const int wa = (kt_ & 1) * WST + (wc * 128 + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4);
         return smem + ((wa ^ ((st >> 3) << 6)) + (st & 7) * 16 * ROWB);
@@ -59,6 +60,12 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc
         const int r = wp * 64 + j * 16 + l15 + kxc;
         return smem + ((2 * WST + xb * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4)) ^ (ks << 6));
     };
+    if ((F & F_MIDBAR) && (F & F_LDS)) {          // the fragments K-tile 0 starts with (later K-tiles: fetched behind the previous one's barrier)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(0, j, 0));
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) Ar[i] = *reinterpret_cast<const bf16x8*>(a_addr(0, i));
+    }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int stage = kt & 1, kxc = kt % 3, xb = (kt / 3) & 1;
         const char* wg = wsrc + (size_t)((kt % 36) * 64) * 2;                        // K-tile kt of the 256 x 2304 weight matrix (L2-resident)
@@ -179,6 +186,7 @@ static void run(const char* name, const char* w, const char* x, float* o, int kt
     }
     const double cyc = (double)cb[0] / 256 / ktiles, ghz = (double)cb[0] / (double)cb[1] * 0.1;
     const double tf = 256.0 * 8 * ktiles * 64 * 16384 / (best * 1e-3) / 1e12;
+    { std::vector<float> ho(256 * 512); hipMemcpy(ho.data(), o, ho.size() * 4, hipMemcpyDeviceToHost); unsigned long long hsh = 1469598103934665603ull; for (float v : ho) { unsigned u; memcpy(&u, &v, 4); hsh = (hsh ^ u) * 1099511628211ull; } printf("[%016llx] ", hsh); }
     printf("%-58s %7.3f us/K-tile  %6.0f cycles/K-tile  clock %.3f GHz  MFMA duty %.3f  %6.0f TFLOP/s\n", name, best * 1e3 / ktiles, cyc, ghz, 2048.0 / cyc, tf);
     hipEventDestroy(e0); hipEventDestroy(e1);
 }
