@@ -21,6 +21,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 
 namespace {
 
@@ -533,44 +534,11 @@ bod_status build_plan(bod_context* h) {
     }
     const int out_ch[3] = {c.anchors_per_location * c.num_classes, c.anchors_per_location * 4, c.anchors_per_location * 10};
     // row tables: layer 1 (pyramid -> N dropout variants), layers 2.. (per sample), output 1x1
-    std::vector<RowEnt> t1((size_t)B * h->P), t2((size_t)B * N * h->P), t3((size_t)B * N * h->P);
+    std::vector<RowEnt> t1, t2, t3;
     {
-        size_t r1 = 0, r2 = 0;
-        for (int b = 0; b < B; ++b) {
-            for (int l = 0; l < 5; ++l)
-                for (int y = 0; y < h->lh[l]; ++y)
-                    for (int xq = 0; xq < h->lw[l]; ++xq) {
-                        const int pitch = h->lw[l] + 2;
-                        RowEnt e{};
-                        e.in_off = (int32_t)((int64_t)b * h->Ppad + h->lvl_off[l] + (int64_t)y * pitch + xq);
-                        e.in_pitch = pitch;
-                        e.out_off = (int32_t)((int64_t)b * N * h->Ppad + h->lvl_off[l] + (int64_t)(y + 1) * pitch + (xq + 1));
-                        e.rng_p = (int32_t)(h->lvl_p0[l] + y * h->lw[l] + xq);
-                        e.rng_zs = (b << 16);
-                        t1[r1++] = e;
-                    }
-            for (int n = 0; n < N; ++n)
-                for (int l = 0; l < 5; ++l)
-                    for (int y = 0; y < h->lh[l]; ++y)
-                        for (int xq = 0; xq < h->lw[l]; ++xq) {
-                            const int pitch = h->lw[l] + 2;
-                            const int64_t plane0 = ((int64_t)b * N + n) * h->Ppad + h->lvl_off[l];
-                            const int32_t dense = (int32_t)(h->lvl_p0[l] + y * h->lw[l] + xq);
-                            RowEnt e{};
-                            e.in_off = (int32_t)(plane0 + (int64_t)y * pitch + xq);
-                            e.in_pitch = pitch;
-                            e.out_off = (int32_t)(plane0 + (int64_t)(y + 1) * pitch + (xq + 1));
-                            e.rng_p = dense;
-                            e.rng_zs = n | (b << 16);
-                            e.pad0 = (int32_t)(((int64_t)b * N + n) * h->P + dense);      // row of the fused 1x1 output
-                            t2[r2] = e;
-                            RowEnt f = e;
-                            f.in_off = e.out_off;                 // 1x1 reads the centre pixel
-                            f.out_off = (int32_t)(((int64_t)b * N + n) * h->P + dense);
-                            t3[r2] = f;
-                            ++r2;
-                        }
-        }
+        PyramidGeometry pg = pyramid_geometry(h->lh, h->lw);      // (plan_tables.h; bod_create laid the planes out with the same function's formulas)
+        if (pg.Ppad != h->Ppad || pg.P != h->P) return h->fail(BOD_ERR_INVALID_ARG, "pyramid geometry mismatch");
+        head_row_tables(pg, B, N, t1, t2, t3);
     }
     RowEnt *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
     BODCHK(h->dalloc(&d1, t1.size(), false));
@@ -592,32 +560,11 @@ bod_status build_plan(bod_context* h) {
         xreuse = xreuse && conv_igemm_uses_full_cout_tile(probe);
     }
     // rows -> 256-slot tiles of x-adjacent runs + each tile's extended input rows (kernels.h, ConvArgs::ext)
+    static_assert(sizeof(ExtRow) == sizeof(int2), "ExtRow is the host-side twin of int2");
     auto make_xr_tiles = [&](const std::vector<RowEnt>& src, RowEnt** d_rows, int2** d_ext, int* m_out) -> bod_status {
         std::vector<RowEnt> tiled;
-        std::vector<int2> ext;
-        RowEnt invalid = src[0];
-        invalid.out_off = -1; invalid.pad0 = 0; invalid.pad1 = 0;
-        size_t r = 0;
-        while (r < src.size()) {
-            const size_t tile0 = tiled.size();
-            const size_t ext0 = ext.size();
-            int pix = 0, nx = 0;
-            while (r < src.size() && pix < 256 && nx + 3 <= XR_EXT_ROWS) {
-                // maximal run of x-adjacent pixels starting at row r
-                size_t e = r + 1;
-                while (e < src.size() && src[e].in_off == src[e - 1].in_off + 1 && src[e].in_pitch == src[r].in_pitch) ++e;
-                int take = (int)std::min<size_t>(e - r, (size_t)std::min(256 - pix, XR_EXT_ROWS - nx - 2));
-                for (int k = 0; k < take + 2; ++k) ext.push_back(int2{src[r].in_off + k, src[r].in_pitch});
-                for (int k = 0; k < take; ++k) { RowEnt q = src[r + k]; q.pad1 = nx + k; tiled.push_back(q); }
-                nx += take + 2; pix += take; r += take;
-            }
-            while (tiled.size() < tile0 + 256) tiled.push_back(invalid);
-            // pad with the tile's first row: never read by a valid pixel, and it keeps the first entry the smallest of
-            // the tile (the kernel takes its 32-bit activation offsets against it)
-            while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(ext[ext0]);
-            for (size_t q = ext0; q < ext0 + XR_EXT_ROWS; ++q)
-                if (ext[q].x < ext[ext0].x) return h->fail(BOD_ERR_INVALID_ARG, "row-reuse tiling: extended rows out of order");
-        }
+        std::vector<ExtRow> ext;
+        if (!xr_tile_rows(src, tiled, ext)) return h->fail(BOD_ERR_INVALID_ARG, "row-reuse tiling: extended rows out of order");
         *m_out = (int)tiled.size();
         BODCHK(h->dalloc(d_rows, tiled.size(), false));
         BODCHK(h->dalloc(d_ext, ext.size(), false));
@@ -663,41 +610,11 @@ bod_status build_plan(bod_context* h) {
     if (const char* e = getenv("BOD_FUSE_AGGREGATION")) agg = agg && atoi(e) != 0;
     RowEnt* d2a = nullptr; int2* dexta = nullptr; int m2a = 0;
     if (agg) {
-        const int Qmax = 256 / N;
         std::vector<RowEnt> tiled;
-        std::vector<int2> ext;
-        RowEnt invalid = t2[0];
-        invalid.out_off = -1; invalid.pad0 = 0; invalid.pad1 = 0;
-        for (int b = 0; b < B; ++b) {
-            const size_t img0 = (size_t)b * N * h->P;               // t2 index of (b, sample 0, pixel 0); sample n: + n * P
-            int p = 0;
-            while (p < h->P) {
-                const size_t tile0 = tiled.size(), ext0 = ext.size();
-                tiled.resize(tile0 + 256, invalid);
-                int Q = 0, X = 0;
-                while (p < h->P && Q < Qmax) {
-                    int L = 1;                                      // maximal run of x-adjacent pixels starting at p
-                    while (p + L < h->P && t2[img0 + p + L].in_off == t2[img0 + p + L - 1].in_off + 1 &&
-                           t2[img0 + p + L].in_pitch == t2[img0 + p].in_pitch) ++L;
-                    const int take = std::min(std::min(L, Qmax - Q), (XR_EXT_ROWS - X) / N - 2);
-                    if (take < 1) break;
-                    for (int n = 0; n < N; ++n) {
-                        const RowEnt& first = t2[img0 + (size_t)n * h->P + p];
-                        for (int k = 0; k < take + 2; ++k) ext.push_back(int2{first.in_off + k, first.in_pitch});
-                        for (int k = 0; k < take; ++k) {
-                            RowEnt q = t2[img0 + (size_t)n * h->P + p + k];
-                            q.pad1 = X + n * (take + 2) + k;
-                            tiled[tile0 + (size_t)(Q + k) * N + n] = q;
-                        }
-                    }
-                    X += N * (take + 2); Q += take; p += take;
-                }
-                if (Q == 0) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: no pixel fits a tile (N = %d)", N);
-                while (ext.size() < ext0 + XR_EXT_ROWS) ext.push_back(ext[ext0]);
-                for (size_t q = ext0; q < ext0 + XR_EXT_ROWS; ++q)
-                    if (ext[q].x < ext[ext0].x) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: extended rows out of order");
-            }
-        }
+        std::vector<ExtRow> ext;
+        const int rc = xr_tile_rows_aggregated(t2, B, N, h->P, tiled, ext);
+        if (rc == 1) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: no pixel fits a tile (N = %d)", N);
+        if (rc == 2) return h->fail(BOD_ERR_INVALID_ARG, "aggregated tiling: extended rows out of order");
         m2a = (int)tiled.size();
         BODCHK(h->dalloc(&d2a, tiled.size(), false));
         BODCHK(h->dalloc(&dexta, ext.size(), false));
@@ -841,6 +758,43 @@ PostCfg post_cfg(bod_context* h, uint64_t seed, uint32_t first_image) {
 // flavour: FLAVOUR_RAW = per-sample head outputs into raw[] (RetinaNetModel.call's tensors), FLAVOUR_AGG = MC statistics
 // reduced inside the last tower layers' tiles (plans with agg_plan only).  only_flavoured: run just the ops that differ
 // between the two (materialise_raw re-runs the raw flavour of the last layers on the activations still in HBM).
+// ---- rocprofv3 markers (tracing): with BOD_ROCTX=1 every stage of a step is bracketed by a roctx range --
+// bod:stem, bod:res2 .. bod:res5, bod:fpn, bod:head_tower_layer_k, bod:posterior, bod:nms, bod:cluster_fuse, bod:collect,
+// bod:upload -- so that `rocprofv3 --marker-trace --kernel-trace` lays the kernels of a step out by stage.  The roctx library is
+// opened at run time (no link dependency; without the variable not a single call is made).  The ranges bracket the ENQUEUE of a
+// stage on the host; the stage timers of the C ABI (bod_profile_begin / bod_profile_end) are the device-side figures.
+struct Markers {
+    bool on = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Markers() {
+        const char* e = getenv("BOD_ROCTX");
+        if (!e || !atoi(e)) return;
+        void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { fprintf(stderr, "bayesod: BOD_ROCTX=1 but no roctx library could be opened (%s)\n", dlerror()); return; }
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        on = push && pop;
+    }
+};
+static Markers& markers() { static Markers m; return m; }
+struct MarkerRange {                    // scope = one range
+    bool on;
+    explicit MarkerRange(const char* name) : on(markers().on) { if (on) markers().push(name); }
+    ~MarkerRange() { if (on) markers().pop(); }
+    MarkerRange(const MarkerRange&) = delete;
+    MarkerRange& operator=(const MarkerRange&) = delete;
+};
+// stage of a forward op, from its name: conv1 / pool1 -> stem, resK* -> resK, C?_reduced / P? -> fpn, head_tower_layer_k(...) -> itself
+static std::string op_stage(const std::string& name) {
+    if (name.rfind("conv1", 0) == 0 || name.rfind("pool1", 0) == 0) return "bod:stem";
+    if (name.rfind("res", 0) == 0 && name.size() > 3) return "bod:" + name.substr(0, 4);
+    if (name.rfind("head_tower_layer_", 0) == 0) return "bod:" + name.substr(0, name.find('(') == std::string::npos ? name.size() : name.find('('));
+    if (name.rfind("pyramid_", 0) == 0) return "bod:head_outputs";      // separate 1x1 output convs (plans without the fused epilogue)
+    return "bod:fpn";
+}
+
 bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image, int flavour = FLAVOUR_RAW,
                        bool only_flavoured = false) {
     const bod_config& c = h->cfg;
@@ -857,10 +811,20 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         HIPCHK(h, hipEventRecord(tev[0], h->stream));
     }
     size_t op_i = 0;
+    std::string cur_stage;                                        // open marker range (BOD_ROCTX=1)
+    struct StageCloser { std::string& s; ~StageCloser() { if (!s.empty()) markers().pop(); } } stage_closer{cur_stage};
     for (Op& op : h->ops) {
         if (trace && op_i > 0) HIPCHK(h, hipEventRecord(tev[op_i], h->stream));
         ++op_i;
         if ((op.flavour != FLAVOUR_BOTH && op.flavour != flavour) || (only_flavoured && op.flavour == FLAVOUR_BOTH)) continue;
+        if (markers().on) {
+            std::string st = op_stage(op.name);
+            if (st != cur_stage) {
+                if (!cur_stage.empty()) markers().pop();
+                markers().push(st.c_str());
+                cur_stage.swap(st);
+            }
+        }
         switch (op.kind) {
             case Op::STEM:
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
@@ -935,6 +899,7 @@ bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
     if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
     for (int sidx = 0; sidx < 2; ++sidx)
         if (h->side_pending[sidx]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_done[sidx], 0));
+    MarkerRange mr("bod:posterior");
     PostCfg pc = post_cfg(h, seed, first_image);
     PostBuffers pb = h->pb;
     pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
@@ -954,6 +919,7 @@ bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
 }
 
 bod_status run_nms(bod_context* h, hipStream_t st) {
+    MarkerRange mr("bod:nms");
     const bod_config& c = h->cfg;
     NmsArgs a{};
     a.B = c.batch; a.A = h->A; a.num_kept = h->pb.num_kept; a.corners = h->pb.corners; a.ranking = h->pb.ranking;
@@ -965,6 +931,7 @@ bod_status run_nms(bod_context* h, hipStream_t st) {
 }
 
 bod_status run_cluster(bod_context* h, hipStream_t st) {
+    MarkerRange mr("bod:cluster_fuse");
     const bod_config& c = h->cfg;
     ClusterArgs a{};
     a.B = c.batch; a.A = h->A; a.C = c.num_classes; a.max_out = c.nms_max_output_size;
@@ -1206,6 +1173,7 @@ static bod_status preproc_geometry(bod_handle h, int32_t src_h, int32_t src_w, c
 
 bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
                                 int32_t aspect_resize) {
+    MarkerRange mr_api("bod:upload");
     if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
     const bod_config& c = h->cfg;
     HIPCHK(h, hipSetDevice(c.device));
@@ -1227,6 +1195,7 @@ bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h,
 
 bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t src_h, int32_t src_w, const float* rgb_means,
                                       int32_t aspect_resize, int32_t buffer) {
+    MarkerRange mr_api("bod:upload");
     if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
     if (buffer < 0 || buffer > 1) return h->fail(BOD_ERR_INVALID_ARG, "bod_upload_frames_u8_async: buffer must be 0 or 1");
     const bod_config& c = h->cfg;
@@ -1553,6 +1522,7 @@ bod_status bod_device_detections(bod_handle h, int32_t sidx, void** p) {
 }
 
 bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
+    MarkerRange mr_api("bod:infer");
     if (!h) return BOD_ERR_INVALID_ARG;
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     if (h->cfg.mc_samples < 2) return h->fail(BOD_ERR_INVALID_ARG, "bayes_od needs mc_samples >= 2 (sample covariance divides by N-1)");
@@ -1567,6 +1537,7 @@ bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint6
 }
 
 bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id, int32_t* slot_out) {
+    MarkerRange mr_api("bod:infer_async");
     if (!h || !slot_out) return BOD_ERR_INVALID_ARG;
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     if (h->cfg.mc_samples < 2) return h->fail(BOD_ERR_INVALID_ARG, "bayes_od needs mc_samples >= 2 (sample covariance divides by N-1)");
@@ -1603,6 +1574,7 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
 }
 
 bod_status bod_collect(bod_handle h, int32_t sidx, int32_t* num, float* scores, float* means, float* covs, float* counts) {
+    MarkerRange mr_api("bod:collect");
     if (!h) return BOD_ERR_INVALID_ARG;
     if (sidx < 0 || sidx > 1 || !h->side_pending[sidx]) return h->fail(BOD_ERR_NOT_READY, "slot %d has no pending batch", sidx);
     const size_t B = (size_t)h->cfg.batch, BK = B * h->cfg.nms_max_output_size, C = h->cfg.num_classes;

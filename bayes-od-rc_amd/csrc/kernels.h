@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "plan_tables.h"
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip)
@@ -11,16 +12,7 @@
 // (pixels) are described by a row table, which lets one launch cover all pyramid levels, MC
 // samples and images at once.
 // ------------------------------------------------------------------------------------------------
-struct RowEnt {            // 32 B per output pixel
-    int32_t in_off;        // pixel index (in the group's input buffer) of the window origin
-    int32_t in_pitch;      // padded row width of that plane, in pixels
-    int32_t out_off;       // pixel index in the output buffer
-    int32_t res_off;       // pixel index in the residual buffer (unused if no residual)
-    int32_t rng_p;         // pixel index in the image's concatenated p3..p7 pyramid (dropout counter x)
-    int32_t rng_zs;        // sample | image_in_batch << 16
-    int32_t pad0;          // dense output row of the fused 1x1 head conv ((b*N+n)*P + p)
-    int32_t pad1;          // extended-row index of this pixel inside its tile (activation row reuse)
-};
+// struct RowEnt (32 B per output pixel) and XR_EXT_ROWS: plan_tables.h (plain C++, shared with the host sanitizer build)
 
 struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (default) or fp32 (fp32 precision mode)
     const void* in;        // activations
@@ -98,7 +90,6 @@ struct ConvArgs {
     // channel), cout_pad / cout_valid stay in channels.
     int32_t split;
 };
-constexpr int XR_EXT_ROWS = 320;
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
 struct PerDeviceOnce {
