@@ -41,3 +41,55 @@ def test_production_conv_kernels_do_not_spill(tmp_path):
         assert hits, "kernel %s not found in the compile remarks" % want
         for n, (spill, scratch) in hits:
             assert spill == 0 and scratch == 0, "%s spills %d VGPRs (%d B scratch/lane)" % (n, spill, scratch)
+
+
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(tmp_path):
+    """The row-reuse tower loop issues its MFMAs as inline asm with the accumulators tied in place.  The compiler neither knows
+    their result latency nor inserts the wait states a real MFMA would get, so any compiler-generated instruction that reads or
+    writes an accumulator register between the loop's first and last MFMA (a v_mov that merges two live ranges, say -- seen when
+    a branch was put around the last fragment's MFMAs) silently corrupts results.  The disassembly of the production kernels must
+    not contain one; the epilogue reads the accumulators behind explicit s_nops."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "bayes-od-rc_amd", "csrc", "conv_igemm.hip")
+    asm = str(tmp_path / "conv.s")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.dirname(src), "-S", "--cuda-device-only",
+                          src, "-o", asm], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = open(asm).read()
+    checked = 0
+    for want in PRODUCTION[:2]:                      # the two kernels on the 16x16x32 row-reuse loop
+        m = re.search(r"^(_Z17%sv8ConvArgs):" % want, text, re.M)
+        assert m, want
+        body = [l.strip() for l in text[m.end():text.find(".Lfunc_end", m.end())].split("\n")]
+        body = [l for l in body if l and not l.startswith(";")]
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma_f32_16x16x32_bf16")]
+        assert len(mf) >= 192, (want, len(mf))       # three unrolled K-tiles of 64
+        # one or more copies of the loop: clusters of MFMAs less than 400 instructions apart
+        clusters, start = [], 0
+        for k in range(1, len(mf) + 1):
+            if k == len(mf) or mf[k] - mf[k - 1] > 400:
+                clusters.append(mf[start:k]); start = k
+        for cl in clusters:
+            acc = set()
+            for i in cl:
+                acc |= _regs(re.match(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\])", body[i]).group(1))
+            assert len(acc) == 128, (want, len(acc))
+            for i in range(cl[0], cl[-1] + 1):
+                l = body[i]
+                if l.startswith("v_mfma_f32_16x16x32_bf16") or not re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
+                    continue
+                toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                assert not (touched & acc), "%s: `%s` touches an accumulator inside the MFMA loop" % (want, l)
+            checked += 1
+    assert checked >= 2
