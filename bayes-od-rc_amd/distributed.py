@@ -44,11 +44,12 @@ def unpack_records(rec, num_classes):
     return out
 
 
-def gather_records(rec, dst=0, group=None):
+def gather_records(rec, dst=0, group=None, always=False):
     """One collective per step: every rank contributes its [B,K,W] block; rank ``dst`` receives
-    [world, B, K, W] (others None).  Latency-bound (~14 KB per image), never a ring all-reduce."""
+    [world, B, K, W] (others None).  Latency-bound (~14 KB per image), never a ring all-reduce.
+    ``always``: issue the collective even in a one-rank group (exercises the backend on a one-GPU box)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (always and dist.is_initialized()):
         return rec[None]
     rank = dist.get_rank(group)
     if rank == dst:

@@ -44,6 +44,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # f32-in MFMA = fp32 vector rate (fp32 precis
 # at 512x512 with synthetic.make_weights() (python bench.py --calibrate)
 CALIBRATED_FG_BIAS = -3.2
 METRIC = "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency"
+USE_DIST = False                   # process group initialised (N > 1, or BOD_BENCH_FORCE_DIST=1 on one rank)
 # conv FLOPs (2 MACs) of backbone + FPN per 512x512 image, linear in the pixel count
 BACKBONE_FPN_GFLOP_512 = {50: 49.05, 101: 49.05 + 17 * 2.0 * 1024 * (1024 * 256 + 2304 * 256 + 256 * 1024) / 1e9}
 
@@ -308,8 +309,15 @@ def main():
     print("# bench rank %d/%d: local_rank %d of %d visible GPU(s), backend %s" % (rank, world, local_rank, ndev, backend),
           file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BOD_BENCH_FORCE_DIST=1: initialise the process group and run EVERY collective of the N>1 path (gather of the records on
+    # device tensors, barrier, max-reduce of the time, all-gather of the per-rank rates) even with one rank -- the only way to run
+    # the RCCL branch on a one-GPU box (tests/test_gpu_pipeline.py::test_bench_collectives_run_under_rccl_with_one_rank)
+    global USE_DIST
+    USE_DIST = world > 1 or os.environ.get("BOD_BENCH_FORCE_DIST") == "1"
+    if USE_DIST:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         # every collective is bounded: a dead peer turns into an exception on the survivors, not a hang
         timeout = datetime.timedelta(seconds=int(os.environ.get("BOD_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
         if backend == "nccl":
@@ -334,7 +342,7 @@ def main():
             print(json.dumps(out), flush=True)
         # never re-exec, never wait for the dead peer: leave without the collective teardown
         os._exit(1)
-    if world > 1:
+    if USE_DIST:
         dist.destroy_process_group()
 
 
@@ -361,7 +369,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
 
     # BOD_BENCH_FORCE_GATHER=1: run the N>1 record path (device-side pack, gather, host copy on rank 0) at world size 1 too,
     # to measure what it costs per step on one GPU
-    force_gather = os.environ.get("BOD_BENCH_FORCE_GATHER") == "1"
+    force_gather = os.environ.get("BOD_BENCH_FORCE_GATHER") == "1" or (USE_DIST and world == 1)
     views = [bdist.torch_views(eng, s) for s in (0, 1)] if (world > 1 or force_gather) else None
     host_out = [None, None]
     gathered = None
@@ -373,7 +381,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             eng.wait_slot(slot)
             v = views[slot]
             rec = bdist.pack_records(v["num"], v["scores"], v["means"], v["covs"], v["counts"])
-            allrec = bdist.gather_records(rec if backend == "nccl" else rec.cpu(), dst=0)
+            allrec = bdist.gather_records(rec if backend == "nccl" else rec.cpu(), dst=0, always=USE_DIST)
             if rank == 0:
                 gathered = allrec.cpu()
             # the pack kernels read the engine's slot buffers on torch's stream: they must have finished before the engine's
@@ -401,7 +409,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if USE_DIST:
             dist.barrier()
         eng.synchronize()
         torch.cuda.synchronize()
@@ -425,7 +433,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     fence()
     elapsed = time.perf_counter() - t0
     per_rank = [B * args.steps / t_local]
-    if world > 1:
+    if USE_DIST:
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -544,6 +552,8 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                      "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
                      "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
                      "per_rank_images_per_sec": [round(v, 1) for v in per_rank],
+                     # valid detections in the records rank 0 received from each rank in the last gathered step (N > 1 path)
+                     "gathered_detections_per_rank": ([int(g[:, :, 0].sum().item()) for g in gathered] if gathered is not None else None),
                      "visible_gpus": torch.cuda.device_count(),
                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),
                      "stages_ms_per_step": stages}

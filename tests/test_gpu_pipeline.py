@@ -488,6 +488,36 @@ def test_bench_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in rec
 
 
+def test_bench_collectives_run_under_rccl_with_one_rank():
+    """The N>1 path of bench.py under the REAL backend: torch.distributed's "nccl" (= RCCL on ROCm) process group, the gather
+    of the packed detection records on device tensors that alias the engine's buffers, the barrier, the max-reduce of the time and
+    the all-gather of the per-rank rates -- with one rank (BOD_BENCH_FORCE_DIST=1), which is all a one-GPU box can hold (RCCL
+    refuses two ranks on one device; the two-rank tests above use gloo).  The gathered records must be the engine's own."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BOD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BOD_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4",
+                          "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "backend nccl" in out.stderr, out.stderr[-1000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]
+    rec = json.loads(line[0])
+    assert "error" not in rec and rec["n_gpus"] == 1 and rec["value"] > 0, rec
+    assert rec["config"]["per_rank_images_per_sec"] and len(rec["config"]["per_rank_images_per_sec"]) == 1
+    got = rec["config"]["gathered_detections_per_rank"]
+    assert got and len(got) == 1 and 0 < got[0] <= 4 * 100, got      # rank 0 read the gathered records back: 4 frames, <= 100 each
+
+
 def test_bench_reports_a_dead_peer_instead_of_hanging():
     """Multi-GPU hardening: rank 1 dies after the warm-up (BOD_BENCH_FAULT_RANK); every collective is bounded
     (BOD_BENCH_COLLECTIVE_TIMEOUT_S), so rank 0 leaves its barrier with an error, still prints the ONE JSON line -- with an
