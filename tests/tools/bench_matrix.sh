@@ -1,6 +1,6 @@
 #!/bin/bash
 # The measurement table of DESIGN.md section 7 (run on the GPU box through gpurun).
-run() { echo "== $*"; python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+run() { echo "== $*"; python bench.py --no-cpu-baseline --no-secondary "$@" 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 r = d['roofline']
