@@ -227,6 +227,60 @@ def test_clustering_uses_the_callers_affinity_matrix(golden_dir):
         inference_utils.bayes_od_clustering(gi[t + "_counts"], gi[t + "_means"], gi[t + "_covs"], gi[t + "_centres"], gi[t + "_iou"][:5], 0.5)
 
 
+def _random_posteriors(rng, m, c=8):
+    means = np.zeros((m, 4), np.float32)
+    means[:, :2] = rng.uniform(10, 90, (m, 2))
+    means[:, 2:] = means[:, :2] + rng.uniform(8, 30, (m, 2))
+    a = rng.normal(size=(m, 4, 4)).astype(np.float32)
+    covs = (a @ a.transpose(0, 2, 1) + 2.0 * np.eye(4, dtype=np.float32)).astype(np.float32)
+    counts = (rng.integers(0, 6, (m, c)) + rng.uniform(0.1, 1.0, (m, c))).astype(np.float32)       # Dirichlet-style pseudo counts
+    return counts, means, covs
+
+
+def test_cluster_of_one_member_is_the_member(golden_dir):
+    """SURVEY section 4, property: fusing a cluster that holds only its centre returns the centre -- mean unchanged, covariance
+    times the calibration constant 70 (inference_utils.py:359-361), normalised counts as score, counts unchanged."""
+    rng = np.random.default_rng(3)
+    eng, _ = _engine(hw=(128, 128), batch=1, n=2, num_classes=8)
+    counts, means, covs = _random_posteriors(rng, 6)
+    means[:, :2] += np.arange(6, dtype=np.float32)[:, None] * 200.0          # far apart: every IoU is 0, each box is its own cluster
+    means[:, 2:] += np.arange(6, dtype=np.float32)[:, None] * 200.0
+    eng.set_posterior(0, counts, means, covs, np.zeros(6, np.float32))
+    eng._set_centres(0, np.arange(6, dtype=np.int32))
+    eng.cluster_fuse()
+    scores, fmeans, fcovs, fcounts = eng.get_detections(0)
+    assert scores.shape == (6, 8)
+    assert np.allclose(fmeans, means, rtol=1e-4, atol=1e-3)
+    assert np.allclose(fcovs, covs * 70.0, rtol=2e-3, atol=1e-3)
+    assert np.allclose(fcounts, counts, rtol=1e-6)
+    assert np.allclose(scores, counts / counts.sum(axis=1, keepdims=True), rtol=1e-5)
+
+
+def test_cluster_fuse_is_invariant_to_the_order_of_the_kept_anchors():
+    """SURVEY section 4, property: permuting the kept anchors (and re-pointing the centres) must not change a fused detection
+    beyond fp32 summation order -- the kernel sums a cluster's precisions over whatever order the members are stored in."""
+    rng = np.random.default_rng(11)
+    eng, _ = _engine(hw=(128, 128), batch=1, n=2, num_classes=8)
+    m = 40
+    counts, means, covs = _random_posteriors(rng, m)
+    means[: m // 2] = means[0] + rng.normal(0, 1.0, (m // 2, 4)).astype(np.float32)      # one big cluster around box 0
+    centres = np.array([0, m - 1, m // 2 + 3], np.int32)
+    outs = []
+    for trial in range(3):
+        perm = np.arange(m) if trial == 0 else rng.permutation(m)
+        inv = np.empty(m, np.int64); inv[perm] = np.arange(m)
+        eng.set_posterior(0, counts[perm], means[perm], covs[perm], np.zeros(m, np.float32))
+        eng._set_centres(0, inv[centres].astype(np.int32))
+        eng.cluster_fuse()
+        outs.append([x.copy() for x in eng.get_detections(0)])
+    for other in outs[1:]:
+        assert np.allclose(other[1], outs[0][1], rtol=1e-4, atol=1e-3)       # means
+        assert np.allclose(other[2], outs[0][2], rtol=2e-3, atol=1e-3)       # covariances
+        # the categorical fusion keeps the three members closest (KL) to the centre: a tie-free top-3 is order-independent
+        assert np.allclose(other[0], outs[0][0], rtol=1e-4, atol=1e-6)
+        assert np.allclose(other[3], outs[0][3], rtol=1e-5)
+
+
 def test_iou_matrix_matches_reference_formula(golden_dir):
     import os
     g = np.load(os.path.join(golden_dir, "clustering.npz"))
