@@ -490,6 +490,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     for (int i = 0; i < FC16; ++i)
 #pragma unroll
         for (int j = 0; j < FP16; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The loop's MFMAs are inline asm: the compiler does not give them the two wait states an MFMA needs behind a VALU write of one of
+    // its sources (tests/tools/mfma_war_probe.hip: 18 % wrong results without them).  Left alone it may sink the zeroing of an
+    // accumulator to just in front of its first MFMA; naming the accumulators as operands of an asm statement pins the zeroing here,
+    // far ahead of the loop.  (tests/test_kernel_resources.py checks the disassembly for this and for copies behind an MFMA.)
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < FC16; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(acc4[i][0]), "+v"(acc4[i][1]), "+v"(acc4[i][2]), "+v"(acc4[i][3]));
+#endif
+        }
+    }
     const int l15 = lane & 15, q4 = lane >> 4;
 
     const int frow = lane & 31;

@@ -79,6 +79,30 @@ def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(tmp_pa
         # only legal users.  (The register ROLES may differ between a peeled first K-tile and the steady-state loop, so the check
         # follows each MFMA's own destination instead of one global accumulator set.)
         WINDOW = 16
+        # ... and the other direction: a VALU instruction that writes a register the MFMA reads (SrcA, SrcB or the tied SrcC) needs two
+        # wait states before the MFMA (tests/tools/mfma_war_probe.hip: 18 % wrong results with 0 or 1 slot in between, none from 2 on);
+        # the compiler inserts them for a real MFMA and cannot for inline asm.  (An LDS load that RETURNS into a source register right
+        # behind the MFMA is safe: same probe.)
+        for i in mf:
+            srcs = set()
+            for tok in re.findall(r"v\[\d+:\d+\]", body[i]):
+                srcs |= _regs(tok)
+            slots, k = 0, i - 1
+            while k >= 0 and slots < 2:
+                l = body[k]
+                if l.endswith(":") or l.startswith("."):  # a label: the fall-through predecessor is checked (other paths end in a branch)
+                    k -= 1
+                    continue
+                mm = re.match(r"s_nop (\d+)", l)
+                if mm:
+                    slots += int(mm.group(1)) + 1
+                else:
+                    if l.startswith("v_") and not l.startswith("v_mfma") and not l.startswith("v_cmp"):
+                        toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                        if toks:
+                            assert not (_regs(toks[0]) & srcs), "%s: `%s` writes a source of `%s` %d slot(s) before it" % (want, l, body[i], slots)
+                    slots += 1
+                k -= 1
         for i in mf:
             dst = _regs(re.match(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\])", body[i]).group(1))
             slots, k = 0, i + 1
