@@ -66,9 +66,22 @@ def write_cdef():
     return CDEF
 
 
+def _load_guard():
+    """kernel_guard.py next to this file (build.py also runs as a plain script, outside the package)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bayesod_kernel_guard", os.path.join(HERE, "kernel_guard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    write_cdef()
+    try:
+        write_cdef()                     # developer convenience: an installed / read-only tree must still build the library
+    except OSError as e:
+        if verbose:
+            print("include/bayesod_cdef.h not refreshed (%s)" % e, flush=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
@@ -85,6 +98,12 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(LIB_PATH, objs):
+        # guards on the object about to be linked: no spills in the production kernels, no hazard around the inline-asm MFMAs of
+        # the tower loop (kernel_guard.py) -- a compiler bump that breaks either fails the build instead of shipping
+        kernel_guard = _load_guard()
+        regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
+        if verbose:
+            print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd), flush=True)

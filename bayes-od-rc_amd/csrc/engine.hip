@@ -795,6 +795,16 @@ static std::string op_stage(const std::string& name) {
     return "bod:fpn";
 }
 
+// Records ev_img_free for the image buffer the current call reads (bod_device_images_buffer(k)): everything enqueued on the main
+// stream so far has finished with the frames once the event fires; bod_upload_frames_u8_async makes the copy stream wait on it.
+bod_status mark_images_consumed(bod_context* h) {
+    if (h->cur_img_buf >= 0 && h->copy) {
+        HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], h->stream));
+        h->img_free_pending[h->cur_img_buf] = true;
+    }
+    return BOD_OK;
+}
+
 bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image, int flavour = FLAVOUR_RAW,
                        bool only_flavoured = false) {
     const bod_config& c = h->cfg;
@@ -829,10 +839,10 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
             case Op::STEM:
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, h->stream));
-                if (h->cur_img_buf >= 0 && h->copy && !h->train) {   // the frames are consumed: the copy stream may refill this buffer
-                    HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], h->stream));
-                    h->img_free_pending[h->cur_img_buf] = true;
-                }
+                // the frames are consumed: the copy stream may refill this buffer.  (Training handles read the frames again in the
+                // backward pass -- bf16 copy + stem weight gradient -- and record the event at the end of the step instead:
+                // mark_images_consumed, train_impl.inc)
+                if (!h->train) BODCHK(mark_images_consumed(h));
                 break;
             case Op::POOL:
                 HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->split ? 2 : (h->es == 4 ? 1 : 0), c.batch,
@@ -873,7 +883,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         }
         for (hipEvent_t& e : tev) hipEventDestroy(e);
     }
-    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; h->affinity_img = -1;
     h->last_seed = seed; h->last_first_image = first_image;
     if (flavour == FLAVOUR_AGG) { h->agg_valid = true; h->raw_valid = false; }
     else { h->raw_valid = true; if (!only_flavoured) h->agg_valid = false; }
@@ -889,9 +899,10 @@ bod_status materialise_raw(bod_context* h) {
     const bool prof = h->profiling;
     h->profiling = false;
     const bool fd = h->forward_done, pd = h->posterior_done, nd = h->nms_done, cd = h->cluster_done;
+    const int aff = h->affinity_img;
     const bod_status st = run_forward(h, h->cur_images, h->last_seed, h->last_first_image, FLAVOUR_RAW, true);
     h->profiling = prof;
-    h->forward_done = fd; h->posterior_done = pd; h->nms_done = nd; h->cluster_done = cd;
+    h->forward_done = fd; h->posterior_done = pd; h->nms_done = nd; h->cluster_done = cd; h->affinity_img = aff;
     return st;
 }
 
@@ -914,7 +925,7 @@ bod_status run_posterior(bod_context* h, uint64_t seed, uint32_t first_image) {
     if (h->cfg.ranking_method == BOD_RANK_JOINT_ENTROPY && h->cfg.gaussian_isotropic && h->cfg.dirichlet_non_informative)
         HIPCHK(h, launch_joint_entropy_rank(pc, pb, h->stream));
     if (h->profiling) { HIPCHK(h, hipEventRecord(e1, h->stream)); h->ev_post.emplace_back(e0, e1); }
-    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    h->posterior_done = true; h->nms_done = h->cluster_done = false; h->affinity_img = -1;
     return BOD_OK;
 }
 
@@ -926,7 +937,7 @@ bod_status run_nms(bod_context* h, hipStream_t st) {
     a.work_scores = h->nms_scores; a.work_begin = h->nms_begin; a.selected = h->nms_sel; a.num_selected = h->nms_nsel;
     a.max_out = c.nms_max_output_size; a.iou_thr = c.nms_iou_threshold; a.sigma = c.nms_soft_sigma; a.variant = c.nms_variant;
     HIPCHK(h, launch_nms(a, st));
-    h->nms_done = true; h->cluster_done = false;
+    h->nms_done = true; h->cluster_done = false; h->affinity_img = -1;      // new centres: a pending bod_set_affinity was sized for the old ones
     return BOD_OK;
 }
 
@@ -1285,7 +1296,7 @@ bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const f
     if (box) HIPCHK(h, hipMemcpyAsync(h->raw[1], box, n * 16, hipMemcpyHostToDevice, h->stream));
     if (cov && c.has_covar_head) HIPCHK(h, hipMemcpyAsync(h->raw[2], cov, n * 40, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false;
+    h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; h->affinity_img = -1;
     h->raw_valid = true; h->agg_valid = false;
     return BOD_OK;
 }
@@ -1336,7 +1347,7 @@ bod_status bod_validation_post(bod_handle h) {
     PostBuffers pb = h->pb;
     pb.cls = h->raw[0]; pb.box = h->raw[1]; pb.cov = h->raw[2]; pb.anchors = h->d_anchors;
     HIPCHK(h, launch_validation_post(pc, pb, h->stream));
-    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    h->posterior_done = true; h->nms_done = h->cluster_done = false; h->affinity_img = -1;
     return BOD_OK;
 }
 
@@ -1391,7 +1402,7 @@ bod_status bod_set_posterior(bod_handle h, int32_t img, int32_t m, const float* 
     }
     HIPCHK(h, hipMemcpyAsync(h->pb.num_kept + img, &m, 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->posterior_done = true; h->nms_done = h->cluster_done = false;
+    h->posterior_done = true; h->nms_done = h->cluster_done = false; h->affinity_img = -1;
     return BOD_OK;
 }
 
@@ -1426,7 +1437,7 @@ bod_status bod_set_nms(bod_handle h, int32_t img, const int32_t* indices, int32_
         HIPCHK(h, hipMemcpyAsync(h->nms_sel + (size_t)img * h->cfg.nms_max_output_size, indices, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->nms_nsel + img, &n, 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->nms_done = true; h->cluster_done = false;
+    h->nms_done = true; h->cluster_done = false; h->affinity_img = -1;      // new centres: a pending bod_set_affinity was sized for the old ones
     return BOD_OK;
 }
 
@@ -1510,7 +1521,7 @@ bod_status bod_device_raw(bod_handle h, void** p, int32_t mark_ready) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (mark_ready) BODCHK(ensure_raw(h)); else BODCHK(materialise_raw(h));
     p[0] = h->raw[0]; p[1] = h->raw[1]; p[2] = h->cfg.has_covar_head ? h->raw[2] : nullptr;
-    if (mark_ready) { h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; h->raw_valid = true; h->agg_valid = false; }
+    if (mark_ready) { h->forward_done = true; h->posterior_done = h->nms_done = h->cluster_done = false; h->affinity_img = -1; h->raw_valid = true; h->agg_valid = false; }
     return BOD_OK;
 }
 

@@ -1,0 +1,166 @@
+"""Build-time guards on the compiled gfx950 code object of csrc/conv_igemm.hip.
+
+Two properties no functional test sees are checked on the DISASSEMBLY / metadata of the object that is about to be linked
+into libbayesod_hip.so (``build.build()`` calls ``verify()`` and refuses to link when it fails; tests/test_kernel_resources.py
+calls the same functions):
+
+* the production instantiations of ``conv_igemm_kernel`` do not spill (a spill in the 256x256 tile costs ~15 % of the
+  pipeline);
+* the row-reuse tower loop issues ``v_mfma_f32_16x16x32_bf16`` as inline asm with the accumulators tied in place.  The
+  compiler neither knows the result latency of an inline-asm MFMA nor inserts the wait states a real one gets, so
+  (a) no other instruction may touch an MFMA's destination in the 16 issue slots behind it and (b) no VALU instruction may
+  write one of its sources in the two slots in front of it (tests/tools/mfma_war_probe.hip: 18 % wrong results otherwise).
+  A compiler bump that re-orders the loop must fail the BUILD, not ship an unchecked kernel.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb0EE",     # head towers (row reuse)
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi5ELb1ELb0EE",     # first tower layer, N-way fan-out, on the row-reuse loop
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb0EE",     # backbone / FPN, big tile
+    "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb0EE",     # fan-out layer, small layers, split-K
+    "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb0EE",
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb1EE",     # bf16x3 precision: the three tile configurations
+    "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb1EE",
+    "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",
+]
+INLINE_ASM_MFMA = PRODUCTION[:2]                               # the kernels on the 16x16x32 inline-asm loop
+
+
+class GuardError(RuntimeError):
+    pass
+
+
+def _tool(name):
+    p = os.path.join(LLVM_BIN, name)
+    if not os.path.exists(p):
+        raise GuardError("%s not found (ROCm llvm tools are needed for the kernel guards)" % p)
+    return p
+
+
+def extract_device_object(host_obj, workdir):
+    """gfx950 code object out of a hipcc host object (.hip_fatbin section -> offload bundle -> hipv4 entry)."""
+    fat = os.path.join(workdir, "fat.bin")
+    co = os.path.join(workdir, "dev.co")
+    subprocess.check_call([_tool("llvm-objcopy"), "--dump-section=.hip_fatbin=" + fat, host_obj, os.path.join(workdir, "stripped.o")])
+    subprocess.check_call([_tool("clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    return co
+
+
+def kernel_metadata(code_object):
+    """{kernel name: {field: int}} from the code object's AMDGPU metadata note."""
+    text = subprocess.run([_tool("llvm-readelf"), "--notes", code_object], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for block in re.split(r"\n  - ", text)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name or ".symbol:" not in block:
+            continue
+        fields = {}
+        for key in ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+                    "group_segment_fixed_size"):
+            m = re.search(r"\.%s:\s+(\d+)" % key, block)
+            if m:
+                fields[key] = int(m.group(1))
+        out[name.group(1)] = fields
+    return out
+
+
+def check_no_spills(meta, wanted=PRODUCTION):
+    for want in wanted:
+        hits = [(n, f) for n, f in meta.items() if want in n]
+        if not hits:
+            raise GuardError("kernel %s not found in the code object" % want)
+        for n, f in hits:
+            if f.get("vgpr_spill_count", 0) or f.get("private_segment_fixed_size", 0):
+                raise GuardError("%s spills %d VGPRs (%d B scratch/lane)" % (n, f.get("vgpr_spill_count", 0), f.get("private_segment_fixed_size", 0)))
+
+
+def disassemble(code_object):
+    """{symbol: [instruction lines]} (comments and encodings stripped)."""
+    text = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", code_object], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for line in text.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if cur is None:
+            continue
+        ins = line.split("//")[0].strip()
+        if ins:
+            cur.append(ins)
+    return funcs
+
+
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+MFMA = "v_mfma_f32_16x16x32_bf16"
+
+
+def check_inline_asm_mfma(body, want, window=16, min_mfma=192):
+    """`body`: instruction list of one kernel.  Returns the number of MFMAs checked."""
+    mf = [i for i, l in enumerate(body) if l.startswith(MFMA)]
+    if len(mf) < min_mfma:                          # three unrolled K-tiles of 64
+        raise GuardError("%s: only %d %s found (the loop changed shape: re-derive the guard)" % (want, len(mf), MFMA))
+    for i in mf:
+        srcs = set()
+        for tok in re.findall(r"v\[\d+:\d+\]", body[i]):
+            srcs |= _regs(tok)
+        # (b) a VALU write of a source register needs two wait states before the MFMA
+        slots, k = 0, i - 1
+        while k >= 0 and slots < 2:
+            l = body[k]
+            mm = re.match(r"s_nop (\d+)", l)
+            if mm:
+                slots += int(mm.group(1)) + 1
+            else:
+                if l.startswith("v_") and not l.startswith("v_mfma") and not l.startswith("v_cmp"):
+                    toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                    if toks and (_regs(toks[0]) & srcs):
+                        raise GuardError("%s: `%s` writes a source of `%s` %d slot(s) before it" % (want, l, body[i], slots))
+                slots += 1
+            k -= 1
+        # (a) nothing but MFMAs on the same accumulator may touch the destination in the next `window` slots
+        dst = _regs(re.match(MFMA + r" (v\[\d+:\d+\])", body[i]).group(1))
+        slots, k = 0, i + 1
+        while k < len(body) and slots < window:
+            l = body[k]
+            mm = re.match(r"s_nop (\d+)", l)
+            slots += int(mm.group(1)) + 1 if mm else 1
+            if not l.startswith(MFMA) and re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
+                toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                if touched & dst:
+                    raise GuardError("%s: `%s` touches the destination of `%s` %d slots behind it" % (want, l, body[i], slots))
+            if l.startswith("s_cbranch") or l.startswith("s_branch") or l.startswith("s_endpgm"):
+                break                                # (fall-through only: the check is per straight-line run)
+            k += 1
+    return len(mf)
+
+
+def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
+    """All guards on a built conv_igemm.o.  Raises GuardError; returns {kernel: vgpr_count} of the production kernels."""
+    with tempfile.TemporaryDirectory() as wd:
+        co = extract_device_object(host_obj, wd)
+        meta = kernel_metadata(co)
+        check_no_spills(meta, wanted)
+        funcs = disassemble(co)
+        for want in asm_kernels:
+            names = [n for n in funcs if want in n]
+            if not names:
+                raise GuardError("kernel %s not found in the disassembly" % want)
+            for n in names:
+                check_inline_asm_mfma(funcs[n], want)
+        return {n: f.get("vgpr_count", -1) + f.get("agpr_count", 0) for n, f in meta.items() if any(w in n for w in wanted)}

@@ -170,17 +170,29 @@ def train(config, args):
     ckpt_dir = os.path.join(config_utils.data_dir(), 'outputs', config['checkpoint_name'], 'checkpoints')
     os.makedirs(ckpt_dir, exist_ok=True)
     # ckpt.restore(manager.latest_checkpoint) (run_training.py:75-82): resume weights, Adam moments and the step counter
-    latest, opt_state = latest_checkpoint(ckpt_dir), None
-    if latest is not None and not getattr(args, 'no_resume', False):
-        z = np.load(latest)
-        weights, opt_state = {}, {}
-        for k in z.files:
-            if k.startswith(OPT_PREFIX):
-                opt_state[k[len(OPT_PREFIX):]] = z[k]
-            else:
-                layer, field = k.rsplit('/', 1)
-                weights.setdefault(layer, {})[field] = z[k]
-        print('Restored from {}'.format(latest))
+    opt_state, restored = None, None
+    if getattr(args, 'no_resume', False):
+        # a fresh run: the previous run's checkpoints must not stay the "latest" of this one
+        for old in sorted_checkpoints(ckpt_dir):
+            os.remove(old)
+    else:
+        for cand in reversed(sorted_checkpoints(ckpt_dir)):           # newest first; a damaged file falls back to the one before
+            try:
+                with np.load(cand) as z:
+                    w, o = {}, {}
+                    for k in z.files:
+                        if k.startswith(OPT_PREFIX):
+                            o[k[len(OPT_PREFIX):]] = z[k]
+                        else:
+                            layer, field = k.rsplit('/', 1)
+                            w.setdefault(layer, {})[field] = z[k]
+            except Exception as e:                                    # truncated / corrupt archive (zipfile.BadZipFile, EOFError, ...)
+                print('Skipping unreadable checkpoint {}: {}'.format(cand, e))
+                continue
+            weights, opt_state, restored = w, o, cand
+            break
+    if restored is not None:
+        print('Restored from {}'.format(restored))
     else:
         print('Initializing from scratch.')
     trainer = Trainer(config, hw, weights, device=int(args.gpu_device), seed=args.seed)
@@ -208,22 +220,45 @@ def train(config, args):
 OPT_PREFIX = '__optimizer__/'
 
 
+def _checkpoint_step(name):
+    """'ckpt-<int>.npz' -> int, anything else (ckpt-foo.npz, a temp file of an interrupted save) -> None"""
+    if not (name.startswith('ckpt-') and name.endswith('.npz')):
+        return None
+    try:
+        return int(name[5:-4])
+    except ValueError:
+        return None
+
+
 def sorted_checkpoints(ckpt_dir):
-    files = [f for f in os.listdir(ckpt_dir) if f.startswith('ckpt-') and f.endswith('.npz')]
-    return [os.path.join(ckpt_dir, f) for f in sorted(files, key=lambda f: int(f[5:-4]))]
+    if not os.path.isdir(ckpt_dir):
+        return []
+    files = [f for f in os.listdir(ckpt_dir) if _checkpoint_step(f) is not None]
+    return [os.path.join(ckpt_dir, f) for f in sorted(files, key=_checkpoint_step)]
 
 
 def latest_checkpoint(ckpt_dir):
-    c = sorted_checkpoints(ckpt_dir) if os.path.isdir(ckpt_dir) else []
+    c = sorted_checkpoints(ckpt_dir)
     return c[-1] if c else None
 
 
 def save_checkpoint(trainer, path):
     """Weights in the schema RetinaNetModel.load_weights reads (keys '<layer>/<field>') + the optimizer state under
-    '__optimizer__/...' (ignored by load_weights' consumers: the inference handle only looks weights up by layer name)."""
+    '__optimizer__/...' (ignored by load_weights' consumers: the inference handle only looks weights up by layer name).
+    Written to a temp file in the same directory and renamed into place, so a kill during the save never leaves a
+    truncated 'latest' checkpoint."""
     flat = {"%s/%s" % (l, f): a for l, e in trainer.weights().items() for f, a in e.items() if a is not None}
     flat.update({OPT_PREFIX + k: v for k, v in trainer.optimizer_state().items()})
-    np.savez(path, **flat)
+    tmp = os.path.join(os.path.dirname(path), '.tmp-%d-%s' % (os.getpid(), os.path.basename(path)))
+    try:
+        with open(tmp, 'wb') as fp:
+            np.savez(fp, **flat)
+            fp.flush()
+            os.fsync(fp.fileno())
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def main(argv=None):
