@@ -496,14 +496,24 @@ hipError_t launch_validation_post(const PostCfg& c, const PostBuffers& b, hipStr
 // ------------------------------------------------------------------------------------------------
 // joint-entropy ranking (:169-200): min-max normalised information gains, one block per image
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float det4(const float* m) {
-    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
-    const float s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
-    const float s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
-    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
-    const float c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
-    const float c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
-    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+// log det of an SPD 4x4 (a posterior covariance) through its Cholesky factor, in double: the cofactor expansion in fp32 loses
+// cond(Sigma) x 2^-24 of the determinant to cancellation, which the min-max normalisation over the image's M boxes then
+// stretches to ~5e-3 of the ranking; log det = 2 sum log L_ii has no cancellation.  (M ~ 10^3 boxes per image: the cost is nil.)
+__device__ __forceinline__ double logdet4_spd(const float* m) {
+    double L[4][4];
+    double ld = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = (double)m[i * 4 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) { L[i][i] = sqrt(s); ld += log(s); }      // log L_ii^2
+            else L[i][j] = s / L[j][j];
+        }
+    }
+    return ld;
 }
 
 __global__ __launch_bounds__(POST_BLOCK) void joint_entropy_kernel(PostCfg c, PostBuffers pb) {
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(POST_BLOCK) void joint_entropy_kernel(PostCfg c, Po
     float gmin = INFINITY, gmax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
     for (int m = tid; m < M; m += POST_BLOCK) {
         const size_t o = (size_t)b * c.A + m;
-        const float g = prior_ent - (two_pi_term + 0.5f * logf(det4(pb.covs + o * 16)));
+        const float g = (float)((double)prior_ent - ((double)two_pi_term + 0.5 * logdet4_spd(pb.covs + o * 16)));
         float ce = 0.f;
         for (int j = 0; j < c.C; ++j) { const float p = pb.score[o * c.C + j]; ce -= p * logf(p); }
         const float cg = cat_prior - ce;
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(POST_BLOCK) void joint_entropy_kernel(PostCfg c, Po
     const float gden = fmaxf(1.0f, gmax - gmin), cden = fmaxf(0.001f, cmax - cmin);
     for (int m = tid; m < M; m += POST_BLOCK) {
         const size_t o = (size_t)b * c.A + m;
-        const float g = prior_ent - (two_pi_term + 0.5f * logf(det4(pb.covs + o * 16)));
+        const float g = (float)((double)prior_ent - ((double)two_pi_term + 0.5 * logdet4_spd(pb.covs + o * 16)));
         float ce = 0.f;
         for (int j = 0; j < c.C; ++j) { const float p = pb.score[o * c.C + j]; ce -= p * logf(p); }
         const float cg = cat_prior - ce;

@@ -77,14 +77,40 @@ def _rel_errs(got, ref):
     return float(np.max(np.abs(got - ref) / (np.abs(ref) + rms))), float(np.sqrt(((got - ref) ** 2).mean()) / rms)
 
 
-def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_raw=None, seed=0, first_image_id=0):
+def detection_parity(dev, ref):
+    """Final output of the path for one frame -- cluster-fused detections (scores [K,C], means [K,4] or [K,4,1], covs [K,4,4],
+    counts [K,C]) -- device vs the CPU leg, both from the same frame, Philox dropout masks and categorical uniforms.  Detection k
+    is soft-NMS centre k on both sides, so the lists are compared IN ORDER (a differing centre list shows up as a large
+    max_abs_dmu_px, never as a silently shorter comparison).  Relative errors carry the abs floors of tests/conftest.py
+    (means: |ref| + 1 px; covariance entries: |ref| + 1 % of the matrix's largest entry; scores: absolute)."""
+    if ref is None or dev is None:
+        return {"matched": 0, "device_detections": 0 if dev is None else int(len(dev[0])), "cpu_detections": 0 if ref is None else int(len(ref[0]))}
+    ds, dm, dc = np.asarray(dev[0], np.float64), np.asarray(dev[1], np.float64).reshape(-1, 4), np.asarray(dev[2], np.float64)
+    rs, rm, rc = np.asarray(ref[0], np.float64), np.asarray(ref[1], np.float64).reshape(-1, 4), np.asarray(ref[2], np.float64)
+    k = min(len(dm), len(rm))
+    out = {"matched": int(k), "device_detections": int(len(dm)), "cpu_detections": int(len(rm))}
+    if k == 0:
+        return out
+    dmu = np.abs(dm[:k] - rm[:k])
+    floor = np.abs(rc[:k]).reshape(k, -1).max(axis=1)[:, None, None] * 1e-2
+    out.update({"max_abs_dmu_px": float("%.3g" % dmu.max()),
+                "max_rel_dmu": float("%.3g" % (dmu / (np.abs(rm[:k]) + 1.0)).max()),
+                "max_rel_dSigma": float("%.3g" % (np.abs(dc[:k] - rc[:k]) / (np.abs(rc[:k]) + floor)).max()),
+                "max_dscore": float("%.3g" % np.abs(ds[:k] - rs[:k]).max()),
+                "counts_equal": bool(np.array_equal(np.asarray(dev[3], np.float64)[:k], np.asarray(ref[3], np.float64)[:k]))})
+    return out
+
+
+def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_raw=None, seed=0, first_image_id=0, device_dets=None):
     """Reference-literal CPU timing with the oracle (kind='port'): PyTorch-CPU fp32 forward
     (oracle/torch_ref.py) + NumPy posterior / soft-NMS / clustering, all host cores.
 
     ``device_raw``: {mode name: (cls, box, cov)} raw head outputs the GPU produced for frame 0 with (seed, first_image_id).
     The CPU forward of frame 0 then runs with the SAME Philox dropout masks, so the two are directly comparable: the
     returned ``parity`` maps each mode to its max relative error / relative RMS distance against this CPU forward
-    (north_star: "outputs match the CPU reference within 1e-3 rel on identical inputs, CPU baseline timed in the same run")."""
+    (north_star: "outputs match the CPU reference within 1e-3 rel on identical inputs, CPU baseline timed in the same run").
+    ``device_dets``: {mode name: (scores, means, covs, counts)} the device's final detections of frame 0 from the same call;
+    ``parity[mode]["detections"]`` compares them with this leg's own posterior -> soft-NMS -> cluster-and-fuse output."""
     import torch
     from oracle import bayes_od, clustering, geometry, network, nms, philox, torch_ref
     tw = torch_ref.prepare(weights)
@@ -123,6 +149,7 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
     done, t_total = 0, 0.0
     parts = {"forward": 0.0, "posterior": 0.0, "nms": 0.0, "cluster": 0.0}
     parity = {}
+    cpu_dets0 = None
     while done < len(frames) and (done == 0 or t_total < seconds_budget):
         t0 = time.perf_counter()
         out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw, keep_masks=masks0 if done == 0 else None)
@@ -133,10 +160,13 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
         corners = post["corners"].astype(np.float32)
         idx, _ = nms.soft_nms(corners, post["ranking"], 100, 0.5, 0.5)
         t3 = time.perf_counter()
+        dets = None
         if len(idx):
             iou = geometry.bbox_iou_vuvu(corners, corners)
-            clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, iou, 0.5)
+            dets = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, iou, 0.5)
         t4 = time.perf_counter()
+        if done == 0:
+            cpu_dets0 = dets
         parts["forward"] += t1 - t0; parts["posterior"] += t2 - t1
         parts["nms"] += t3 - t2; parts["cluster"] += t4 - t3
         t_total += t4 - t0
@@ -145,6 +175,8 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
                 errs = [_rel_errs(g, out[k]) for g, k in ((cls, "anchors_class_predictions"), (box, "anchors_box_predictions"),
                                                           (cov, "_covar_params"))]
                 parity[mode] = {"max_rel_err": max(e[0] for e in errs), "rel_rms": max(e[1] for e in errs)}
+            for mode, dev in (device_dets or {}).items():
+                parity.setdefault(mode, {})["detections"] = detection_parity(dev, cpu_dets0)
         done += 1
     base = {"value": done / t_total, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "%d frame(s) of %dx%d at N=%d, reference-literal (11*N head convs, no dedup), "
@@ -503,8 +535,8 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes) when they were taken on this exact configuration, else null
-    traffic = None
-    for pmc_file in ("round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
+    traffic, traffic_source = None, None
+    for pmc_file in ("round3_head_conv_pmc.json", "round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as fp:
                 pmc = json.load(fp)
@@ -514,12 +546,16 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                 is_tower = lambda l: "4, 0, true" in l["kernel"] or l["kernel"].rstrip().endswith("true>(ConvArgs)") and ", 5, true" not in l["kernel"]
                 sel = [l for l in pmc["launches"] if is_tower(l) == tower_only or not tower_only]
                 traffic = int(sum(l["hbm_read_bytes_corrected"] + l["hbm_write_bytes"] for l in sel) / len(sel))
+                traffic_source = "profiles/" + pmc_file
                 break
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
     roofline = {"bound": "mfma", "kernel": kernel_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
+                # `traffic` is not measured in this run: it is read from the committed rocprofv3 --pmc passes of the same
+                # configuration (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE, per launch)
+                "traffic_source": traffic_source,
                 "avg_launch_ms": round(prof["head_conv_ms"] / launches, 4), "launches_per_step": launches // prof_steps,
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
     if args.precision == "bf16x3":
@@ -555,12 +591,17 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                      # valid detections in the records rank 0 received from each rank in the last gathered step (N > 1 path)
                      "gathered_detections_per_rank": ([int(g[:, :, 0].sum().item()) for g in gathered] if gathered is not None else None),
                      "visible_gpus": torch.cuda.device_count(),
+                     # posterior launches only; the default run (extras) replaces both fields with the stage's full cost: posterior +
+                     # the A/B-measured share of the tower launches that is the fused MC aggregation (see below)
                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),
+                     "per_anchor_covariance_latency": {"posterior_only_ns": round(post_us_per_anchor * 1e3, 4),
+                                                       "note": "posterior launches only: the MC aggregation runs inside the tower "
+                                                               "epilogues and is not in this figure (A/B skipped in this invocation)"},
                      "stages_ms_per_step": stages}
     out["roofline"] = roofline
 
     extras = rank == 0 and world == 1 and not args.no_secondary and not fwd_only and args.precision == "bf16"
-    device_raw = {}
+    device_raw, device_dets = {}, {}
     if extras:
         # ---- value_with_h2d: the same steps with the frames crossing PCIe EVERY step as uint8 (a quarter of the fp32 bytes),
         # copy + device preprocessing on the handle's copy stream, overlapped with the previous step's convolutions
@@ -596,10 +637,49 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         del pinned, clips
         # raw head outputs of frame 0 with (seed 0, image id lo) for the parity figures of the CPU leg
         eng.upload_images(frames)
-        eng.forward(None, seed=0, first_image_id=lo)
-        device_raw["bf16"] = raw_of_image0(eng)
-    eng.close()
-    del eng
+        eng.infer(None, seed=0, first_image_id=lo)
+        device_dets["bf16"] = eng.get_detections(0)
+        device_raw["bf16"] = raw_of_image0(eng)          # (re-runs the raw flavour of the last tower launches: same Philox streams)
+        # ---- what the MC aggregation (a9-a10) costs where it now lives, inside the tower epilogues: the same steps on a handle
+        # planned WITHOUT it (raw [B,N,A,.] tensors + the posterior's own loops over the samples), same box, same frames
+        eng.close()
+        del eng
+        os.environ["BOD_FUSE_AGGREGATION"] = "0"
+        try:
+            enga = make_engine(hw, B, n, local_rank, precision=args.precision, weights=weights, anchors=anchors)
+        finally:
+            del os.environ["BOD_FUSE_AGGREGATION"]
+        enga.upload_images(frames)
+        timed_pipeline(enga, 1, 1, False, B, first_id=lo)
+        enga.profile_begin(which=1)
+        ab_steps = 3
+        timed_pipeline(enga, ab_steps, 0, False, B, first_id=lo)
+        pa = enga.profile_end()
+        enga.close()
+        del enga
+        towers_off = pa["head_conv_ms"] / ab_steps
+        post_off = pa["posterior_ms"] / max(1, pa["posterior_launches"])
+        towers_on = prof["head_conv_ms"] / prof_steps
+        post_on = prof["posterior_ms"] / max(1, prof["posterior_launches"])
+        anchors_per_step = B * out["config"]["anchors"]
+        in_tower = towers_on - towers_off                  # ms per step the fused aggregation adds to (or takes off) the tower launches
+        stage_ms = post_on + max(0.0, in_tower)
+        algo_bytes = (n * (4 + 10 + 8) * 4 + 16 + (4 + 16 + 8) * 4) * anchors_per_step     # 49.5 MB per 512x512 image at N=10
+        out["config"]["per_anchor_covariance_latency_ns"] = round(stage_ms * 1e6 / anchors_per_step, 4)
+        out["config"]["per_anchor_covariance_latency"] = {
+            "definition": "stage a9-a11 (per-anchor mean / 4x4 covariance over the MC samples, aleatoric mix, prior fusion) = posterior "
+                          "launches + what the fused MC aggregation adds to the tower launches (towers with it - towers of a plan "
+                          "without it, %d steps on a second handle, same box), / (frames x anchors)" % ab_steps,
+            "posterior_only_ns": round(post_on * 1e6 / anchors_per_step, 4),
+            "aggregation_in_tower_epilogues_ms_per_step": round(in_tower, 3),
+            "towers_ms_per_step": {"fused_aggregation": round(towers_on, 3), "raw_tensors": round(towers_off, 3)},
+            "unfused_stage_ns": round(post_off * 1e6 / anchors_per_step, 4),
+            "algorithmic_bytes_per_step": int(algo_bytes),
+            "implied_hbm_frac_of_8TBs": round(algo_bytes / (stage_ms * 1e-3) / 8e12, 3),
+            "unfused_hbm_frac_of_8TBs": round(algo_bytes / (post_off * 1e-3) / 8e12, 3)}
+    else:
+        eng.close()
+        del eng
 
     if extras:
         # ---- parity_mode: the bf16x3 precision mode ((hi, lo) bf16 pairs, three MFMA products per MAC) -- the mode in which the
@@ -607,7 +687,8 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         Bp = max(1, B // 2)
         engp = make_engine(hw, Bp, n, local_rank, precision="bf16x3", weights=weights, anchors=anchors)
         engp.upload_images(frames[:Bp])
-        engp.forward(None, seed=0, first_image_id=lo)
+        engp.infer(None, seed=0, first_image_id=lo)
+        device_dets["bf16x3"] = engp.get_detections(0)
         device_raw["bf16x3"] = raw_of_image0(engp)
         p_steps = 5
         dt = timed_pipeline(engp, p_steps, 2, False, Bp, first_id=lo)
@@ -621,7 +702,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         del engp
         out["secondary"] = secondary_configs(local_rank, weights, lo)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(hw, n, frames, weights, anchors, device_raw=device_raw, seed=0, first_image_id=lo)
+        base, parity = cpu_baseline(hw, n, frames, weights, anchors, device_raw=device_raw, seed=0, first_image_id=lo, device_dets=device_dets)
         out["cpu_baseline"] = base
         out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
         if "bf16x3" in parity and "parity_mode" in out:
@@ -630,8 +711,12 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             out["parity_mode"]["against"] = ("cpu_baseline's fp32 forward of frame 0 with the same Philox dropout masks: raw head outputs "
                                              "(class logits, box deltas, covariance parameters), max |d| / (|ref| + rms(ref))")
             out["parity_mode"]["speedup_vs_cpu_baseline"] = round(out["parity_mode"]["images_per_sec"] / base["value"], 1)
+            # the path's OUTPUT (boxes, class scores, 4x4 covariances of the cluster-fused detections of frame 0 at full size)
+            # against the CPU leg's own posterior -> soft-NMS -> cluster-and-fuse, same Philox streams
+            out["parity_mode"]["detections"] = parity["bf16x3"].get("detections")
         if "bf16" in parity:
-            out["config"]["headline_mode_distance_to_cpu_forward"] = {k: float("%.3g" % v) for k, v in parity["bf16"].items()}
+            out["config"]["headline_mode_distance_to_cpu_forward"] = {k: (float("%.3g" % v) if not isinstance(v, dict) else v)
+                                                                      for k, v in parity["bf16"].items()}
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -150,9 +150,15 @@ def test_async_pipeline_equals_synchronous():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_fp32_pipeline_matches_oracle_end_to_end(precision):
-    """fp32 / bf16x3 precision modes, whole pipeline against the float64 oracle run from the raw frame: same
-    kept anchors, same soft-NMS centres, detections within 1e-3 (images whose categorical draw or
-    centre ordering sits on a float rounding boundary are skipped, they are covered stage-wise)."""
+    """fp32 / bf16x3 precision modes, whole pipeline against the float64 oracle run from the raw frame.  EVERY image goes through
+    every stage comparison -- nothing is skipped:
+      * posterior vs the oracle's, anchors whose categorical draw sits on a CDF rounding boundary masked (compare_posterior
+        asserts that only such anchors may differ in the background filter);
+      * soft-NMS and cluster-and-fuse CHAINED on the device's own posterior: the oracle's soft-NMS of the device's candidates
+        must return the device's centre list bit for bit, the oracle's clustering of the device's posterior must give the
+        device's detections within 1e-3;
+      * and, where both sides kept the same anchors, the oracle run all the way from the frame: same centres (or a
+        divergence explained by a tie of the soft-NMS scores at the first differing position) and detections within 1e-3."""
     from bayes_od_rc_amd import synthetic
     from bayes_od_rc_amd.model import RetinaNetModel
     from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
@@ -169,7 +175,19 @@ def test_fp32_pipeline_matches_oracle_end_to_end(precision):
     frames = synthetic.make_frames(batch, hw[0], hw[1], seed=40)
     dets = pipe(frames, seed=seed, first_image_id=0)
     eng = pipe.engine
-    checked = 0
+
+    def check_detections(got4, ref4, margins):
+        ok = margins > 1e-6                # clusters whose top-3-min-KL selection is decided by a wide margin (others: stage tests)
+        assert ok.sum() >= max(1, len(ok) // 2)
+        scores, means, covs, counts = got4
+        s, mu, cv, cn = ref4
+        assert scores.shape[0] == s.shape[0]
+        assert rel_err(means[ok], mu[ok][:, :, 0], 1.0) < REL_TOL
+        floor = np.abs(cv).reshape(len(cv), -1).max(axis=1)[:, None, None] * 1e-2
+        assert (np.abs(covs - cv) / (np.abs(cv) + floor))[ok].max() < REL_TOL
+        assert rel_err(scores[ok], s[ok], 1e-6) < REL_TOL
+
+    pure = 0
     for b in range(batch):
         km = lambda s, lid: philox.dropout_keep_mask(seed, b, s, lid, eng.P, 256, 0.3)
         pred = network.retinanet_forward(w, frames[b][None], n, 8, mode="literal", dtype=np.float64, keep_masks=km)
@@ -182,27 +200,37 @@ def test_fp32_pipeline_matches_oracle_end_to_end(precision):
         # 1.2e-5 of the matrix norm; means and scores keep the 1e-3 bound in both modes
         _, same_set = compare_posterior(got, post, u, tol=REL_TOL, cov_tol=REL_TOL if precision == "fp32" else 3e-3, min_checked=50,
                                         boundary_eps=5e-5, max_ambiguous=5e-2)
-        cov_ref = post["covs"]
-        if same_set:
-            norm = np.abs(cov_ref).reshape(len(cov_ref), -1).max(axis=1)[:, None, None]
-            assert (np.abs(got["covs"] - cov_ref) / norm).max() < 1e-4
+        # ---- chained on the device's own posterior (every image)
+        dev_corners = geometry.vuhw_to_vuvu(got["means"]).astype(np.float32)
+        dev_idx = eng.get_nms(b)
+        idx_chain, sc_chain = nms.soft_nms(dev_corners, got["ranking"], 100, 0.5, 0.5)
+        assert np.array_equal(idx_chain, dev_idx)
+        assert len(dev_idx) > 0
+        iou_dev = geometry.bbox_iou_vuvu(dev_corners, dev_corners)           # float32, like the device's on-the-fly affinity
+        *ref4, margins = clustering.bayes_od_clustering(got["counts"].astype(np.float64), got["means"].astype(np.float64)[:, :, None],
+                                                        got["covs"].astype(np.float64), dev_idx, iou_dev, 0.5, return_margins=True)
+        check_detections(dets[b], ref4, margins)
+        # ---- the oracle all the way from the frame (needs identical candidate lists)
         if not same_set:
-            continue                       # the later stages need identical candidate lists
+            continue                       # (compare_posterior asserted that only boundary-ambiguous anchors differ)
+        cov_ref = post["covs"]
+        norm = np.abs(cov_ref).reshape(len(cov_ref), -1).max(axis=1)[:, None, None]
+        assert (np.abs(got["covs"] - cov_ref) / norm).max() < 1e-4
         corners = post["corners"].astype(np.float32)
-        idx, _ = nms.soft_nms(corners, post["ranking"].astype(np.float32), 100, 0.5, 0.5)
-        if not np.array_equal(idx, eng.get_nms(b)):
+        idx, sc_ref = nms.soft_nms(corners, post["ranking"].astype(np.float32), 100, 0.5, 0.5)
+        if not np.array_equal(idx, dev_idx):
+            # the only legitimate divergence: two candidates whose (decayed) soft-NMS scores tie to float32 round-off at the first
+            # position where the lists differ
+            k = min(len(idx), len(dev_idx))
+            p = int(np.nonzero(idx[:k] != dev_idx[:k])[0][0]) if np.any(idx[:k] != dev_idx[:k]) else k
+            assert p < k, "centre lists of different length with a common prefix"
+            assert abs(float(sc_ref[p]) - float(sc_chain[p])) <= 1e-5 * abs(float(sc_ref[p])), (p, sc_ref[p], sc_chain[p])
             continue
         iou = geometry.bbox_iou_vuvu(post["corners"], post["corners"])
-        s, mu, cv, cn, margins = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx,
-                                                                iou, 0.5, return_margins=True)
-        ok = margins > 1e-6
-        scores, means, covs, counts = dets[b]
-        assert rel_err(means[ok], mu[ok][:, :, 0], 1.0) < REL_TOL
-        floor = np.abs(cv).reshape(len(cv), -1).max(axis=1)[:, None, None] * 1e-2
-        assert (np.abs(covs - cv) / (np.abs(cv) + floor))[ok].max() < REL_TOL
-        assert rel_err(scores[ok], s[ok], 1e-6) < REL_TOL
-        checked += 1
-    assert checked >= 1
+        *ref4, margins = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, iou, 0.5, return_margins=True)
+        check_detections(dets[b], ref4, margins)
+        pure += 1
+    assert pure >= 1
 
 
 def test_run_inference_cli_writes_reference_layout(tmp_path, monkeypatch):

@@ -84,7 +84,11 @@ def test_posterior_matches_oracle(use_full_covar, ranking):
         if ranking == "score":
             assert rel_err(got["ranking"][gi], ref["ranking"][ri], 1e-6) < REL_TOL
         elif not np.any(diff):
-            assert rel_err(got["ranking"], ref["ranking"], 1e-2) < 5e-3
+            # joint entropy = min-max-normalised information gains over the image's M boxes (inference_utils.py:171-200): the
+            # Gaussian term is -0.5 log det(Sigma_post), taken through a double-precision Cholesky on the device, so the ranking
+            # inherits only the covariances' own error (1e-3 of an entry -> <= 4e-3 of log det in the worst, aligned case; observed
+            # far below) divided by the gains' range
+            assert rel_err(got["ranking"], ref["ranking"], 1e-2) < REL_TOL
         # covariances are symmetric positive definite
         c = got["covs"]
         assert np.allclose(c, np.transpose(c, (0, 2, 1)), rtol=1e-5, atol=1e-7)

@@ -79,3 +79,28 @@ def test_synthetic_inputs_follow_reference_convention():
     b = w["pyramid_classification"]["bias"].reshape(9, 8)
     assert np.allclose(b[:, :7], -np.log(99.0)) and np.all(b[:, 7] == 0)        # multitask_headers.py:79-83
     assert "pyramid_regression_3" in w                                          # built but unused
+
+
+def test_checkpoint_files_are_atomic_and_resume_skips_damaged_ones(tmp_path):
+    """run_training's checkpoint helpers (reference: tf.train.CheckpointManager, run_training.py:72-82): a save goes through a
+    temp file + rename, names that are not ckpt-<int>.npz are ignored, and listing orders by step."""
+    from bayes_od_rc_amd import run_training as rt
+
+    class FakeTrainer:
+        def weights(self):
+            return {"conv1": {"kernel": np.ones((2, 2), np.float32), "bias": None}}
+
+        def optimizer_state(self):
+            return {"optimizer/step": np.int64(3), "trainer/step": np.int64(3)}
+
+    d = str(tmp_path)
+    rt.save_checkpoint(FakeTrainer(), os.path.join(d, "ckpt-3.npz"))
+    rt.save_checkpoint(FakeTrainer(), os.path.join(d, "ckpt-12.npz"))
+    open(os.path.join(d, "ckpt-foo.npz"), "w").close()                 # stray name: must not raise
+    with open(os.path.join(d, "ckpt-20.npz"), "wb") as fp:              # truncated "latest": unreadable
+        fp.write(b"PK\x03\x04 not a zip")
+    assert [os.path.basename(p) for p in rt.sorted_checkpoints(d)] == ["ckpt-3.npz", "ckpt-12.npz", "ckpt-20.npz"]
+    assert not [f for f in os.listdir(d) if f.startswith(".tmp-")]
+    with np.load(os.path.join(d, "ckpt-12.npz")) as z:
+        assert set(z.files) == {"conv1/kernel", rt.OPT_PREFIX + "optimizer/step", rt.OPT_PREFIX + "trainer/step"}
+    assert rt.sorted_checkpoints(os.path.join(d, "missing")) == []
