@@ -102,6 +102,7 @@ SIGNATURES = {
     "bod_bench_head_conv": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bod_profile_begin": (C.c_int, [_H]),
     "bod_profile_select": (C.c_int, [_H, C.c_int32]),
+    "bod_plan_info": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "bod_profile_end": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -33,10 +33,12 @@
 #include "philox.h"
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -949,7 +951,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
         return;
     }
-    const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT, of32 = a.flags & CONV_OUT_F32;
+    const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT, of32 = !XR && (a.flags & CONV_OUT_F32);   // (row-reuse launches: head towers, bf16 / pair outputs only)
     if (of32) {
         // ---- fp32 outputs.  Channel counts that are multiples of 4 (input gradients, weight gradients): 16-byte
         // accesses, and with CONV_ACCUM the four old values of a fragment row are loaded before the first store
@@ -1027,86 +1029,243 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         static_assert(PPASS * ROW2 <= Cfg::MAIN, "split epilogue tile does not fit the staging area");
         uint32_t rng_seed_lo = a.seed_lo, rng_seed_hi = a.seed_hi, rng_image_base = a.image_base;
         if (a.dyn_rng) { rng_seed_lo = a.dyn_rng[0]; rng_seed_hi = a.dyn_rng[1]; rng_image_base = a.dyn_rng[2]; }
-        const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
+        // (uniform: the Philox key schedule -- 20 values -- stays in scalar registers)
+        rng_seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng_seed_lo);
+        rng_seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng_seed_hi);
+        // (row-reuse launches never fan out in this mode -- launch_conv_igemm refuses it: no sample loop there, so that nothing
+        // loop-invariant is hoisted in front of the passes, where all 128 accumulators are live)
+        const int fan = XR ? 1 : ((drop && a.fan_count > 1) ? a.fan_count : 1);
         const uint32_t thr_m1 = a.drop_threshold > 0 ? a.drop_threshold - 1u : 0u;
         const uint32_t thr_m1_x2 = thr_m1 | (thr_m1 << 16);
         uint16_t* out16 = reinterpret_cast<uint16_t*>(G.out);
-        __syncthreads();                              // all waves are done with the staging buffers
-        for (int n = 0; n < fan; ++n) {
+
+        // pass PASS of the tile: bias / residual / ReLU / (hi, lo) split / dropout mask in registers -> LDS tile [PPASS][ROW2]
+        auto write_pass = [&](auto PASS, int n) {
+            constexpr int pass = decltype(PASS)::value;
 #pragma unroll
-            for (int pass = 0; pass < EPASS; ++pass) {
+            for (int jj = 0; jj < JP; ++jj) {
+                constexpr int dummy = 0; (void)dummy;
+                const int j = pass * JP + jj;
+                const int pixl = wp * WTP + j * 32 + frow;
+                const int2 rg = s_rng[pixl];
+                const int ro = s_res[pixl];
+                const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
+                const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
 #pragma unroll
-                for (int jj = 0; jj < JP; ++jj) {
-                    const int j = pass * JP + jj;
-                    const int pixl = wp * WTP + j * 32 + frow;
-                    const int lr = wp * WPP + jj * 32 + frow;
+                for (int i = 0; i < FC; ++i) {
+                    Philox4 rr{0u, 0u, 0u, 0u};
+                    // the lane's row / half re-derived behind an opaque barrier per cout fragment: the tile addresses of this
+                    // fragment are then computed HERE -- otherwise the whole unrolled epilogue's address arithmetic is scheduled
+                    // to the top of the block, where all 128 accumulators are live, and spills by the hundred
+                    int fr_i = frow, fh_i = fhalf;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(fr_i), "+v"(fh_i));
+#endif
+                    const int lr = wp * WPP + jj * 32 + fr_i;
                     char* prow = smem + lr * ROW2;
-                    const int2 rg = s_rng[pixl];
-                    const int ro = s_res[pixl];
-                    const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
-                    const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
 #pragma unroll
-                    for (int i = 0; i < FC; ++i) {
-                        Philox4 rr{0u, 0u, 0u, 0u};
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = wc * WTC + i * 32 + g4 * 8 + fh_i * 4;
+                        const int slot = (col >> 5) * 64 + (col & 31);          // hi half; the lo half sits 32 slots on
+                        const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
+                        float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
+                                      __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
+                        if (G.res) {
+                            const uint16_t* rp = reinterpret_cast<const uint16_t*>(G.res) + (size_t)ro * a.res_cstride + bc0 * 2 + slot;
+                            const uint2 rh = *reinterpret_cast<const uint2*>(rp), rl = *reinterpret_cast<const uint2*>(rp + 32);
+                            v[0] += (bf16_to_f32(rh.x & 0xFFFFu) + bf16_to_f32(rl.x & 0xFFFFu)) * epi_scale;
+                            v[1] += (bf16_to_f32(rh.x >> 16) + bf16_to_f32(rl.x >> 16)) * epi_scale;
+                            v[2] += (bf16_to_f32(rh.y & 0xFFFFu) + bf16_to_f32(rl.y & 0xFFFFu)) * epi_scale;
+                            v[3] += (bf16_to_f32(rh.y >> 16) + bf16_to_f32(rl.y >> 16)) * epi_scale;
+                        }
+                        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        uint2 hi, lo;
+                        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
+                        lo.x = pack_bf16x2(v[0] - bf16_to_f32(hi.x & 0xFFFFu), v[1] - bf16_to_f32(hi.x >> 16));
+                        lo.y = pack_bf16x2(v[2] - bf16_to_f32(hi.y & 0xFFFFu), v[3] - bf16_to_f32(hi.y >> 16));
+                        if (drop) {                       // dropout contract v2, as in the bf16 epilogue below
+                            if ((g4 & 1) == 0)
+                                rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img,
+                                                   rng_seed_lo, rng_seed_hi);
+                            const uint32_t m0 = keep_mask_u16x2((g4 & 1) ? rr.z : rr.x, thr_m1_x2);
+                            const uint32_t m1 = keep_mask_u16x2((g4 & 1) ? rr.w : rr.y, thr_m1_x2);
+                            hi.x &= m0; lo.x &= m0; hi.y &= m1; lo.y &= m1;
+                        }
+                        const int ch = slot >> 3;
+                        *reinterpret_cast<uint2*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = hi;
+                        *reinterpret_cast<uint2*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = lo;
+                        __builtin_amdgcn_sched_barrier(0);           // one 4-channel run at a time (register pressure)
+                    }
+                }
+            }
+        };
+
+        // Fused 1x1 head output conv (+ MC aggregation) of the bf16x3 mode, row-reuse tower kernel only: after each pass the
+        // wave multiplies its share of the pass's 128 pixels -- cout2 fragment wave>>1, pixel fragments 2(wave&1), 2(wave&1)+1 --
+        // with the (hi, lo) weight pairs read straight from global memory (96 KB per head, L2-resident): per 16-channel half the
+        // products hi*lo, lo*hi, hi*hi in the main loop's order, i.e. the sums of a separate bf16x3 1x1 launch, bit for bit.  The
+        // fp32 outputs of both passes stay in registers (the accumulators are dead by then) until the whole tile is done; then
+        // they go out as [B,N,A,.] rows or, aggregating, through LDS into agg_reduce_* exactly like the bf16 mode's tile.
+        // (Its own straight-line branch of the epilogue: the four output fragments are defined on every path that reads them.)
+        constexpr bool CAN_FUSE_S = XR && BC == 256 && BP == 256 && WC * WP == 8 && EPASS == 2 && JP == 1;
+        if constexpr (CAN_FUSE_S) {
+            if (G.w2 != nullptr) {
+                const int f2 = wave >> 1;
+                const bool fuse_active = f2 * 32 < G.cout2;
+#if defined(__HIP_DEVICE_COMPILE__)
+                // weight fragments by buffer loads: resource in SGPRs, ONE 32-bit lane offset, batch / fragment offsets as scalar +
+                // immediate (sixteen 64-bit lane pointers would not fit beside the accumulators); the next batch of fragments is in flight
+                // while the current one multiplies
+                const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.w2), 0, -1, 0x00020000);
+                auto one_by_one = [&](f32x16& y0, f32x16& y1, u32x4 (&wn)[4]) {
+                    const int lr0 = (wave & 1) * 64 + frow, lr1 = lr0 + 32;
+                    const char* prow0 = smem + lr0 * ROW2;
+                    const char* prow1 = smem + lr1 * ROW2;
+                    int w2lane = ((f2 * 32 + frow) * 512 + fhalf * 8) * 2;
+                    asm volatile("" : "+v"(w2lane));
+#pragma unroll 1
+                    for (int cb = 0; cb < 8; ++cb) {          // a batch = 32 channels = the (hi, lo) fragments of two 16-channel halves
+                        bf16x8 wc[4];
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
-                            const int slot = (col >> 5) * 64 + (col & 31);          // hi half; the lo half sits 32 slots on
-                            const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
-                            float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
-                                          __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
-                            if (G.res) {
-                                const uint16_t* rp = reinterpret_cast<const uint16_t*>(G.res) + (size_t)ro * a.res_cstride + bc0 * 2 + slot;
-                                const uint2 rh = *reinterpret_cast<const uint2*>(rp), rl = *reinterpret_cast<const uint2*>(rp + 32);
-                                v[0] += (bf16_to_f32(rh.x & 0xFFFFu) + bf16_to_f32(rl.x & 0xFFFFu)) * epi_scale;
-                                v[1] += (bf16_to_f32(rh.x >> 16) + bf16_to_f32(rl.x >> 16)) * epi_scale;
-                                v[2] += (bf16_to_f32(rh.y & 0xFFFFu) + bf16_to_f32(rl.y & 0xFFFFu)) * epi_scale;
-                                v[3] += (bf16_to_f32(rh.y >> 16) + bf16_to_f32(rl.y >> 16)) * epi_scale;
-                            }
-                            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                            uint2 hi, lo;
-                            hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
-                            lo.x = pack_bf16x2(v[0] - bf16_to_f32(hi.x & 0xFFFFu), v[1] - bf16_to_f32(hi.x >> 16));
-                            lo.y = pack_bf16x2(v[2] - bf16_to_f32(hi.y & 0xFFFFu), v[3] - bf16_to_f32(hi.y >> 16));
-                            if (drop) {                       // dropout contract v2, as in the bf16 epilogue below
-                                if ((g4 & 1) == 0)
-                                    rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img,
-                                                       rng_seed_lo, rng_seed_hi);
-                                const uint32_t m0 = keep_mask_u16x2((g4 & 1) ? rr.z : rr.x, thr_m1_x2);
-                                const uint32_t m1 = keep_mask_u16x2((g4 & 1) ? rr.w : rr.y, thr_m1_x2);
-                                hi.x &= m0; lo.x &= m0; hi.y &= m1; lo.y &= m1;
-                            }
-                            const int ch = slot >> 3;
-                            *reinterpret_cast<uint2*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = hi;
-                            *reinterpret_cast<uint2*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4) + (slot & 7) * 2) = lo;
-                            __builtin_amdgcn_sched_barrier(0);           // one 4-channel run at a time (register pressure)
+                        for (int k = 0; k < 4; ++k) wc[k] = __builtin_bit_cast(bf16x8, wn[k]);
+                        if (cb < 7) {
+                            const int so = (cb + 1) * 128;
+                            wn[0] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane, so, 0);      wn[1] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 64, so, 0);
+                            wn[2] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 32, so, 0); wn[3] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 96, so, 0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            // half k of the batch: the lane's 8 channels c8 = (cb*2 + k)*2 + fhalf -> chunk of their hi half
+                            const int ch = cb * 8 + k * 2 + fhalf;
+                            const bf16x8 Bh0 = *reinterpret_cast<const bf16x8*>(prow0 + (((ch ^ lr0) & (CPR2 - 1)) << 4));
+                            const bf16x8 Bl0 = *reinterpret_cast<const bf16x8*>(prow0 + ((((ch + 4) ^ lr0) & (CPR2 - 1)) << 4));
+                            const bf16x8 Bh1 = *reinterpret_cast<const bf16x8*>(prow1 + (((ch ^ lr1) & (CPR2 - 1)) << 4));
+                            const bf16x8 Bl1 = *reinterpret_cast<const bf16x8*>(prow1 + ((((ch + 4) ^ lr1) & (CPR2 - 1)) << 4));
+                            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k], Bl0, y0, 0, 0, 0);     y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k], Bl1, y1, 0, 0, 0);
+                            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k + 1], Bh0, y0, 0, 0, 0); y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k + 1], Bh1, y1, 0, 0, 0);
+                            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k], Bh0, y0, 0, 0, 0);     y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[2 * k], Bh1, y1, 0, 0, 0);
                         }
                     }
-                }
+                };
+                auto first_batch = [&](u32x4 (&wn)[4]) {             // requested before the pass's barrier: L2 latency under the wait
+                    int w2lane = ((f2 * 32 + frow) * 512 + fhalf * 8) * 2;
+                    asm volatile("" : "+v"(w2lane));
+                    wn[0] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane, 0, 0);      wn[1] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 64, 0, 0);
+                    wn[2] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 32, 0, 0); wn[3] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w2lane + 96, 0, 0);
+                };
+                __syncthreads();                          // all waves are done with the staging buffers
+                f32x16 y00, y01, y10, y11;                // [pass][pixel fragment 2(wave&1) + h]
+                u32x4 wn[4];
+                // ---- pass 0
+                write_pass(std::integral_constant<int, 0>{}, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wn[k] = u32x4{0u, 0u, 0u, 0u};
+                if (fuse_active) first_batch(wn);
                 __syncthreads();
-                for (int q = tid; q < PPASS * (CPR2 / 2); q += THREADS) {       // a (hi chunk, lo chunk) pair per item
-                    const int lr = q / (CPR2 / 2), hc = q % (CPR2 / 2);
-                    const int ch = (hc >> 2) * 8 + (hc & 3);
-                    const int rem = lr % WPP;
-                    const int pixl = (lr / WPP) * WTP + (pass * JP + rem / 32) * 32 + (rem & 31);
-                    const int off = s_off[pixl];
-                    if (off < 0) continue;
-                    const char* prow = smem + lr * ROW2;
-                    const uint4 vh = *reinterpret_cast<const uint4*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4));
-                    const uint4 vl = *reinterpret_cast<const uint4*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4));
-                    const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 * 2 + ch * 8;
-                    *reinterpret_cast<uint4*>(out16 + e) = vh;
-                    *reinterpret_cast<uint4*>(out16 + e + 32) = vl;
-                    if (G.out_relu) {                 // relu(hi + lo): the pair survives iff hi is not negative
-                        auto keep = [](uint32_t h) { return ~(((h >> 15) & 0x00010001u) * 0xFFFFu); };
-                        const uint32_t k0 = keep(vh.x), k1 = keep(vh.y), k2 = keep(vh.z), k3 = keep(vh.w);
-                        uint16_t* o2 = reinterpret_cast<uint16_t*>(G.out_relu);
-                        *reinterpret_cast<uint4*>(o2 + e) = make_uint4(vh.x & k0, vh.y & k1, vh.z & k2, vh.w & k3);
-                        *reinterpret_cast<uint4*>(o2 + e + 32) = make_uint4(vl.x & k0, vl.y & k1, vl.z & k2, vl.w & k3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; }
+                if (fuse_active) one_by_one(y00, y01, wn);
+                __syncthreads();                          // the pass's tile has been read: the next pass may overwrite it
+                // ---- pass 1
+                write_pass(std::integral_constant<int, 1>{}, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wn[k] = u32x4{0u, 0u, 0u, 0u};
+                if (fuse_active) first_batch(wn);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { y10[r] = 0.f; y11[r] = 0.f; }
+                if (fuse_active) one_by_one(y10, y11, wn);
+                __syncthreads();                          // ... or the fp32 output tile
+                // ---- outputs: cout2 rows f2*32 + g4*8 + fhalf*4 + r of tile pixels (2(wave&1) + h)*64 + pass*32 + frow
+                int frow_o = frow, fhalf_o = fhalf;
+                asm volatile("" : "+v"(frow_o), "+v"(fhalf_o));      // output addresses are computed HERE (hoisted, they spill)
+                auto each_fragment = [&](auto&& fn) {
+                    fn(y00, ((wave & 1) * 2 + 0) * 64 + 0 * 32 + frow_o); fn(y01, ((wave & 1) * 2 + 1) * 64 + 0 * 32 + frow_o);
+                    fn(y10, ((wave & 1) * 2 + 0) * 64 + 1 * 32 + frow_o); fn(y11, ((wave & 1) * 2 + 1) * 64 + 1 * 32 + frow_o);
+                };
+                if (G.agg_kind != AGG_NONE) {
+                    const int ystride = ((G.cout2 + 31) & ~31) + 4;            // floats per row: = 4 mod 32, conflict-free 16-byte writes
+                    float* ytile = reinterpret_cast<float*>(smem);
+                    if (fuse_active)
+                        each_fragment([&](const f32x16& y, int row) {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int co2 = f2 * 32 + g4 * 8 + fhalf_o * 4;
+                                if (co2 >= G.cout2) continue;
+                                const float4 b2 = *reinterpret_cast<const float4*>(G.bias2 + co2);
+                                *reinterpret_cast<float4*>(ytile + (size_t)row * ystride + co2) =
+                                    make_float4(y[g4 * 4 + 0] + b2.x, y[g4 * 4 + 1] + b2.y, y[g4 * 4 + 2] + b2.z, y[g4 * 4 + 3] + b2.w);
+                            }
+                        });
+                    __syncthreads();
+                    if (G.agg_kind == AGG_CLS) {
+                        if (G.agg_C == 8) agg_reduce_cls<8>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+                        else agg_reduce_cls<4>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+                    } else if (G.agg_kind == AGG_BOX) {
+                        agg_reduce_box(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
+                    } else {
+                        agg_reduce_cov(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
                     }
+                    return;
                 }
-                if (pass + 1 < EPASS || n + 1 < fan) __syncthreads();
+                if (fuse_active)
+                    each_fragment([&](const f32x16& y, int pixl) {
+                        if (s_off[pixl] < 0) return;
+                        float* orow = G.out2 + (size_t)s_off2[pixl] * G.out2_cstride;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int co2 = f2 * 32 + g4 * 8 + fhalf_o * 4;
+                            if (co2 >= G.cout2) continue;
+                            const float4 b2 = *reinterpret_cast<const float4*>(G.bias2 + co2);
+                            const float v0 = y[g4 * 4 + 0] + b2.x, v1 = y[g4 * 4 + 1] + b2.y;
+                            const float v2 = y[g4 * 4 + 2] + b2.z, v3 = y[g4 * 4 + 3] + b2.w;
+                            if (co2 + 1 < G.cout2) *reinterpret_cast<float2*>(orow + co2) = make_float2(v0, v1);
+                            else orow[co2] = v0;
+                            if (co2 + 3 < G.cout2) *reinterpret_cast<float2*>(orow + co2 + 2) = make_float2(v2, v3);
+                            else if (co2 + 2 < G.cout2) orow[co2 + 2] = v2;
+                        }
+                    });
+#endif
+                return;                               // the tile itself has no other consumer (fused groups never fan out)
             }
+        }
+
+        auto store_pass = [&](int pass, int n) {      // LDS tile -> 16-byte stores of (hi chunk, lo chunk) pairs of whole pixel rows
+            for (int q = tid; q < PPASS * (CPR2 / 2); q += THREADS) {
+                const int lr = q / (CPR2 / 2), hc = q % (CPR2 / 2);
+                const int ch = (hc >> 2) * 8 + (hc & 3);
+                const int rem = lr % WPP;
+                const int pixl = (lr / WPP) * WTP + (pass * JP + rem / 32) * 32 + (rem & 31);
+                const int off = s_off[pixl];
+                if (off < 0) continue;
+                const char* prow = smem + lr * ROW2;
+                const uint4 vh = *reinterpret_cast<const uint4*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4));
+                const uint4 vl = *reinterpret_cast<const uint4*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4));
+                const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 * 2 + ch * 8;
+                *reinterpret_cast<uint4*>(out16 + e) = vh;
+                *reinterpret_cast<uint4*>(out16 + e + 32) = vl;
+                if (G.out_relu) {                 // relu(hi + lo): the pair survives iff hi is not negative
+                    auto keep = [](uint32_t h) { return ~(((h >> 15) & 0x00010001u) * 0xFFFFu); };
+                    const uint32_t k0 = keep(vh.x), k1 = keep(vh.y), k2 = keep(vh.z), k3 = keep(vh.w);
+                    uint16_t* o2 = reinterpret_cast<uint16_t*>(G.out_relu);
+                    *reinterpret_cast<uint4*>(o2 + e) = make_uint4(vh.x & k0, vh.y & k1, vh.z & k2, vh.w & k3);
+                    *reinterpret_cast<uint4*>(o2 + e + 32) = make_uint4(vl.x & k0, vl.y & k1, vl.z & k2, vl.w & k3);
+                }
+            }
+        };
+        __syncthreads();                              // all waves are done with the staging buffers
+        for (int n = 0; n < fan; ++n) {
+            write_pass(std::integral_constant<int, 0>{}, n);
+            __syncthreads();
+            store_pass(0, n);
+            if constexpr (EPASS > 1) {
+                static_assert(EPASS <= 2, "two passes at most");
+                __syncthreads();
+                write_pass(std::integral_constant<int, EPASS - 1>{}, n);
+                __syncthreads();
+                store_pass(EPASS - 1, n);
+            }
+            if (n + 1 < fan) __syncthreads();
         }
         return;
     }
@@ -1635,9 +1794,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (forced == 128) big = false;
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
-    if (a.split) {                                   // bf16x3: no fused 1x1, no ablation builds, no fan-out on the row-reuse loop
+    if (a.split) {                                   // bf16x3: fused 1x1 (+ aggregation) on the row-reuse loop only, no ablation builds, no fan-out on the row-reuse loop
         if (a.variant != 0 || a.cin % 128 != 0 || (a.xreuse && (a.xreuse != 2 || a.fan_count > 1))) return hipErrorInvalidValue;
-        for (int g = 0; g < a.groups; ++g) if (a.g[g].w2) return hipErrorInvalidValue;
+        for (int g = 0; g < a.groups; ++g) if (a.g[g].w2 && !a.xreuse) return hipErrorInvalidValue;   // the fused 1x1 lives in the row-reuse kernel's epilogue
     }
     if (a.ksplit > 1) {
         if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & CONV_DROPOUT) || a.variant != 0)
@@ -1653,7 +1812,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     }
     if (a.split) {
         if (a.xreuse) {
-            if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
+            if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0) || (a.flags & CONV_OUT_F32)) return hipErrorInvalidValue;
             return launch_cfg<256, 256, 2, 4, 0, true, true>(a, s);
         }
         if (big) return launch_cfg<256, 256, 2, 4, 0, false, true>(a, s);
@@ -1664,6 +1823,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.xreuse) {
         if (!(big && a.cout_pad == 256 && a.taps == 9 && a.KW == 3 && a.ext && a.M % 256 == 0)) return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g) if (a.g[g].res || a.g[g].out_relu) return hipErrorInvalidValue;   // compiled out of the row-reuse kernel
+        if (a.flags & CONV_OUT_F32) return hipErrorInvalidValue;                                              // likewise
         // xreuse == 2: compact-state, software-pipelined loop (32-bit byte offsets against the tile's first extended row);
         // otherwise (or variant 81, for A/B timing) the first-generation loop with 64-bit pointers
         if (a.xreuse != 2 || a.variant == 81) return launch_cfg<256, 256, 2, 4, 81, true>(a, s);

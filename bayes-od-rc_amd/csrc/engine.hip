@@ -111,6 +111,7 @@ struct bod_context {
     // MC aggregation fused into the last tower layers (ConvGroup.agg_kind): per-anchor statistics instead of raw[]
     float* agg[3] = {nullptr};                           // sum softmax [B,A,C], Welford box [B,A,16], sum cov params [B,A,10]
     bool agg_plan = false;                               // the plan holds FLAVOUR_AGG ops
+    bool plan_fused_out = false, plan_xreuse = false, plan_xreuse0 = false;     // bod_plan_info
     bool raw_valid = false, agg_valid = false;           // which of the two the last forward produced
     uint64_t last_seed = 0; uint32_t last_first_image = 0;
     std::map<std::string, RowEnt*> tables;
@@ -595,7 +596,9 @@ bod_status build_plan(bod_context* h) {
     // Fuse each head's 1x1 output conv into the epilogue of its last tower layer whenever that layer runs
     // with the full 256-channel cout tile (bf16 mode, enough rows): the last tower activation then never
     // goes to HBM and three launches disappear.  BOD_FUSE_HEAD_OUTPUT=0 keeps the separate launches.
-    bool fuse_out = h->es == 2 && !train_mode;
+    // (bf16x3: the fused form exists in the row-reuse kernel's epilogue only -- `xreuse` below -- with the same products in the
+    // same order as the separate 1x1 launches: bit-identical head outputs either way)
+    bool fuse_out = (h->es == 2 || (h->split && xreuse)) && !train_mode;
     if (const char* e = getenv("BOD_FUSE_HEAD_OUTPUT")) fuse_out = fuse_out && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -628,7 +631,7 @@ bod_status build_plan(bod_context* h) {
     } else {
         BODCHK(ensure_raw(h));                 // the ops below reference the raw tensors directly
     }
-    h->agg_plan = agg;
+    h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0;
     for (int layer = 0; layer < 4; ++layer)
     for (int flav = (agg && layer >= 2) ? FLAVOUR_RAW : FLAVOUR_BOTH; flav <= ((agg && layer >= 2) ? FLAVOUR_AGG : FLAVOUR_BOTH); ++flav) {
         Op op; op.kind = Op::CONV; op.is_head3x3 = true; op.flavour = flav;
@@ -1998,6 +2001,15 @@ bod_status bod_profile_begin(bod_handle h) {
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     h->ev_head.clear(); h->ev_post.clear(); h->prof_flops = 0; h->profiling = true;
+    return BOD_OK;
+}
+
+bod_status bod_plan_info(bod_handle h, int32_t* info8) {
+    if (!h || !info8) return BOD_ERR_INVALID_ARG;
+    if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "bod_plan_info: the plan is built by bod_finalize_weights");
+    for (int i = 0; i < 8; ++i) info8[i] = 0;
+    info8[0] = h->agg_plan; info8[1] = h->plan_fused_out; info8[2] = h->plan_xreuse; info8[3] = h->plan_xreuse0;
+    info8[4] = (int32_t)h->ops.size();
     return BOD_OK;
 }
 

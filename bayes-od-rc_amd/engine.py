@@ -400,6 +400,17 @@ class Engine(object):
         return ms.value, fl.value
 
     # ------------------------------------------------------------------ measurement
+    def plan_info(self):
+        """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops'} of the forward plan (bod_plan_info)."""
+        info = (C.c_int32 * 8)()
+        self._chk(self.lib.bod_plan_info(self.h, info))
+        return {"aggregating": bool(info[0]), "fused_head_outputs": bool(info[1]), "row_reuse": bool(info[2]),
+                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4])}
+
+    @property
+    def aggregating(self):
+        return self.plan_info()["aggregating"]
+
     def profile_begin(self, which=None):
         """which: None keeps the current selection; 0 = every head 3x3 launch, 1 = the row-reuse tower kernel's launches
         only (one kernel symbol), 2 = the others (the fan-out launch of the first tower layer)."""

@@ -28,6 +28,7 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb1EE",     # bf16x3 precision: the three tile configurations
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb1EE",     # bf16x3 on the row-reuse loop (fused 1x1 + MC aggregation)
 ]
 INLINE_ASM_MFMA = PRODUCTION[:2]                               # the kernels on the 16x16x32 inline-asm loop
 

@@ -329,6 +329,12 @@ bod_status bod_profile_select(bod_handle h, int32_t which);
 bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
                            double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
 
+/* What the handle's plan looks like (tests / bench report it; nothing on the hot path reads it).  info8[0] = 1 when the MC
+ * statistics are reduced inside the last tower layers' tiles (no [B,N,A,.] tensors on the bod_infer path), [1] = 1 when the 1x1
+ * head output convs are fused into the last tower layers' epilogues, [2] = 1 when the per-sample tower layers run on the
+ * activation-row-reuse kernel, [3] = 1 when the fan-out layer does, [4] = number of ops of the forward plan, [5..7] = 0. */
+bod_status bod_plan_info(bod_handle h, int32_t* info8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,3 +131,4 @@ bod_status bod_profile_begin(bod_handle h);
 bod_status bod_profile_select(bod_handle h, int32_t which);
 bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
                            double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
+bod_status bod_plan_info(bod_handle h, int32_t* info8);

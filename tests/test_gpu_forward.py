@@ -166,9 +166,12 @@ def test_non_square_and_odd_pyramids(hw, precision):
     assert _rms(c16 - f64["anchors_class_predictions"]) / _rms(f64["anchors_class_predictions"]) < 2e-2
 
 
-def test_fused_head_output_equals_separate_launches():
-    """The 1x1 head output convs fused into the last tower layer's epilogue (bf16 mode, 256-wide cout
-    tile) give the same raw head outputs as the separate 1x1 launches."""
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_fused_head_output_equals_separate_launches(precision):
+    """The 1x1 head output convs fused into the last tower layer's epilogue (256-wide cout tile) give the same raw head
+    outputs as the separate 1x1 launches: to fp32 round-off in the bf16 mode (the fused form multiplies the bf16 tile in LDS,
+    the separate launch the same values from HBM, in another summation order), BIT FOR BIT in the bf16x3 mode, whose fused form
+    issues the (hi, lo) products of the separate launch in the same order per accumulator."""
     import os
     import subprocess
     import sys
@@ -177,23 +180,30 @@ def test_fused_head_output_equals_separate_launches():
     code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
             "from bayes_od_rc_amd import synthetic\n"
             "from bayes_od_rc_amd.engine import Engine, make_config\n"
-            "eng = Engine(make_config((128, 160), batch=2, mc_samples=3))\n"
+            "eng = Engine(make_config((128, 160), batch=2, mc_samples=3, precision=%r))\n"
             "eng.load_weights(synthetic.make_weights())\n"
+            "eng.profile_begin(which=0)\n"
             "eng.forward(synthetic.make_frames(2, 128, 160, seed=6), seed=21, first_image_id=4)\n"
+            "print('HEAD_LAUNCHES', eng.profile_end()['head_conv_launches'])\n"
             "c, b, v = eng.get_raw()\n"
-            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % root)
+            "np.savez(sys.argv[1], c=c, b=b, v=v)\n" % (root, precision))
     outs = []
     for fuse in ("1", "0"):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "o.npz")
             env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_FUSE_HEAD_OUTPUT=fuse)
-            subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            assert "HEAD_LAUNCHES 4" in r.stdout, r.stdout[-300:]       # the four tower launches either way (1x1 launches are not head 3x3 launches)
             z = np.load(path)
             outs.append({k: z[k] for k in z.files})
     for k in ("c", "b", "v"):
         a, b = outs[0][k], outs[1][k]
-        assert a.shape == b.shape
-        assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max())), k
+        assert a.shape == b.shape and np.abs(b).max() > 0
+        if precision == "bf16x3":
+            assert np.array_equal(a, b), k
+        else:
+            assert np.max(np.abs(a - b)) <= 1e-5 * max(1.0, float(np.abs(b).max())), k
 
 
 @pytest.mark.parametrize("precision", ["bf16", "bf16x3"])

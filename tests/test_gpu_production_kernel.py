@@ -58,6 +58,8 @@ def test_heads_on_device_pyramid_match_bf16_emulation():
 
 
 FORCED_SUITE = [
+    "tests/test_gpu_pipeline.py::test_fp32_pipeline_matches_oracle_end_to_end[bf16x3]",      # bf16x3 on the fused row-reuse kernel + MC aggregation
+    "tests/test_gpu_forward.py::test_fp32_mode_end_to_end[hw0-2-3-50-bf16x3]",
     "tests/test_gpu_production_kernel.py::test_heads_on_device_pyramid_match_bf16_emulation",
     "tests/test_gpu_forward.py::test_forward_at_bf16_noise_floor",
     "tests/test_gpu_pipeline.py::test_infer_stage_chain_matches_oracle",
@@ -107,12 +109,13 @@ from bayes_od_rc_amd import synthetic
 from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
 from bayes_od_rc_amd.engine import Engine, make_config
 h, w, batch, n = (int(v) for v in sys.argv[3:7])
-eng = Engine(make_config((h, w), batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+precision = sys.argv[7] if len(sys.argv) > 7 else "bf16"
+eng = Engine(make_config((h, w), batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True, precision=precision))
 eng.load_weights(synthetic.make_weights(cls_fg_bias=-1.0))
 eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((h, w, 3)))
 frames = synthetic.make_frames(batch, h, w, seed=31)
 eng.infer(frames, seed=77, first_image_id=5)
-out = {}
+out = {"agg_plan": np.int32(eng.aggregating)}
 for b in range(batch):
     post = eng.get_posterior(b)
     for k, v in post.items():
@@ -128,24 +131,27 @@ np.savez(sys.argv[2], **out)
 """
 
 
-@pytest.mark.parametrize("h,w,batch,n", [(128, 160, 2, 5), (96, 160, 1, 30), (128, 128, 3, 2), (160, 160, 1, 10)])
-def test_fused_mc_aggregation_equals_the_raw_path(tmp_path, h, w, batch, n):
+@pytest.mark.parametrize("h,w,batch,n,precision", [(128, 160, 2, 5, "bf16"), (96, 160, 1, 30, "bf16"), (128, 128, 3, 2, "bf16"), (160, 160, 1, 10, "bf16"),
+                                                   (128, 160, 2, 5, "bf16x3"), (160, 160, 1, 10, "bf16x3"), (96, 96, 1, 30, "bf16x3")])
+def test_fused_mc_aggregation_equals_the_raw_path(tmp_path, h, w, batch, n, precision):
     """The MC aggregation fused into the last tower layers' epilogues (sum of softmax, Welford box mean / co-moments, sum of
     covariance parameters; sample-complete tiles) against the same pipeline with BOD_FUSE_AGGREGATION=0, i.e. raw
     [B,N,A,.] tensors + the posterior kernels' own loops: identical kept set, Dirichlet counts and scores bit for bit
     (the softmax sums are the same operations in the same order), box means / covariances to fp32 round-off (Welford
     vs two-pass), identical soft-NMS centres; and the raw tensors re-materialised after an aggregating infer equal a
-    raw-flavour forward bit for bit."""
+    raw-flavour forward bit for bit.  Both precisions: the bf16x3 mode runs the same fused epilogue on (hi, lo) pairs
+    (the production data path of the parity mode: no [B,N,A,.] tensors)."""
     outs = []
     for fuse in ("1", "0"):
         path = str(tmp_path / ("agg%s.npz" % fuse))
         env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_FUSE_AGGREGATION=fuse)
-        r = subprocess.run([sys.executable, "-c", _AGG_SCRIPT, ROOT, path, str(h), str(w), str(batch), str(n)], env=env,
+        r = subprocess.run([sys.executable, "-c", _AGG_SCRIPT, ROOT, path, str(h), str(w), str(batch), str(n), precision], env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         z = np.load(path)
         outs.append({k: z[k] for k in z.files})
     fused, plain = outs
+    assert int(fused["agg_plan"]) == 1 and int(plain["agg_plan"]) == 0       # the switch really selects the two plans (both precisions)
     for k in ("raw_cls", "raw_box", "raw_cov"):
         assert np.array_equal(fused[k], plain[k]), k               # the tiling of the last layers does not enter the arithmetic
     for b in range(batch):
