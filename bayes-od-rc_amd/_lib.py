@@ -103,6 +103,8 @@ SIGNATURES = {
     "bod_profile_begin": (C.c_int, [_H]),
     "bod_profile_select": (C.c_int, [_H, C.c_int32]),
     "bod_plan_info": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "bod_record_width": (C.c_int32, [_H]),
+    "bod_gather_detections": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bod_profile_end": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -1112,6 +1112,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             if (G.w2 != nullptr) {
                 const int f2 = wave >> 1;
                 const bool fuse_active = f2 * 32 < G.cout2;
+                (void)fuse_active;
 #if defined(__HIP_DEVICE_COMPILE__)
                 // weight fragments by buffer loads: resource in SGPRs, ONE 32-bit lane offset, batch / fragment offsets as scalar +
                 // immediate (sixteen 64-bit lane pointers would not fit beside the accumulators); the next batch of fragments is in flight

@@ -134,6 +134,7 @@ struct bod_context {
     hipEvent_t ev_posterior = nullptr; hipEvent_t ev_done[2] = {nullptr, nullptr};
     bool side_pending[2] = {false, false};
     char* host_stage[2] = {nullptr, nullptr};     // pinned host copy of a slot's records (filled on the side stream)
+    float* rec_send = nullptr; float* rec_recv = nullptr; size_t rec_recv_elems = 0;      // bod_gather_detections: packed records, gathered blocks
     void select_slot(int sidx) {
         slot = sidx;
         nms_sel = nms_sel_s[sidx]; nms_nsel = nms_nsel_s[sidx];
@@ -1067,6 +1068,8 @@ bod_status bod_destroy(bod_handle h) {
     for (int sidx = 0; sidx < 2; ++sidx) if (h->ev_done[sidx]) hipEventDestroy(h->ev_done[sidx]);
     train_destroy(h);
     for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
+    if (h->rec_recv && h->rec_recv != h->rec_send) hipFree(h->rec_recv);
+    if (h->rec_send) hipFree(h->rec_send);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
     if (h->affinity) hipFree(h->affinity);
@@ -2001,6 +2004,88 @@ bod_status bod_profile_begin(bod_handle h) {
     for (auto& e : h->ev_head) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : h->ev_post) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     h->ev_head.clear(); h->ev_post.clear(); h->prof_flops = 0; h->profiling = true;
+    return BOD_OK;
+}
+
+// ---- the path's one multi-GPU exchange through the C ABI ----
+extern "C++" {
+namespace {
+// RCCL is opened at run time: the library neither links librccl nor needs it on a single GPU.  (ncclGather is RCCL's own entry point;
+// datatype 7 = ncclFloat32, result 0 = ncclSuccess -- rccl.h.)
+struct Rccl {
+    typedef int (*gather_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    gather_fn gather = nullptr; errstr_fn errstr = nullptr; bool tried = false;
+    bool load() {
+        if (tried) return gather != nullptr;
+        tried = true;
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return false;
+        gather = reinterpret_cast<gather_fn>(dlsym(lib, "ncclGather"));
+        errstr = reinterpret_cast<errstr_fn>(dlsym(lib, "ncclGetErrorString"));
+        return gather != nullptr;
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+}  // namespace
+}  // extern "C++"
+
+int32_t bod_record_width(bod_handle h) { return h ? 21 + 2 * h->cfg.num_classes : 0; }
+
+bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, int32_t world, int32_t rank, int32_t root,
+                                 float* gathered_host, float** gathered_device) {
+    MarkerRange mr_api("bod:gather_detections");
+    if (!h) return BOD_ERR_INVALID_ARG;
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return h->fail(BOD_ERR_INVALID_ARG, "bod_gather_detections: world %d, rank %d, root %d", world, rank, root);
+    if (!nccl_comm && world != 1) return h->fail(BOD_ERR_INVALID_ARG, "bod_gather_detections: %d ranks need an ncclComm_t", world);
+    if (rank != root && (gathered_host || gathered_device)) return h->fail(BOD_ERR_INVALID_ARG, "bod_gather_detections: only the root receives");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.batch, K = h->cfg.nms_max_output_size, C = h->cfg.num_classes, W = 21 + 2 * C;
+    const size_t block = (size_t)B * K * W;
+    // where the records are and which stream finished them
+    int sidx = slot;
+    hipStream_t st = h->side;
+    if (slot < 0) {                                   // synchronous bod_infer / bod_cluster_fuse: current buffers, main stream
+        if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_gather_detections: bod_cluster_fuse has not run");
+        sidx = h->slot;
+        HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
+    } else if (slot > 1 || !h->side_pending[slot]) {
+        return h->fail(BOD_ERR_NOT_READY, "bod_gather_detections: slot %d has no pending batch", slot);
+    }
+    if (!h->rec_send && hipMalloc(reinterpret_cast<void**>(&h->rec_send), block * 4) != hipSuccess)
+        return h->fail(BOD_ERR_OOM, "bod_gather_detections: %zu bytes", block * 4);
+    HIPCHK(h, launch_pack_records(h->nms_nsel_s[sidx], h->out_scores_s[sidx], h->out_means_s[sidx], h->out_covs_s[sidx],
+                                  h->out_counts_s[sidx], h->rec_send, B, K, C, st));
+    float* recv = nullptr;
+    if (rank == root) {
+        if (world == 1 && !nccl_comm) recv = h->rec_send;
+        else {
+            if (h->rec_recv_elems < block * world) {
+                if (h->rec_recv && h->rec_recv != h->rec_send) hipFree(h->rec_recv);
+                h->rec_recv = nullptr; h->rec_recv_elems = 0;
+                if (hipMalloc(reinterpret_cast<void**>(&h->rec_recv), block * world * 4) != hipSuccess)
+                    return h->fail(BOD_ERR_OOM, "bod_gather_detections: %zu bytes", block * world * 4);
+                h->rec_recv_elems = block * world;
+            }
+            recv = h->rec_recv;
+        }
+    }
+    if (nccl_comm) {
+        if (!rccl().load()) return h->fail(BOD_ERR_NOT_READY, "bod_gather_detections: librccl.so (ncclGather) could not be opened");
+        const int rc = rccl().gather(h->rec_send, recv, block, /*ncclFloat32*/ 7, root, nccl_comm, st);
+        if (rc != 0) return h->fail(BOD_ERR_HIP, "ncclGather: %s", rccl().errstr ? rccl().errstr(rc) : "error");
+    }
+    if (rank == root && gathered_host) {
+        HIPCHK(h, hipMemcpyAsync(gathered_host, recv, block * world * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+    } else if (slot >= 0) {
+        // keep bod_collect / the next bod_infer_async of this slot behind the send: re-record the slot's event
+        HIPCHK(h, hipEventRecord(h->ev_done[slot], st));
+    }
+    if (gathered_device) *gathered_device = recv;
     return BOD_OK;
 }
 

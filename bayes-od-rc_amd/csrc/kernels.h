@@ -187,6 +187,9 @@ struct ClusterArgs {
 };
 hipError_t launch_cluster_fuse(const ClusterArgs& a, hipStream_t s);
 hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s);
+// detection records [B][K][1 + 4 + 16 + 2C] of the multi-GPU gather (zero rows beyond num[b])
+hipError_t launch_pack_records(const int32_t* num, const float* scores, const float* means, const float* covs, const float* counts,
+                               float* rec, int B, int K, int C, hipStream_t s);
 
 struct PreprocArgs {
     const uint8_t* src;        // [B, sh, sw, 3] uint8 RGB

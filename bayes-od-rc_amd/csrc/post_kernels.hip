@@ -920,6 +920,39 @@ __global__ void iou_matrix_kernel(const float4* boxes, int M, float* out) {
     if (j < M) out[(size_t)i * M + j] = iou_plus1(boxes[i], boxes[j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Detection records for the path's one multi-GPU exchange: per image K padded rows of
+// W = 1 + 4 + 16 + 2C floats -- [valid, mean (v,u,h,w), covariance row-major, score[C], counts[C]] -- zero beyond the image's
+// detection count.  The layout of distributed.pack_records, written by one kernel instead of five torch ops.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_records_kernel(const int32_t* __restrict__ num, const float* __restrict__ scores,
+                                                           const float* __restrict__ means, const float* __restrict__ covs,
+                                                           const float* __restrict__ counts, float* __restrict__ rec, int B, int K, int C) {
+    const int W = 21 + 2 * C;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * K * W) return;
+    const int w = (int)(i % W);
+    const long row = i / W;                      // b * K + k
+    const int b = (int)(row / K), k = (int)(row % K);
+    float v = 0.f;
+    if (k < num[b]) {
+        if (w == 0) v = 1.f;
+        else if (w < 5) v = means[row * 4 + (w - 1)];
+        else if (w < 21) v = covs[row * 16 + (w - 5)];
+        else if (w < 21 + C) v = scores[row * C + (w - 21)];
+        else v = counts[row * C + (w - 21 - C)];
+    }
+    rec[i] = v;
+}
+
+hipError_t launch_pack_records(const int32_t* num, const float* scores, const float* means, const float* covs, const float* counts,
+                               float* rec, int B, int K, int C, hipStream_t s) {
+    const long n = (long)B * K * (21 + 2 * C);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, num, scores, means, covs, counts, rec, B, K, C);
+    return hipGetLastError();
+}
+
 hipError_t launch_iou_matrix(const float* corners, int M, float* out, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(iou_matrix_kernel, dim3((M + 255) / 256, M), dim3(256), 0, s,

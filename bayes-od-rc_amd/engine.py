@@ -400,6 +400,21 @@ class Engine(object):
         return ms.value, fl.value
 
     # ------------------------------------------------------------------ measurement
+    def gather_detections(self, slot=-1, comm=None, world=1, rank=0, root=0, want_host=True):
+        """The path's one multi-GPU exchange through the C ABI (``bod_gather_detections``): packs this batch's detection
+        records on the device and gathers every rank's block on ``root`` with ONE RCCL gather.  ``comm``: an ``ncclComm_t``
+        as an integer / ``c_void_p`` (None: single process).  ``slot``: ticket of ``infer_async`` (-1 after ``infer``).
+        Returns [world, B, K, 1+4+16+2C] float32 on the root (None elsewhere); unpack with distributed.unpack_records."""
+        w = int(self.lib.bod_record_width(self.h))
+        out = None
+        dev = C.c_void_p(0)
+        if rank == root and want_host:
+            out = np.empty((world, self.B, self.K, w), np.float32)
+        self._chk(self.lib.bod_gather_detections(self.h, int(slot), C.c_void_p(int(comm) if comm else 0), int(world), int(rank), int(root),
+                                                 out.ctypes.data if out is not None else None,
+                                                 C.byref(dev) if rank == root else None))
+        return out
+
     def plan_info(self):
         """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops'} of the forward plan (bod_plan_info)."""
         info = (C.c_int32 * 8)()

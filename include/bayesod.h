@@ -329,6 +329,24 @@ bod_status bod_profile_select(bod_handle h, int32_t which);
 bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
                            double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
 
+/* ---- the path's ONE multi-GPU exchange for callers of the C ABI (no PyTorch in the loop) ----
+ * Images shard across processes (one per GPU); per step every rank contributes the detection records of its batch and `root`
+ * receives all of them.  A record row is W = bod_record_width() = 1 + 4 + 16 + 2C floats: [valid, mean (v,u,h,w), covariance
+ * row-major, score[C], counts[C]]; a rank's block is [batch][max_detections][W], rows beyond an image's detection count are zero.
+ *
+ * bod_gather_detections packs the records of `slot` (the ticket of bod_infer_async; pass -1 after a synchronous bod_infer) on the
+ * device and issues ONE RCCL gather -- ncclGather(send, recv, batch*K*W, ncclFloat32, root, comm, stream) -- on the handle's side
+ * stream, behind the slot's cluster-and-fuse kernels, so it overlaps the next batch's convolutions like bod_collect's copies do.
+ * `nccl_comm` is the caller's ncclComm_t (created with ncclCommInitRank on this handle's device; librccl.so is opened at run time,
+ * the library does not link it); `world` / `rank` are the communicator's size and this process' rank.  nccl_comm == NULL is the
+ * single-process form (world must be 1: the block is "gathered" by a device copy).
+ * On `root`, `gathered_host` (may be NULL) receives [world][batch][K][W] floats, in rank order, after the stream has been waited
+ * for; *gathered_device (may be NULL) is set to the device copy, valid until the next gather.  Other ranks pass NULL for both (their
+ * call returns once the send is enqueued and the slot's event recorded).  A pending slot is NOT released: bod_collect still may. */
+int32_t bod_record_width(bod_handle h);
+bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, int32_t world, int32_t rank, int32_t root,
+                                 float* gathered_host, float** gathered_device);
+
 /* What the handle's plan looks like (tests / bench report it; nothing on the hot path reads it).  info8[0] = 1 when the MC
  * statistics are reduced inside the last tower layers' tiles (no [B,N,A,.] tensors on the bod_infer path), [1] = 1 when the 1x1
  * head output convs are fused into the last tower layers' epilogues, [2] = 1 when the per-sample tower layers run on the

@@ -131,4 +131,7 @@ bod_status bod_profile_begin(bod_handle h);
 bod_status bod_profile_select(bod_handle h, int32_t which);
 bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_conv_launches,
                            double* head_conv_flops, double* posterior_ms, int64_t* posterior_launches);
+int32_t bod_record_width(bod_handle h);
+bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, int32_t world, int32_t rank, int32_t root,
+                                 float* gathered_host, float** gathered_device);
 bod_status bod_plan_info(bod_handle h, int32_t* info8);

@@ -514,6 +514,12 @@ def test_bench_two_ranks_on_one_gpu():
     rec = json.loads(line[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert "cpu_baseline" not in rec
+    # one entry per rank, in rank order: each rank's own rate, and what rank 0 read out of each rank's gathered block (the two
+    # ranks run DIFFERENT frames -- shards [0,4) and [4,8) of the clip -- so their detection counts are two numbers, both > 0)
+    per_rank, gathered = rec["config"]["per_rank_images_per_sec"], rec["config"]["gathered_detections_per_rank"]
+    assert len(per_rank) == 2 and all(v > 0 for v in per_rank)
+    assert gathered is not None and len(gathered) == 2 and all(0 < g <= 4 * 100 for g in gathered)
+    assert rec["value"] <= sum(per_rank) * 1.001            # max-over-ranks time: the aggregate never exceeds the sum of the ranks' own rates
 
 
 def test_bench_collectives_run_under_rccl_with_one_rank():
@@ -713,3 +719,63 @@ def test_large_batch_equals_small_batch():
     env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_CONV_SPLITK="0")
     r = subprocess.run([sys.executable, "-c", _LARGE_BATCH_SCRIPT, root], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _tiny_pipeline_engine(batch=3, n=4, hw=(128, 128)):
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+    eng.load_weights(synthetic.make_weights(cls_fg_bias=-1.0))
+    eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3)))
+    return eng, synthetic.make_frames(batch, hw[0], hw[1], seed=17)
+
+
+def test_gather_detections_through_the_c_abi_single_process():
+    """bod_gather_detections without a communicator (world 1): the device-side pack equals distributed.pack_records of the
+    same batch, after a synchronous infer (slot -1) and for a pipelined slot (whose bod_collect still works afterwards)."""
+    import torch
+    from bayes_od_rc_amd import distributed as bd
+    eng, frames = _tiny_pipeline_engine()
+    eng.infer(frames, seed=5, first_image_id=0)
+    want = eng.get_detections_batch()
+    ref = bd.pack_records(*[torch.from_numpy(want[k]) for k in ("num", "scores", "means", "covs", "counts")]).numpy()
+    assert want["num"].sum() > 0
+    got = eng.gather_detections(slot=-1)
+    assert got.shape == (1,) + ref.shape and np.array_equal(got[0], ref)
+    slot = eng.infer_async(frames, seed=5, first_image_id=0)
+    got2 = eng.gather_detections(slot=slot)
+    assert np.array_equal(got2[0], ref)
+    host = eng.collect(slot)
+    assert np.array_equal(host["num"], want["num"]) and np.array_equal(host["means"], want["means"])
+    with pytest.raises(Exception):
+        eng.gather_detections(slot=slot)              # released by collect: no pending batch
+    with pytest.raises(Exception):
+        eng.gather_detections(slot=-1, world=2, rank=0)   # two ranks need a communicator
+    eng.close()
+
+
+def test_gather_detections_issues_a_real_rccl_gather():
+    """The same entry point with a REAL ncclComm_t: a one-rank RCCL communicator created through librccl's C API (ctypes; no
+    torch.distributed anywhere), which is all a one-GPU box can hold.  ncclGather runs on the handle's side stream; the root's
+    block equals the single-process pack."""
+    import ctypes as C
+    rccl = C.CDLL("librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    eng, frames = _tiny_pipeline_engine(batch=2)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        eng.infer(frames, seed=9, first_image_id=3)
+        ref = eng.gather_detections(slot=-1)
+        got = eng.gather_detections(slot=-1, comm=comm.value, world=1, rank=0, root=0)
+        assert got.shape == ref.shape and np.array_equal(got, ref) and got[0, :, :, 0].sum() > 0
+    finally:
+        eng.close()
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -168,6 +168,143 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ wsrc
     out[blockIdx.x * 512 + tid] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The structural alternative (DESIGN.md section 10.1b, round-3 review item 1): FOUR waves per CU, one per SIMD, wave tile 128 x 128 =
+// 8 x 8 fragments of 16 x 16 (256 accumulator registers -- in AGPRs with F_AGPR -- of the 512 a lone wave may use).  Same CU tile
+// (256 couts x 256 pixels), same LDS image, same K-tile: per wave 128 MFMAs, 32 ds_read_b128 (16 A + 16 B: two thirds of the fragment
+// reads per MFMA of the 8-wave form), 12 LDS-DMA pieces, 14 Philox rounds.  With a single wave on the SIMD nothing else covers an issue
+// gap, so the fillers are placed by hand, one small group behind each MFMA (sched_barrier between groups): a 16 x 16 x 32 MFMA occupies
+// the pipe for 16 cycles = 4 issue slots, i.e. up to three other instructions per MFMA are free IF they are spread.
+// F_SPREAD = 0 puts a step's fillers in one clump behind its eight MFMAs instead (what a compiler-scheduled port would do).
+enum { G_SPREAD = 1 << 16 };
+template <int F>
+__global__ __launch_bounds__(256) void loop_kernel_4w(const char* __restrict__ wsrc, const char* __restrict__ xsrc, float* __restrict__ out, int ktiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp = wave & 1, l15 = lane & 15, q4 = lane >> 4;
+    for (int i = tid; i < LDS_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(wsrc)[i];
+    __syncthreads();
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 Ar[3], Bc[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ar[i] = reinterpret_cast<const bf16x8*>(smem)[i * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Bc[j] = reinterpret_cast<const bf16x8*>(smem)[(4 + j) * 64 + lane];
+    const uint32_t wlane = (uint32_t)(((tid >> 3) * 2304 + (tid & 7) * 8) * 2);      // 32 weight rows per piece (256 threads)
+    const uint32_t xlane = (uint32_t)(tid * 16);
+    uint32_t ph0 = tid * 2654435761u, ph1 = tid ^ 0x9E3779B9u, ph2 = 12345u, ph3 = tid + 77u;
+    unsigned long long p0 = 0, p1 = 0;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    auto a_addr = [&](int kt_, int st) {
+        const int wa = (kt_ & 1) * WST + (wc * 128 + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4);
+        return smem + ((wa ^ ((st >> 3) << 6)) + (st & 7) * 16 * ROWB);
+    };
+    auto b_addr = [&](int kt_, int j, int ks) {
+        const int kxc = kt_ % 3, xb = (kt_ / 3) & 1;
+        const int r = wp * 128 + j * 16 + l15 + kxc;
+        return smem + ((2 * WST + xb * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4)) ^ (ks << 6));
+    };
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int stage = kt & 1, kxc = kt % 3, xb = (kt / 3) & 1;
+        const char* wg = wsrc + (size_t)((kt % 36) * 64) * 2;
+        const char* xg = xsrc + (size_t)(blockIdx.x % 64) * 65536 + (size_t)(kt % 12) * 40960;
+        const int wdst = (stage ^ 1) * WST, xdst = 2 * WST + (xb ^ 1) * XBUF;
+        if (F & F_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (F & F_BAR) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        if (F & F_LDS) {
+            if (kxc == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 0));
+            }
+            Ar[0] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 0));
+            Ar[1] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int fc = st & 7;
+            auto filler = [&](int part) {          // the step's non-MFMA work in four parts
+                if (part == 0) {
+                    if ((F & F_LDS) && st + 2 < 16) Ar[(st + 2) % 3] = *reinterpret_cast<const bf16x8*>(a_addr(kt, st + 2));
+                } else if (part == 1) {
+                    if ((F & F_DMA) && st < 12) {
+                        const char* p = st < 8 ? wg + (size_t)st * 32 * 2304 * 2 : xg + (size_t)(st - 8) * 4096;
+                        asm volatile("" : "+s"(p));
+                        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (st < 8 ? wdst + st * 4096 : xdst + (st - 8) * 4096) + wave * 1024), 16, st < 8 ? wlane : xlane, 0, 0, 0);
+                    }
+                } else if (part == 2) {
+                    if ((F & F_VALU) && st < 14) { p0 = (unsigned long long)ph0 * 0xD2511F53u; p1 = (unsigned long long)ph2 * 0xCD9E8D57u; }
+                } else {
+                    if ((F & F_VALU) && st < 14) {
+                        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ph1 ^ 0x12345u, n2 = (uint32_t)(p0 >> 32) ^ ph3 ^ 0x6789u;
+                        ph1 = (uint32_t)p1; ph3 = (uint32_t)p0; ph0 = n0; ph2 = n2;
+                    }
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mfma16<(F & F_AGPR) != 0>(acc[fc][j], Ar[st % 3], Bc[j]);
+                if ((F & F_LDS) && st == 7) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 1));
+                if ((F & F_LDS) && st == 15 && kxc < 2) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt + 1, j, 0));
+                if (F & G_SPREAD) {
+                    if (j == 0) filler(0); else if (j == 2) filler(1); else if (j == 4) filler(2); else if (j == 6) filler(3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!(F & G_SPREAD)) {
+                __builtin_amdgcn_sched_barrier(0);
+                filler(0); filler(1); filler(2); filler(3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (tid == 0) {
+        atomicAdd(&g_cycles[0], __builtin_amdgcn_s_memtime() - t0);
+        atomicAdd(&g_cycles[1], __builtin_amdgcn_s_memrealtime() - r0);
+    }
+    float s = (float)(ph0 ^ ph1 ^ ph2 ^ ph3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 v = acc[i][j];
+            if constexpr ((F & F_AGPR) != 0) asm volatile("" : "+v"(v));
+            s += v[0] + v[3];
+        }
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int F>
+static void run4(const char* name, const char* w, const char* x, float* o, int ktiles) {
+    auto kern = loop_kernel_4w<F>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double best = 1e30; unsigned long long c[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 4; ++rep) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_cycles), z, sizeof z);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(256), LDS_BYTES, 0, w, x, o, ktiles);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cycles), sizeof c);
+        if (rep > 0 && ms < best) { best = ms; memcpy(cb, c, sizeof c); }
+    }
+    const double cyc = (double)cb[0] / 256 / ktiles, ghz = (double)cb[0] / (double)cb[1] * 0.1;
+    const double tf = 256.0 * 4 * ktiles * 128 * 16384 / (best * 1e-3) / 1e12;
+    printf("[4 waves x 128x128 ] %-58s %7.3f us/K-tile  %6.0f cycles/K-tile  clock %.3f GHz  MFMA duty %.3f  %6.0f TFLOP/s\n", name, best * 1e3 / ktiles, cyc, ghz,
+           2048.0 / cyc, tf);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
 template <int F>
 static void run(const char* name, const char* w, const char* x, float* o, int ktiles) {
     auto kern = loop_kernel<F>;
@@ -223,5 +360,14 @@ int main() {
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_MIDBAR>("   the loop, barrier two steps early", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_DMA_BUF>("   the loop, buffer_load ... lds", w, x, o, ktiles);
     run<F_LDS | F_BAR | F_DMA | F_VALU | F_DMA_BUF | F_MIDBAR>("   the loop, buffer_load ... lds + barrier two steps early", w, x, o, ktiles);
+    // ---- round 3: four waves per CU, one per SIMD, 128 x 128 wave tiles (see loop_kernel_4w)
+    run4<F_BAR | F_AGPR>("MFMA + barrier, AGPR accumulators", w, x, o, ktiles);
+    run4<F_BAR>("MFMA + barrier, VGPR accumulators", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | G_SPREAD>("+ 32 ds_read_b128", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | F_DMA | G_SPREAD>("+ ds_read + 12 buffer_load ... lds pieces", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | F_VALU | G_SPREAD>("+ ds_read + 14 Philox rounds", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | F_DMA | F_VALU | G_SPREAD>("the loop (ds_read + DMA + Philox), fillers spread", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | F_DMA | F_VALU>("the loop, fillers in one clump per step", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_DMA | F_VALU | G_SPREAD>("the loop, fillers spread, VGPR accumulators", w, x, o, ktiles);
     return 0;
 }
