@@ -190,9 +190,10 @@ __global__ __launch_bounds__(256) void loop_kernel_4w(const char* __restrict__ w
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 Ar[3], Bc[8];
+    constexpr int RN = (F & F_MIDBAR) ? 4 : 3, BS = (F & F_MIDBAR) ? 14 : 0;
+    bf16x8 Ar[RN], Bc[8];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Ar[i] = reinterpret_cast<const bf16x8*>(smem)[i * 64 + lane];
+    for (int i = 0; i < RN; ++i) Ar[i] = reinterpret_cast<const bf16x8*>(smem)[i * 64 + lane];
 #pragma unroll
     for (int j = 0; j < 8; ++j) Bc[j] = reinterpret_cast<const bf16x8*>(smem)[(4 + j) * 64 + lane];
     const uint32_t wlane = (uint32_t)(((tid >> 3) * 2304 + (tid & 7) * 8) * 2);      // 32 weight rows per piece (256 threads)
@@ -210,34 +211,54 @@ __global__ __launch_bounds__(256) void loop_kernel_4w(const char* __restrict__ w
         const int r = wp * 128 + j * 16 + l15 + kxc;
         return smem + ((2 * WST + xb * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4)) ^ (ks << 6));
     };
+    if ((F & F_MIDBAR) && (F & F_LDS)) {          // the fragments K-tile 0 starts with (later K-tiles: fetched behind the previous one's barrier)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(0, j, 0));
+        Ar[0] = *reinterpret_cast<const bf16x8*>(a_addr(0, 0));
+        Ar[1] = *reinterpret_cast<const bf16x8*>(a_addr(0, 1));
+    }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int stage = kt & 1, kxc = kt % 3, xb = (kt / 3) & 1;
         const char* wg = wsrc + (size_t)((kt % 36) * 64) * 2;
         const char* xg = xsrc + (size_t)(blockIdx.x % 64) * 65536 + (size_t)(kt % 12) * 40960;
         const int wdst = (stage ^ 1) * WST, xdst = 2 * WST + (xb ^ 1) * XBUF;
-        if (F & F_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (F & F_BAR) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-        if (F & F_LDS) {
-            if (kxc == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 0));
-            }
-            Ar[0] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 0));
-            Ar[1] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 1));
-        }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             const int fc = st & 7;
+            if (st == BS) {
+                if (F & F_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((F & F_MIDBAR) && (F & F_LDS)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (F & F_BAR) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+                if (!(F & F_MIDBAR) && (F & F_LDS)) {
+                    if (kxc == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 0));
+                    }
+                    Ar[0] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 0));
+                    Ar[1] = *reinterpret_cast<const bf16x8*>(a_addr(kt, 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the DMA pieces of K-tile kt+1 go out in the 12 steps BEHIND this K-tile's barrier: steps BS .. BS+11 (mod 16), i.e. with
+            // the mid-tile barrier steps 14, 15 of this K-tile and 0..9 of the next
+            const int dslot = (st - BS + 16) % 16;
             auto filler = [&](int part) {          // the step's non-MFMA work in four parts
                 if (part == 0) {
-                    if ((F & F_LDS) && st + 2 < 16) Ar[(st + 2) % 3] = *reinterpret_cast<const bf16x8*>(a_addr(kt, st + 2));
+                    if (F & F_LDS) {
+                        if (st + 2 < 16) Ar[(st + 2) % RN] = *reinterpret_cast<const bf16x8*>(a_addr(kt, st + 2));
+                        else if (F & F_MIDBAR) Ar[(st + 2) % RN] = *reinterpret_cast<const bf16x8*>(a_addr(kt + 1, st + 2 - 16));
+                    }
                 } else if (part == 1) {
-                    if ((F & F_DMA) && st < 12) {
-                        const char* p = st < 8 ? wg + (size_t)st * 32 * 2304 * 2 : xg + (size_t)(st - 8) * 4096;
+                    if ((F & F_DMA) && dslot < 12) {
+                        // (mid-tile barrier: steps 0..9 issue the pieces 2..11 of THIS K-tile's successor, whose first two went out in steps 14, 15 of the previous one)
+                        const bool late = (F & F_MIDBAR) && st < BS;
+                        const char* wgn = late ? wg : wsrc + (size_t)(((kt + 1) % 36) * 64) * 2;
+                        const char* xgn = late ? xg : xsrc + (size_t)(blockIdx.x % 64) * 65536 + (size_t)((kt + 1) % 12) * 40960;
+                        const int wd = late ? wdst : ((F & F_MIDBAR) ? (stage) * WST : wdst), xd = late ? xdst : ((F & F_MIDBAR) ? 2 * WST + (((kt + 1) / 3) & 1 ^ 1) * XBUF : xdst);
+                        const char* p = dslot < 8 ? wgn + (size_t)dslot * 32 * 2304 * 2 : xgn + (size_t)(dslot - 8) * 4096;
                         asm volatile("" : "+s"(p));
                         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (st < 8 ? wdst + st * 4096 : xdst + (st - 8) * 4096) + wave * 1024), 16, st < 8 ? wlane : xlane, 0, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (dslot < 8 ? wd + dslot * 4096 : xd + (dslot - 8) * 4096) + wave * 1024), 16, dslot < 8 ? wlane : xlane, 0, 0, 0);
                     }
                 } else if (part == 2) {
                     if ((F & F_VALU) && st < 14) { p0 = (unsigned long long)ph0 * 0xD2511F53u; p1 = (unsigned long long)ph2 * 0xCD9E8D57u; }
@@ -250,9 +271,9 @@ __global__ __launch_bounds__(256) void loop_kernel_4w(const char* __restrict__ w
             };
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                mfma16<(F & F_AGPR) != 0>(acc[fc][j], Ar[st % 3], Bc[j]);
+                mfma16<(F & F_AGPR) != 0>(acc[fc][j], Ar[st % RN], Bc[j]);
                 if ((F & F_LDS) && st == 7) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt, j, 1));
-                if ((F & F_LDS) && st == 15 && kxc < 2) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt + 1, j, 0));
+                if ((F & F_LDS) && st == 15 && (kxc < 2 || (F & F_MIDBAR))) Bc[j] = *reinterpret_cast<const bf16x8*>(b_addr(kt + 1, j, 0));
                 if (F & G_SPREAD) {
                     if (j == 0) filler(0); else if (j == 2) filler(1); else if (j == 4) filler(2); else if (j == 6) filler(3);
                     __builtin_amdgcn_sched_barrier(0);
@@ -369,5 +390,7 @@ int main() {
     run4<F_LDS | F_BAR | F_AGPR | F_DMA | F_VALU | G_SPREAD>("the loop (ds_read + DMA + Philox), fillers spread", w, x, o, ktiles);
     run4<F_LDS | F_BAR | F_AGPR | F_DMA | F_VALU>("the loop, fillers in one clump per step", w, x, o, ktiles);
     run4<F_LDS | F_BAR | F_DMA | F_VALU | G_SPREAD>("the loop, fillers spread, VGPR accumulators", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | G_SPREAD | F_MIDBAR>("ds_read only, barrier two steps before the K-tile's end", w, x, o, ktiles);
+    run4<F_LDS | F_BAR | F_AGPR | F_DMA | F_VALU | G_SPREAD | F_MIDBAR>("the loop, fillers spread, barrier two steps early", w, x, o, ktiles);
     return 0;
 }
