@@ -585,7 +585,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0 (k-step ks: ^ (ks << 5))
         const int a_row = (wc * WTC + frow) * ROWB + a_c0;
         const int NG = KT / 3;
-        constexpr bool PH_BUILD = !SPLIT && FP == 2 && (ABL == 0 || ABL == 90 || ABL == 30 || ABL == 31 || ABL == 1 || ABL == 2);
+        constexpr bool PH_BUILD = !SPLIT && FP == 2 && (ABL == 0 || ABL == 6 || ABL == 90 || ABL == 30 || ABL == 31 || ABL == 1 || ABL == 2);
         const bool ph_on = PH_BUILD && (a.flags & CONV_DROPOUT) && !(a.flags & CONV_OUT_F32) && a.fan_count <= 1 && NG >= 8 && bc0 == 0 &&
                            a.drop_threshold >= 1 && a.variant != 83;            // (variant 83: decisions drawn in the epilogue, A/B)
         ph_inloop = ph_on;
@@ -608,10 +608,168 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 b |= (((w[k] & 0xFFFFu) >= ph_thr) ? 1u : 0u) << (2 * k) | (((w[k] >> 16) >= ph_thr) ? 1u : 0u) << (2 * k + 1);
             return b;
         };
-        // One (chunk, ky) group = three K-tiles (kx = 0,1,2, unrolled so the staged piece indices are compile-time).
-        // The next tile's LDS-DMA pieces are NOT issued in a burst after the barrier (both waves of a SIMD would
-        // sit in that burst together with the matrix pipe idle) but one at a time in MFMA shadows: W pieces after
-        // MFMAs 4, 8, 12, 16 and the (at most two) activation pieces after MFMAs 20 and 24 of the 32.
+        // ------------------------------------------------------------------------------------------------------------------
+        // ABL == 6: the tower loop with the K-tile barrier TWO FRAGMENT STEPS BEFORE THE K-TILE'S END (round 3).  A K-tile is 16
+        // steps (k-step ks = step >> 3, cout fragment fc = step & 7) of four MFMAs.  The barrier in front of step 14 comes after
+        // every read of this K-tile's weight stage has returned (the A fragments of steps 14, 15 are fetched two steps ahead), so
+        // behind it the NEXT K-tile's first fragments are read -- A(0), A(1), and the B set behind step 15's MFMAs -- while
+        // steps 14 and 15 still multiply: the LDS round trip and the barrier skew that opened every K-tile with the matrix pipe
+        // idle (tests/tools/loop_anatomy.hip: 3111 -> 2714 cycles per K-tile) disappear behind eight MFMAs.  The compiled forms of
+        // round 2 lost that gain to `s_waitcnt lgkmcnt(0)` instructions the compiler put behind the prefetch (it cannot count
+        // loads it mixes with hand-written waits).  Here EVERY LDS read of the loop is inline asm and every wait is written out
+        // with its exact count -- LDS returns in order, so `lgkmcnt(n)` in front of an MFMA leaves exactly the n younger reads in
+        // flight -- the compiler sees no LDS access at all and adds no wait of its own.  bayes_od_rc_amd/kernel_guard.py checks
+        // the disassembly: no instruction may touch a fragment register between its ds_read and the wait that covers it.
+        // DMA schedule: a stage is free from the barrier in front of step 14 of the K-tile that read it, so the weight pieces of
+        // K-tile t+1 go out behind steps 15 (of t-1), 1, 3, 5 (of t) and are waited for in front of step 14 of t; the next
+        // group's extended rows behind steps 7, 9, 11 of the group's first K-tile and 7, 9 of its second.
+        // ------------------------------------------------------------------------------------------------------------------
+        constexpr bool MB = M16 && ABL == 6;
+        if constexpr (MB) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            auto lgkm = [](int n) {
+                switch (n) {
+                    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+                }
+            };
+            // A fragment fc of the K-tile whose stage / k-step is folded into `addr`: immediate offset fc * 16 rows
+            auto rdA = [](bf16x8& d, uint32_t addr, int fc) {
+                switch (fc) {
+                    case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); break;
+                    case 1: asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(d) : "v"(addr)); break;
+                    case 2: asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(d) : "v"(addr)); break;
+                    case 3: asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(d) : "v"(addr)); break;
+                    case 4: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(d) : "v"(addr)); break;
+                    case 5: asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(d) : "v"(addr)); break;
+                    case 6: asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(d) : "v"(addr)); break;
+                    default: asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(d) : "v"(addr)); break;
+                }
+            };
+            auto rdB = [](bf16x8& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+            static_assert(ROWB * 16 == 2048 && WST == 32768, "immediate offsets of rdA");
+            const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+            // A address of fragment 0, k-step 0 in the stage of the CURRENT K-tile (k-step 1: ^ 64; other stage: ^ WST)
+            uint32_t a_cur = lds0 + (uint32_t)((wc * WTC + l15) * ROWB + ((q4 ^ ((l15 >> 1) & 7)) << 4));
+            auto b_addr = [&](int xbuf, int j, int kxc_) -> uint32_t {
+                const int r = xrow16[j] + kxc_;
+                return lds0 + (uint32_t)(2 * WST + xbuf * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4));
+            };
+            bf16x8 Ar[4], Bc[4];
+            // weight offsets of the K-tiles one and two ahead: K-tile t is tap t % 9 of channel chunk t / 9
+            int wo1 = a.cin * 2, tap1 = 1, wo2 = 2 * a.cin * 2, tap2 = 2;
+            auto w_advance = [&](int& wo, int& tap) { if (++tap == 9) { tap = 0; wo += BK * 2 - 8 * a.cin * 2; } else wo += a.cin * 2; };
+            auto dma_w = [&](int piece, int wo, int stage_) {
+                int so_ = wo + piece * wrs;
+                asm volatile("" : "+s"(so_));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + stage_ * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, so_, 0, 0);
+            };
+            // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); add weight piece 0 of K-tile 1, then
+            // wait for everything but that piece
+            if (KT > 1) dma_w(0, wo1, 1);
+            if (KT > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            rdA(Ar[0], a_cur, 0); rdA(Ar[1], a_cur, 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rdB(Bc[j], b_addr(0, j, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < NG; ++g) {
+                const bool xnext = g + 1 < NG;
+                const bool next_row = ky + 1 < 3;
+                const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
+                const bool ph_act = ph_on && g < 8;
+                auto ph_slot = [&](int sidx) {
+                    if (!PH_BUILD || !ph_act || sidx > 19) return;
+                    if (sidx == 0 || sidx == 9) {
+                        if (sidx == 9) { philox_rounds(ph, 1); ph_byte_a = ph_compress(); }
+                        long long rr;
+                        const uint32_t ra = (uint32_t)(uintptr_t)LDS_PTR(&s_rng[wp * WTP + (g >> 1) * 16 + l15]);
+                        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(ra) : "memory");
+                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);
+                        ph.c0 = (uint32_t)rr;
+                        const uint32_t ry = (uint32_t)((unsigned long long)rr >> 32);
+                        ph.c2 = (a.sample_base + (ry & 0xFFFFu)) | ((uint32_t)G.layer_id << 16);
+                        ph.c3 = ph_img + (ry >> 16);
+                        ph.k0 = ph_k0; ph.k1 = ph_k1;
+                        if (sidx == 0) philox_rounds(ph, 1);
+                        return;
+                    }
+                    philox_rounds(ph, 1);
+                    if (sidx == 19) {
+                        const uint32_t n16 = (ph_byte_a << 8) | ph_compress();
+                        ph_bits[3] = (ph_bits[3] << 16) | (ph_bits[2] >> 16);
+                        ph_bits[2] = (ph_bits[2] << 16) | (ph_bits[1] >> 16);
+                        ph_bits[1] = (ph_bits[1] << 16) | (ph_bits[0] >> 16);
+                        ph_bits[0] = (ph_bits[0] << 16) | n16;
+                    }
+                };
+#pragma unroll
+                for (int kxc = 0; kxc < 3; ++kxc) {
+                    const int kt = g * 3 + kxc;
+                    const bool w1 = kt + 1 < KT, w2 = kt + 2 < KT;
+                    // B fragments: k-step 1 of this K-tile; k-step 0 of the next (same rows one further, or the next group's rows)
+                    uint32_t xb1[4], xbn[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        xb1[j] = b_addr(g & 1, j, kxc) ^ 64u;
+                        xbn[j] = kxc < 2 ? b_addr(g & 1, j, kxc + 1) : b_addr((g + 1) & 1, j, 0);
+                    }
+                    const uint32_t a_k1 = a_cur ^ 64u, a_nxt = a_cur ^ (uint32_t)WST;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int fc = st & 7;
+                        if (st == 14) {
+                            // the next K-tile's weights (and, behind a group's last K-tile, the next group's rows) have landed; my reads of
+                            // this K-tile's stage have returned
+                            if (xnext && kxc == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                            else if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            lgkm(0);
+                            __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+                        }
+                        // A fragment two steps ahead (ring of four: 16 % 4 == 0, the slots repeat per K-tile)
+                        if (st + 2 < 16) rdA(Ar[(st + 2) & 3], (st + 2) < 8 ? a_cur : a_k1, (st + 2) & 7);
+                        else rdA(Ar[(st + 2) & 3], a_nxt, st + 2 - 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // in flight behind what this MFMA needs: the A fragments of steps st+1 (only if issued AFTER the operand) and st+2,
+                            // and in the first step of a k-step the B fragments j+1.. (issued behind A(st+1), in front of A(st+2))
+                            if (st == 0 || st == 8) lgkm(4 - j);
+                            else if (j == 0) lgkm(2);
+                            mfma16_inplace(acc4[fc][j], Ar[st & 3], Bc[j]);
+                            if (st == 7) rdB(Bc[j], xb1[j]);
+                            if (st == 15) rdB(Bc[j], xbn[j]);
+                        }
+                        if (st & 1) {                        // 8 slots per K-tile, behind steps 1, 3, .. 15
+                            const int slot = st >> 1;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (slot < 3) { if (w1) dma_w(slot + 1, wo1, (kt + 1) & 1); }
+                            else if (slot == 7) { if (w2) dma_w(0, wo2, kt & 1); }
+                            else if ((kxc == 0 && slot < 6) || (kxc == 1 && slot < 5)) {
+                                const int I = kxc == 0 ? slot - 3 : slot;          // pieces 0..2 in the group's first K-tile, 3..4 in its second
+                                if (xnext) {
+                                    xo[I] += next_row ? (uint32_t)xp[I] : (uint32_t)(BK * 2 - 2 * xp[I]);
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(smem + xdst + (I * THREADS + wave * 64) * 16), 16, (int)xo[I], 0, 0, 0);
+                                }
+                            }
+                            if (slot < 7) ph_slot(kxc * 7 + slot);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    a_cur = a_nxt;
+                    w_advance(wo1, tap1); w_advance(wo2, tap2);
+                }
+                if (++ky == 3) { ky = 0; ++cc; }
+            }
+            // the reads issued for a K-tile that does not exist: their registers stay allocated until they have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ar[0]), "+v"(Ar[1]), "+v"(Ar[2]), "+v"(Ar[3]), "+v"(Bc[0]), "+v"(Bc[1]), "+v"(Bc[2]), "+v"(Bc[3]) :: "memory");
+#endif
+        } else
         for (int g = 0; g < NG; ++g) {
             const bool xnext = g + 1 < NG;
             const bool next_row = ky + 1 < 3;
@@ -1277,12 +1435,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     // keeps the kernel at the 256-register budget without a spill
     constexpr bool CAN_RES = !XR;
     int2 rng[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) rng[j] = s_rng[wp * WTP + j * 32 + frow];    // rng_p, rng_zs
+    // Residual (bottleneck shortcuts, FPN merges): the tile's residual pixels come in by LDS-DMA -- whole 16-byte pieces of the
+    // NHWC rows, every lane of a wave on consecutive pieces (two 512-byte rows per instruction at 256 channels) -- straight into
+    // the [pixel][cout] tile image the outputs will overwrite: piece (pixel, physical chunk pc) holds the row's logical chunk
+    // pc ^ pixel, like the output tile, so a lane reads its four residual channels from the position it later writes its result
+    // to.  (The first form read them from global memory in the accumulator layout: 8 bytes per lane, 32 rows per instruction --
+    // eight requests per 128-byte line; the memory-bound 1x1 layers of res2 / res3 spent their epilogue in the texture path.)
+    const bool res_lds = CAN_RES && G.res != nullptr && ABL == 0 && a.variant != 82;      // (variant 82: the register form, A/B)
+    if (CAN_RES && res_lds) {
+        const char* rbase = reinterpret_cast<const char*>(G.res) + (size_t)bc0 * 2;
+#pragma unroll
+        for (int it = 0; it < BP * CPR / THREADS; ++it) {
+            const int q = it * THREADS + tid;
+            const int pixl = q / CPR, pc = q % CPR;
+            const int cp = (pc ^ pixl) & (CPR - 1);
+            const char* src = rbase + ((size_t)s_res[pixl] * a.res_cstride + cp * 8) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + (it * THREADS + wave * 64) * 16), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     int res_off[FP];
 #pragma unroll
-    for (int j = 0; j < FP; ++j) {
-        rng[j] = s_rng[wp * WTP + j * 32 + frow];                             // rng_p, rng_zs
-        res_off[j] = CAN_RES ? s_res[wp * WTP + j * 32 + frow] : 0;
-    }
+    for (int j = 0; j < FP; ++j) res_off[j] = (CAN_RES && !res_lds) ? s_res[wp * WTP + j * 32 + frow] : 0;
     // phase A: finish the arithmetic and pack to bf16 (halves the live registers before the RNG):
     // rounding(x*scale) then zeroing == zeroing then rounding, so the mask is applied on packed words
     uint2 pk16[FC16][FP16];                           // M16: (cout fragment, pixel fragment) -> the lane's 4 packed channels
@@ -1310,7 +1487,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
                               __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
                 if (CAN_RES && G.res) {
-                    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)res_off[j] * a.res_cstride + co);
+                    uint2 r;
+                    if (res_lds) {
+                        const int pixl = wp * WTP + j * 32 + frow;
+                        r = *reinterpret_cast<const uint2*>(smem + pixl * (BC * 2) + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2);
+                    } else {
+                        r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G.res) + (size_t)res_off[j] * a.res_cstride + co);
+                    }
                     v[0] += bf16_to_f32(r.x & 0xFFFFu) * epi_scale; v[1] += bf16_to_f32(r.x >> 16) * epi_scale;
                     v[2] += bf16_to_f32(r.y & 0xFFFFu) * epi_scale; v[3] += bf16_to_f32(r.y >> 16) * epi_scale;
                 }
@@ -1785,6 +1968,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a_local = a_in;
     // a threshold of 0 keeps every element (rate < 2^-16): the packed keep-mask needs threshold >= 1, so run without dropout
     if ((a_local.flags & CONV_DROPOUT) && a_local.drop_threshold == 0) a_local.flags &= ~CONV_DROPOUT;
+    // BOD_RES_REGISTER=1: residuals read from global memory in the accumulator layout instead of through the LDS tile (A/B aid)
+    static const bool res_register = getenv("BOD_RES_REGISTER") && atoi(getenv("BOD_RES_REGISTER")) == 1;
+    if (res_register && a_local.variant == 0 && !a_local.xreuse && !a_local.split && a_local.ksplit <= 1) a_local.variant = 82;
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
@@ -1840,10 +2026,15 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // it runs the loop and the register-resident fan-out epilogue), so that a kernel trace lists the per-sample tower
         // launches -- the roofline kernel of bench.py -- and the fan-out launch separately
         if (a.fan_count > 1) return launch_cfg<256, 256, 2, 4, 5, true>(a, s);
+        // BOD_TOWER_MIDBAR=1: the per-sample tower launches on the loop with the K-tile barrier two fragment steps before the
+        // K-tile's end and hand-counted LDS waits (ABL = 6; bit-identical results: same products in the same order)
+        static const bool midbar = getenv("BOD_TOWER_MIDBAR") && atoi(getenv("BOD_TOWER_MIDBAR")) == 1;
+        if (midbar && a.variant == 0) return launch_cfg<256, 256, 2, 4, 6, true>(a, s);
         return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
     }
     switch (variant) {          // ablation builds of the generic loop (tests/tools/bench_head_conv.py)
         case 0: break;
+        case 82: break;                                             // production build, residual read in the accumulator layout (A/B)
         case 1: return launch_cfg<256, 256, 2, 4, 1>(a, s);        // no epilogue
         case 2: return launch_cfg<256, 256, 2, 4, 2>(a, s);        // no staging after tile 0
         case 4: return launch_cfg<256, 256, 2, 4, 4>(a, s);        // cheap hash instead of Philox

@@ -29,8 +29,10 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb1EE",     # bf16x3 on the row-reuse loop (fused 1x1 + MC aggregation)
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi6ELb1ELb0EE",     # head towers, K-tile barrier two steps before the K-tile's end, asm LDS reads
 ]
-INLINE_ASM_MFMA = PRODUCTION[:2]                               # the kernels on the 16x16x32 inline-asm loop
+INLINE_ASM_MFMA = PRODUCTION[:2] + PRODUCTION[-1:]             # the kernels on the 16x16x32 inline-asm loop
+INLINE_ASM_LDS = PRODUCTION[-1:]                               # ... whose fragment reads and lgkmcnt waits are hand-written too
 
 
 class GuardError(RuntimeError):
@@ -82,8 +84,8 @@ def check_no_spills(meta, wanted=PRODUCTION):
                 raise GuardError("%s spills %d VGPRs (%d B scratch/lane)" % (n, f.get("vgpr_spill_count", 0), f.get("private_segment_fixed_size", 0)))
 
 
-def disassemble(code_object):
-    """{symbol: [instruction lines]} (comments and encodings stripped)."""
+def disassemble(code_object, with_addr=False):
+    """{symbol: [instruction lines]} (comments and encodings stripped); with_addr: [(byte address, instruction)]."""
     text = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", code_object], capture_output=True, text=True, check=True).stdout
     funcs, cur = {}, None
     for line in text.split("\n"):
@@ -93,9 +95,14 @@ def disassemble(code_object):
             continue
         if cur is None:
             continue
-        ins = line.split("//")[0].strip()
+        parts = line.split("//")
+        ins = parts[0].strip()
         if ins:
-            cur.append(ins)
+            if with_addr:
+                am = re.match(r"\s*([0-9A-Fa-f]+):", parts[1]) if len(parts) > 1 else None
+                cur.append((int(am.group(1), 16) if am else -1, ins))
+            else:
+                cur.append(ins)
     return funcs
 
 
@@ -151,6 +158,90 @@ def check_inline_asm_mfma(body, want, window=16, min_mfma=192):
     return len(mf)
 
 
+def check_asm_lds_reads(body, want, min_reads=60):
+    """The mid-tile-barrier tower loop (conv_igemm.hip, ABL = 6) issues every fragment read as inline asm and places every
+    `s_waitcnt lgkmcnt(n)` by hand; the compiler believes a fragment register is written the moment its ds_read issues.  Walk the
+    loop -- every forward conditional branch around a block WITHOUT fragment reads or MFMAs taken (LDS-DMA issues, Philox rounds:
+    the path with the fewest waits) -- with the in-order LDS return queue and fail if any instruction reads or writes
+    a fragment register while its ds_read may still be in flight (an MFMA placed in front of the wait that covers its operand, a
+    compiler copy of a register across the loop's back edge, a register reused for something else ...).
+    `body`: [(address, instruction)] of one kernel.  Returns the number of fragment reads checked."""
+    addr_index = {a: i for i, (a, _) in enumerate(body)}
+    mf = [i for i, (_, l) in enumerate(body) if l.startswith(MFMA)]
+    if not mf:
+        raise GuardError("%s: no %s" % (want, MFMA))
+    # start at the first fragment read in front of the first MFMA's prologue (the reads issued behind the prologue barrier)
+    start = mf[0]
+    while start > 0 and not body[start - 1][1].startswith("s_barrier"):
+        start -= 1
+    queue, checked, i, steps = [], 0, start, 0
+    end = mf[-1] + 1
+    seen_back_edge = False
+    while i < len(body) and steps < 200000:
+        steps += 1
+        a, l = body[i]
+        op = l.split()[0]
+        if op == "ds_read_b128":
+            dst = _regs(re.match(r"ds_read_b128 (v\[\d+:\d+\])", l).group(1))
+            addr_regs = set().union(*[_regs(t) for t in re.findall(r"\bv\d+\b", l)]) if re.findall(r"\bv\d+\b", l) else set()
+            busy = set().union(*[q for q in queue if q]) if queue else set()
+            if (dst | addr_regs) & busy:
+                raise GuardError("%s: `%s` touches a fragment register still in flight" % (want, l))
+            queue.append(dst)
+            checked += 1
+        elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
+            queue.append(set())                      # another LGKM operation: counted, no fragment register
+        elif op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", l)
+            if m:
+                n = int(m.group(1))
+                # SMEM returns out of order: an entry without registers may retire early, which only makes the count conservative
+                while len(queue) > n:
+                    queue.pop(0)
+        elif op.startswith("s_cbranch") or op == "s_branch":
+            off = int(l.split()[1])
+            if off >= 32768:
+                off -= 65536
+            target = a + 4 + 4 * off
+            if off < 0:                              # the loop's back edge: one more trip with the queue as it is, then stop
+                if seen_back_edge:
+                    i += 1                           # second visit: leave the loop, drain behind it
+                    continue
+                seen_back_edge = True
+                if target not in addr_index:
+                    raise GuardError("%s: branch target %x not found" % (want, target))
+                i = addr_index[target]
+                continue
+            if target not in addr_index:
+                raise GuardError("%s: branch target %x not found" % (want, target))
+            skipped = [sk for _, sk in body[i + 1:addr_index[target]]]
+
+            def backward(sk):
+                return (sk.startswith("s_cbranch") or sk.startswith("s_branch ")) and int(sk.split()[1]) >= 32768
+            if not seen_back_edge and any(backward(sk) for sk in skipped):
+                i += 1                               # the loop's exit test in front of its back edge: stay in the loop once more
+                continue
+            if any(sk.startswith(MFMA) or sk.startswith("ds_read_b128") for sk in skipped):
+                i += 1                               # a branch around the loop itself (trip-count check): fall through
+                continue
+            i = addr_index[target]                   # a conditional block of DMA issues / Philox rounds: the path without it
+            continue
+        else:
+            busy = set().union(*[q for q in queue if q]) if queue else set()
+            if busy:
+                toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
+                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                if touched & busy:
+                    raise GuardError("%s: `%s` touches a fragment register whose ds_read may still be in flight (%d reads outstanding)"
+                                     % (want, l, len([q for q in queue if q])))
+        if i >= end and seen_back_edge and not queue:
+            break
+        i += 1
+    if checked < min_reads:
+        raise GuardError("%s: only %d fragment reads walked" % (want, checked))
+    return checked
+
+
 def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
     """All guards on a built conv_igemm.o.  Raises GuardError; returns {kernel: vgpr_count} of the production kernels."""
     with tempfile.TemporaryDirectory() as wd:
@@ -164,4 +255,9 @@ def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
                 raise GuardError("kernel %s not found in the disassembly" % want)
             for n in names:
                 check_inline_asm_mfma(funcs[n], want)
+        if any(w in INLINE_ASM_LDS for w in asm_kernels):
+            funcs_a = disassemble(co, with_addr=True)
+            for want in INLINE_ASM_LDS:
+                for n in [n for n in funcs_a if want in n]:
+                    check_asm_lds_reads(funcs_a[n], want)
         return {n: f.get("vgpr_count", -1) + f.get("agpr_count", 0) for n, f in meta.items() if any(w in n for w in wanted)}

@@ -237,3 +237,48 @@ def test_activation_row_reuse_is_bit_identical(precision):
     # accumulates both in the same order over k, so even that changes no bit)
     for k in ("c", "b", "v"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_mid_tile_barrier_tower_loop_is_bit_identical():
+    """BOD_TOWER_MIDBAR=1 runs the per-sample tower launches on the loop whose K-tile barrier sits two fragment steps before the
+    K-tile's end, with inline-asm fragment reads and hand-counted lgkmcnt waits (conv_igemm.hip, ABL = 6).  Same products in the same
+    order per accumulator: raw head outputs of a forward AND the detections of an aggregating infer must not change by one bit --
+    any fragment consumed before it landed, or a stage overwritten while it is read, shows up here."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+            "from conftest import ANCHOR_CFG, BAYES_CFG, NMS_CFG\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for hw, b, n in (((96, 160), 2, 3), ((160, 160), 3, 10)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))\n"
+            "    eng.load_weights(synthetic.make_weights(cls_fg_bias=-1.0))\n"
+            "    eng.set_anchors(FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3)))\n"
+            "    fr = synthetic.make_frames(b, hw[0], hw[1], seed=8)\n"
+            "    for rep in range(3):\n"
+            "        eng.infer(fr, seed=5 + rep, first_image_id=rep)\n"
+            "        for k, v in zip('smcn', eng.get_detections(b - 1)): out['det%d_%d_%s' % (n, rep, k)] = v\n"
+            "        for k, v in eng.get_posterior(0).items(): out['post%d_%d_%s' % (n, rep, k)] = v\n"
+            "    eng.forward(fr, seed=5, first_image_id=1)\n"
+            "    for k, v in zip('cbv', eng.get_raw()): out['raw%d_%s' % (n, k)] = v\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % (root, root))
+    outs = []
+    for mb in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_FORCE_CONV_TILE="256", BOD_TOWER_MIDBAR=mb)
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) > 20
+    for k in sorted(outs[0]):
+        assert outs[0][k].shape == outs[1][k].shape, k
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert np.abs(outs[0]["raw10_c"]).max() > 0

@@ -45,7 +45,21 @@ def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(conv_o
         assert names, want
         for n in names:
             checked += guard.check_inline_asm_mfma(funcs[n], want)
-    assert checked >= 2 * 192
+    assert checked >= 3 * 192
+
+
+def test_hand_counted_lds_waits_cover_every_fragment_read(conv_object, tmp_path):
+    """The mid-tile-barrier tower loop (ABL = 6) reads its MFMA fragments with inline-asm ds_read_b128 and waits with hand-written
+    `s_waitcnt lgkmcnt(n)`: walk the loop's disassembly with the in-order LDS return queue (two trips, across the back edge)."""
+    co = guard.extract_device_object(conv_object, str(tmp_path))
+    funcs = guard.disassemble(co, with_addr=True)
+    walked = 0
+    for want in guard.INLINE_ASM_LDS:
+        names = [n for n in funcs if want in n]
+        assert names, want
+        for n in names:
+            walked += guard.check_asm_lds_reads(funcs[n], want)
+    assert walked >= 6 + 2 * 72
 
 
 def test_the_guard_catches_both_hazards():
@@ -61,6 +75,14 @@ def test_the_guard_catches_both_hazards():
     assert guard.check_inline_asm_mfma([mf] * 100 + ["v_mov_b32_e32 v11, v50", "s_nop 1", mf] + [mf] * 91 + pad, "k") == 192
     with pytest.raises(guard.GuardError, match="changed shape"):
         guard.check_inline_asm_mfma([mf] * 10, "k")
+    # the LDS queue walk: an MFMA in front of the wait that covers its operand, and a correct sequence
+    rd = lambda r: "ds_read_b128 v[%d:%d], v200" % (r, r + 3)
+    mm = lambda a_: "v_mfma_f32_16x16x32_bf16 v[0:3], v[%d:%d], v[20:23], v[0:3]" % (a_, a_ + 3)
+    good = [(4 * i, l) for i, l in enumerate(["s_barrier", rd(100), rd(104), "s_waitcnt lgkmcnt(1)", mm(100), "s_waitcnt lgkmcnt(0)", mm(104)])]
+    assert guard.check_asm_lds_reads(good, "k", min_reads=2) == 2
+    bad = [(4 * i, l) for i, l in enumerate(["s_barrier", rd(100), rd(104), "s_waitcnt lgkmcnt(1)", mm(104), "s_waitcnt lgkmcnt(0)", mm(100)])]
+    with pytest.raises(guard.GuardError, match="may still be in flight"):
+        guard.check_asm_lds_reads(bad, "k", min_reads=2)
     with pytest.raises(guard.GuardError, match="spills"):
         guard.check_no_spills({"_Z17" + guard.PRODUCTION[0] + "v8ConvArgs": {"vgpr_spill_count": 3, "private_segment_fixed_size": 16}},
                               wanted=guard.PRODUCTION[:1])
