@@ -659,7 +659,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int r = xrow16[j] + kxc_;
                 return lds0 + (uint32_t)(2 * WST + xbuf * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4));
             };
-            bf16x8 Ar[4], Bc[4];
+            // fragments: A in a ring of four (two steps ahead; 16 % 4 == 0, the slots repeat per K-tile), B in TWO sets -- set ks holds
+            // the fragments of k-step ks; the set not in use is refilled half a K-tile ahead: k-step 1's fragments behind steps 2..5,
+            // the next K-tile's k-step-0 fragments behind steps 9..12 (same staged rows, one further: resident since the group's
+            // first barrier) or, at a group's last K-tile, behind the barrier (steps 14, 15: the next group's rows)
+            bf16x8 Ar[4], Bc[2][4];
             // weight offsets of the K-tiles one and two ahead: K-tile t is tap t % 9 of channel chunk t / 9
             int wo1 = a.cin * 2, tap1 = 1, wo2 = 2 * a.cin * 2, tap2 = 2;
             auto w_advance = [&](int& wo, int& tap) { if (++tap == 9) { tap = 0; wo += BK * 2 - 8 * a.cin * 2; } else wo += a.cin * 2; };
@@ -673,9 +677,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             if (KT > 1) dma_w(0, wo1, 1);
             if (KT > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-            rdA(Ar[0], a_cur, 0); rdA(Ar[1], a_cur, 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rdB(Bc[j], b_addr(0, j, 0));
+            // (the order a group's last K-tile leaves behind: A(0), B0, B1, A(1), B2, B3)
+            rdA(Ar[0], a_cur, 0); rdB(Bc[0][0], b_addr(0, 0, 0)); rdB(Bc[0][1], b_addr(0, 1, 0));
+            rdA(Ar[1], a_cur, 1); rdB(Bc[0][2], b_addr(0, 2, 0)); rdB(Bc[0][3], b_addr(0, 3, 0));
             __builtin_amdgcn_sched_barrier(0);
             for (int g = 0; g < NG; ++g) {
                 const bool xnext = g + 1 < NG;
@@ -722,7 +726,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int st = 0; st < 16; ++st) {
-                        const int fc = st & 7;
+                        const int fc = st & 7, ks = st >> 3;
                         if (st == 14) {
                             // the next K-tile's weights (and, behind a group's last K-tile, the next group's rows) have landed; my reads of
                             // this K-tile's stage have returned
@@ -732,19 +736,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             lgkm(0);
                             __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
                         }
-                        // A fragment two steps ahead (ring of four: 16 % 4 == 0, the slots repeat per K-tile)
+                        // ---- this step's reads, in the order the wait table below assumes
                         if (st + 2 < 16) rdA(Ar[(st + 2) & 3], (st + 2) < 8 ? a_cur : a_k1, (st + 2) & 7);
                         else rdA(Ar[(st + 2) & 3], a_nxt, st + 2 - 16);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // in flight behind what this MFMA needs: the A fragments of steps st+1 (only if issued AFTER the operand) and st+2,
-                            // and in the first step of a k-step the B fragments j+1.. (issued behind A(st+1), in front of A(st+2))
-                            if (st == 0 || st == 8) lgkm(4 - j);
-                            else if (j == 0) lgkm(2);
-                            mfma16_inplace(acc4[fc][j], Ar[st & 3], Bc[j]);
-                            if (st == 7) rdB(Bc[j], xb1[j]);
-                            if (st == 15) rdB(Bc[j], xbn[j]);
+                        if (st >= 2 && st <= 5) rdB(Bc[1][st - 2], xb1[st - 2]);
+                        if (kxc < 2 && st >= 9 && st <= 12) rdB(Bc[0][st - 9], xbn[st - 9]);
+                        if (kxc == 2 && st >= 14) { rdB(Bc[0][2 * (st - 14)], xbn[2 * (st - 14)]); rdB(Bc[0][2 * (st - 14) + 1], xbn[2 * (st - 14) + 1]); }
+                        // ---- reads younger than the operands of this step's MFMAs (LDS returns in order).  Step 0: A(0) and the B set were
+                        // issued by the previous K-tile -- behind its barrier if that was a group's last one (kxc == 0 here): then only
+                        // A(2) is younger than the last B fragment.
+                        {
+                            constexpr int W_SAME[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 3, 4, 5, 5, 4, -1, -1};      // kxc < 2: next B set read in steps 9..12
+                            constexpr int W_LAST[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 2, 2, 2, 2, 2, -1, -1};      // kxc == 2: next B set read behind the barrier
+                            int n = kxc < 2 ? W_SAME[st] : W_LAST[st];
+                            if (st == 0 && kxc == 0) n = 1;
+                            if (n >= 0) lgkm(n);
                         }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mfma16_inplace(acc4[fc][j], Ar[st & 3], Bc[ks][j]);
                         if (st & 1) {                        // 8 slots per K-tile, behind steps 1, 3, .. 15
                             const int slot = st >> 1;
                             __builtin_amdgcn_sched_barrier(0);
@@ -767,7 +776,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 if (++ky == 3) { ky = 0; ++cc; }
             }
             // the reads issued for a K-tile that does not exist: their registers stay allocated until they have landed
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ar[0]), "+v"(Ar[1]), "+v"(Ar[2]), "+v"(Ar[3]), "+v"(Bc[0]), "+v"(Bc[1]), "+v"(Bc[2]), "+v"(Bc[3]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ar[0]), "+v"(Ar[1]), "+v"(Ar[2]), "+v"(Ar[3]), "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]), "+v"(Bc[0][3]),
+                         "+v"(Bc[1][0]), "+v"(Bc[1][1]), "+v"(Bc[1][2]), "+v"(Bc[1][3]) :: "memory");
 #endif
         } else
         for (int g = 0; g < NG; ++g) {

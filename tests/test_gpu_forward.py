@@ -262,10 +262,10 @@ def test_mid_tile_barrier_tower_loop_is_bit_identical():
             "    fr = synthetic.make_frames(b, hw[0], hw[1], seed=8)\n"
             "    for rep in range(3):\n"
             "        eng.infer(fr, seed=5 + rep, first_image_id=rep)\n"
-            "        for k, v in zip('smcn', eng.get_detections(b - 1)): out['det%d_%d_%s' % (n, rep, k)] = v\n"
-            "        for k, v in eng.get_posterior(0).items(): out['post%d_%d_%s' % (n, rep, k)] = v\n"
+            "        for k, v in zip('smcn', eng.get_detections(b - 1)): out['det%%d_%%d_%%s' %% (n, rep, k)] = v\n"
+            "        for k, v in eng.get_posterior(0).items(): out['post%%d_%%d_%%s' %% (n, rep, k)] = v\n"
             "    eng.forward(fr, seed=5, first_image_id=1)\n"
-            "    for k, v in zip('cbv', eng.get_raw()): out['raw%d_%s' % (n, k)] = v\n"
+            "    for k, v in zip('cbv', eng.get_raw()): out['raw%%d_%%s' %% (n, k)] = v\n"
             "    eng.close()\n"
             "np.savez(sys.argv[1], **out)\n" % (root, root))
     outs = []
