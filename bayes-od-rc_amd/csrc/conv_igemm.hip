@@ -585,7 +585,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const int a_c0 = (fhalf ^ fswz) << 4;                                // chunk byte offset of k-step 0 (k-step ks: ^ (ks << 5))
         const int a_row = (wc * WTC + frow) * ROWB + a_c0;
         const int NG = KT / 3;
-        constexpr bool PH_BUILD = !SPLIT && FP == 2 && (ABL == 0 || ABL == 6 || ABL == 90 || ABL == 30 || ABL == 31 || ABL == 1 || ABL == 2);
+        constexpr bool PH_BUILD = !SPLIT && FP == 2 && (ABL == 0 || ABL == 9 || ABL == 90 || ABL == 30 || ABL == 31 || ABL == 1 || ABL == 2);
         const bool ph_on = PH_BUILD && (a.flags & CONV_DROPOUT) && !(a.flags & CONV_OUT_F32) && a.fan_count <= 1 && NG >= 8 && bc0 == 0 &&
                            a.drop_threshold >= 1 && a.variant != 83;            // (variant 83: decisions drawn in the epilogue, A/B)
         ph_inloop = ph_on;
@@ -609,7 +609,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             return b;
         };
         // ------------------------------------------------------------------------------------------------------------------
-        // ABL == 6: the tower loop with the K-tile barrier TWO FRAGMENT STEPS BEFORE THE K-TILE'S END (round 3).  A K-tile is 16
+        // The tower loop with the K-tile barrier TWO FRAGMENT STEPS BEFORE THE K-TILE'S END (round 3; every M16 build but ABL 9).  A K-tile is 16
         // steps (k-step ks = step >> 3, cout fragment fc = step & 7) of four MFMAs.  The barrier in front of step 14 comes after
         // every read of this K-tile's weight stage has returned (the A fragments of steps 14, 15 are fetched two steps ahead), so
         // behind it the NEXT K-tile's first fragments are read -- A(0), A(1), and the B set behind step 15's MFMAs -- while
@@ -624,7 +624,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // K-tile t+1 go out behind steps 15 (of t-1), 1, 3, 5 (of t) and are waited for in front of step 14 of t; the next
         // group's extended rows behind steps 7, 9, 11 of the group's first K-tile and 7, 9 of its second.
         // ------------------------------------------------------------------------------------------------------------------
-        constexpr bool MB = M16 && ABL == 6;
+        constexpr bool MB = M16 && ABL != 9 && ABL != 2;      // every build of the 16x16x32 loop but ABL 9 (the round-2 loop, top-of-K-tile barrier: A/B) and the no-staging ablation
+        [[maybe_unused]] constexpr int AHEAD = 2;             // A fragments fetched this many steps ahead (ring of four; three ahead measured 0.3-0.5 % slower)
         if constexpr (MB) {
 #if defined(__HIP_DEVICE_COMPILE__)
             auto lgkm = [](int n) {
@@ -634,7 +635,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
                     case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
                     case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
                 }
             };
             // A fragment fc of the K-tile whose stage / k-step is folded into `addr`: immediate offset fc * 16 rows
@@ -659,7 +662,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int r = xrow16[j] + kxc_;
                 return lds0 + (uint32_t)(2 * WST + xbuf * XBUF + r * ROWB + (((q4 + (r & 6)) & 7) << 4));
             };
-            // fragments: A in a ring of four (two steps ahead; 16 % 4 == 0, the slots repeat per K-tile), B in TWO sets -- set ks holds
+            // fragments: A in a ring of four (three steps ahead; 16 % 4 == 0, the slots repeat per K-tile), B in TWO sets -- set ks holds
             // the fragments of k-step ks; the set not in use is refilled half a K-tile ahead: k-step 1's fragments behind steps 2..5,
             // the next K-tile's k-step-0 fragments behind steps 9..12 (same staged rows, one further: resident since the group's
             // first barrier) or, at a group's last K-tile, behind the barrier (steps 14, 15: the next group's rows)
@@ -677,9 +680,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             if (KT > 1) dma_w(0, wo1, 1);
             if (KT > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-            // (the order a group's last K-tile leaves behind: A(0), B0, B1, A(1), B2, B3)
-            rdA(Ar[0], a_cur, 0); rdB(Bc[0][0], b_addr(0, 0, 0)); rdB(Bc[0][1], b_addr(0, 1, 0));
-            rdA(Ar[1], a_cur, 1); rdB(Bc[0][2], b_addr(0, 2, 0)); rdB(Bc[0][3], b_addr(0, 3, 0));
+            // (the order a group's last K-tile leaves behind: A(0), A(1), B0, B1, A(2), B2, B3)
+            rdA(Ar[0], a_cur, 0);
+            if constexpr (AHEAD == 3) rdA(Ar[1], a_cur, 1);
+            rdB(Bc[0][0], b_addr(0, 0, 0)); rdB(Bc[0][1], b_addr(0, 1, 0));
+            rdA(Ar[AHEAD - 1], a_cur, AHEAD - 1); rdB(Bc[0][2], b_addr(0, 2, 0)); rdB(Bc[0][3], b_addr(0, 3, 0));
             __builtin_amdgcn_sched_barrier(0);
             for (int g = 0; g < NG; ++g) {
                 const bool xnext = g + 1 < NG;
@@ -737,18 +742,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
                         }
                         // ---- this step's reads, in the order the wait table below assumes
-                        if (st + 2 < 16) rdA(Ar[(st + 2) & 3], (st + 2) < 8 ? a_cur : a_k1, (st + 2) & 7);
-                        else rdA(Ar[(st + 2) & 3], a_nxt, st + 2 - 16);
+                        // A fragments THREE steps ahead (ring of four): the last one of the K-tile, A(15), goes out in step 12, so the
+                        // lgkmcnt(0) in front of the barrier finds it landed; the next K-tile's A(0), A(1) follow the barrier, A(2) step 15
+                        if (st + AHEAD <= 15) rdA(Ar[(st + AHEAD) & 3], (st + AHEAD) < 8 ? a_cur : a_k1, (st + AHEAD) & 7);
+                        else if (st == 14) { rdA(Ar[0], a_nxt, 0); if constexpr (AHEAD == 3) rdA(Ar[1], a_nxt, 1); }
+                        else if (st == 15) rdA(Ar[AHEAD - 1], a_nxt, AHEAD - 1);
                         if (st >= 2 && st <= 5) rdB(Bc[1][st - 2], xb1[st - 2]);
                         if (kxc < 2 && st >= 9 && st <= 12) rdB(Bc[0][st - 9], xbn[st - 9]);
                         if (kxc == 2 && st >= 14) { rdB(Bc[0][2 * (st - 14)], xbn[2 * (st - 14)]); rdB(Bc[0][2 * (st - 14) + 1], xbn[2 * (st - 14) + 1]); }
                         // ---- reads younger than the operands of this step's MFMAs (LDS returns in order).  Step 0: A(0) and the B set were
                         // issued by the previous K-tile -- behind its barrier if that was a group's last one (kxc == 0 here): then only
-                        // A(2) is younger than the last B fragment.
+                        // A(AHEAD) is younger than the last B fragment.
                         {
-                            constexpr int W_SAME[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 3, 4, 5, 5, 4, -1, -1};      // kxc < 2: next B set read in steps 9..12
-                            constexpr int W_LAST[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 2, 2, 2, 2, 2, -1, -1};      // kxc == 2: next B set read behind the barrier
-                            int n = kxc < 2 ? W_SAME[st] : W_LAST[st];
+                            // (tables: tests/tools/lds_wait_tables.py replays the issue order below and counts)
+                            constexpr int W_SAME3[16] = {3, 3, 4, 5, 6, 7, 6, 5, 3, 4, 5, 6, 7, 5, -1, -1};     // kxc < 2: next B set read in steps 9..12
+                            constexpr int W_LAST3[16] = {3, 3, 4, 5, 6, 7, 6, 5, 3, 3, 3, 3, 3, 2, -1, -1};     // kxc == 2: next B set read behind the barrier
+                            constexpr int W_SAME2[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 3, 4, 5, 5, 4, -1, -1};
+                            constexpr int W_LAST2[16] = {2, 2, 3, 4, 5, 5, 4, 3, 2, 2, 2, 2, 2, 2, -1, -1};
+                            int n = AHEAD == 3 ? (kxc < 2 ? W_SAME3[st] : W_LAST3[st]) : (kxc < 2 ? W_SAME2[st] : W_LAST2[st]);
                             if (st == 0 && kxc == 0) n = 1;
                             if (n >= 0) lgkm(n);
                         }
@@ -757,6 +768,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         if (st & 1) {                        // 8 slots per K-tile, behind steps 1, 3, .. 15
                             const int slot = st >> 1;
                             __builtin_amdgcn_sched_barrier(0);
+                            // (two pieces right behind the barrier and the others a slot earlier: no difference, A/B on one box)
                             if (slot < 3) { if (w1) dma_w(slot + 1, wo1, (kt + 1) & 1); }
                             else if (slot == 7) { if (w2) dma_w(0, wo2, kt & 1); }
                             else if ((kxc == 0 && slot < 6) || (kxc == 1 && slot < 5)) {
@@ -2036,10 +2048,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // it runs the loop and the register-resident fan-out epilogue), so that a kernel trace lists the per-sample tower
         // launches -- the roofline kernel of bench.py -- and the fan-out launch separately
         if (a.fan_count > 1) return launch_cfg<256, 256, 2, 4, 5, true>(a, s);
-        // BOD_TOWER_MIDBAR=1: the per-sample tower launches on the loop with the K-tile barrier two fragment steps before the
-        // K-tile's end and hand-counted LDS waits (ABL = 6; bit-identical results: same products in the same order)
-        static const bool midbar = getenv("BOD_TOWER_MIDBAR") && atoi(getenv("BOD_TOWER_MIDBAR")) == 1;
-        if (midbar && a.variant == 0) return launch_cfg<256, 256, 2, 4, 6, true>(a, s);
+        // BOD_TOWER_MIDBAR=0: the per-sample tower launches on the round-2 loop (barrier at the top of the K-tile, compiler-placed
+        // LDS waits; ABL = 9) -- A/B aid, bit-identical results
+        static const bool old_loop = getenv("BOD_TOWER_MIDBAR") && atoi(getenv("BOD_TOWER_MIDBAR")) == 0;
+        if (old_loop && a.variant == 0) return launch_cfg<256, 256, 2, 4, 9, true>(a, s);
         return launch_cfg<256, 256, 2, 4, 0, true>(a, s);
     }
     switch (variant) {          // ablation builds of the generic loop (tests/tools/bench_head_conv.py)

@@ -29,10 +29,10 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb1EE",     # bf16x3 on the row-reuse loop (fused 1x1 + MC aggregation)
-    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi6ELb1ELb0EE",     # head towers, K-tile barrier two steps before the K-tile's end, asm LDS reads
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi9ELb1ELb0EE",     # head towers on the round-2 loop (top-of-K-tile barrier): A/B twin, BOD_TOWER_MIDBAR=0
 ]
 INLINE_ASM_MFMA = PRODUCTION[:2] + PRODUCTION[-1:]             # the kernels on the 16x16x32 inline-asm loop
-INLINE_ASM_LDS = PRODUCTION[-1:]                               # ... whose fragment reads and lgkmcnt waits are hand-written too
+INLINE_ASM_LDS = PRODUCTION[:2]                                # ... whose fragment reads and lgkmcnt waits are hand-written too (mid-tile barrier)
 
 
 class GuardError(RuntimeError):

@@ -540,7 +540,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         # (the plan fuses them whenever the launch uses the full-cout tile: from about 8 frames per step on; below that
         # they are separate small launches and are not counted here)
         algo_flops = n * 8 * conv_flops * B * prof_steps
-        kernel_name = "conv_igemm_kernel<256,256,2,4,0,true%s> (head towers, 3x3 256->256, layers 1-3)" % (
+        kernel_name = "conv_igemm_kernel<256,256,2,4,0,true%s> (head towers, 3x3 256->256, layers 1-3; mid-tile-barrier loop)" % (
             ",SPLIT: 3 MFMA products per MAC" if args.precision == "bf16x3" else "")
     else:                                # no row-reuse kernel in the plan (fp32 / bf16x3 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))

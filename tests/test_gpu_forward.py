@@ -240,8 +240,9 @@ def test_activation_row_reuse_is_bit_identical(precision):
 
 
 def test_mid_tile_barrier_tower_loop_is_bit_identical():
-    """BOD_TOWER_MIDBAR=1 runs the per-sample tower launches on the loop whose K-tile barrier sits two fragment steps before the
-    K-tile's end, with inline-asm fragment reads and hand-counted lgkmcnt waits (conv_igemm.hip, ABL = 6).  Same products in the same
+    """The per-sample tower launches run on the loop whose K-tile barrier sits two fragment steps before the K-tile's end, with
+    inline-asm fragment reads and hand-counted lgkmcnt waits (conv_igemm.hip); BOD_TOWER_MIDBAR=0 selects the round-2 loop
+    (barrier at the top of the K-tile, compiler-placed waits).  Same products in the same
     order per accumulator: raw head outputs of a forward AND the detections of an aggregating infer must not change by one bit --
     any fragment consumed before it landed, or a stage overwritten while it is read, shows up here."""
     import os
