@@ -1456,6 +1456,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     // the row-reuse launches (head towers) have neither a residual nor a second relu output: compiled out there, which
     // keeps the kernel at the 256-register budget without a spill
     constexpr bool CAN_RES = !XR;
+    // streaming outputs: activations of 2-22 GB per launch that the next launch reads from HBM anyway are stored non-temporally, so
+    // that they do not evict what the kernels re-read through L2 / the Infinity Cache (weights, halo rows) -- ConvArgs.flags & CONV_NT_OUT
+    const bool nt_out = (a.flags & CONV_NT_OUT) != 0;
     int2 rng[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) rng[j] = s_rng[wp * WTP + j * 32 + frow];    // rng_p, rng_zs
@@ -1607,8 +1610,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const Philox4 p1 = philox4x32_10((uint32_t)r.x, gb, key, img, rng_seed_lo, rng_seed_hi);
                 const uint4 oa = make_uint4(va.x & keep2(p0.x), va.y & keep2(p0.y), va.z & keep2(p1.x), va.w & keep2(p1.y));
                 const uint4 ob = make_uint4(vb.x & keep2(p0.z), vb.y & keep2(p0.w), vb.z & keep2(p1.z), vb.w & keep2(p1.w));
-                *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride) = oa;
-                *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride + 8) = ob;
+                if (nt_out) {
+                    __builtin_nontemporal_store(u32x4{oa.x, oa.y, oa.z, oa.w}, reinterpret_cast<u32x4*>(o + (size_t)n * sample_stride));
+                    __builtin_nontemporal_store(u32x4{ob.x, ob.y, ob.z, ob.w}, reinterpret_cast<u32x4*>(o + (size_t)n * sample_stride + 8));
+                } else {
+                    *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride) = oa;
+                    *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride + 8) = ob;
+                }
             }
         }
         return;
@@ -1788,7 +1796,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             const int c16 = (cp ^ pixl) & (CPR - 1);
             const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 + c16 * 8;
             if (ABL == 30) { if (v.x == 0x12345678u && e == 0) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out)) = v; continue; }
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + e) = v;
+            // (variant 86, BOD_NT_STORES=1: non-temporal stores for the generic kernel's outputs -- A/B)
+            if (nt_out) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(G.out) + e));
+            else *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + e) = v;
             if (CAN_RES && G.out_relu) {
                 uint4 r;
                 r.x = relu_bf16x2(v.x); r.y = relu_bf16x2(v.y); r.z = relu_bf16x2(v.z); r.w = relu_bf16x2(v.w);
@@ -1993,6 +2003,14 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // BOD_RES_REGISTER=1: residuals read from global memory in the accumulator layout instead of through the LDS tile (A/B aid)
     static const bool res_register = getenv("BOD_RES_REGISTER") && atoi(getenv("BOD_RES_REGISTER")) == 1;
     if (res_register && a_local.variant == 0 && !a_local.xreuse && !a_local.split && a_local.ksplit <= 1) a_local.variant = 82;
+    // BOD_NT_STORES (default 0 = plain stores): bit 0 = non-temporal output stores in the generic kernel (backbone / FPN), bit 1 = in
+    // the row-reuse kernels (head towers, fan-out launch).  Measured on one box, 256 frames: backbone -0.35 ms with bit 0, the tower
+    // launches +0.5 ms beside it (net 0); bit 1 costs the towers 1 % and the fan-out launch 4 %: the outputs are re-read by the next
+    // launch's neighbouring tiles through L2 after all.  Kept as an A/B switch.
+    static const int nt_stores = getenv("BOD_NT_STORES") ? atoi(getenv("BOD_NT_STORES")) : 0;
+    if (!(a_local.flags & CONV_OUT_F32) && !a_local.split && a_local.ksplit <= 1 &&
+        (((nt_stores & 1) && !a_local.xreuse) || ((nt_stores & 2) && a_local.xreuse)))
+        a_local.flags |= CONV_NT_OUT;
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;

@@ -45,7 +45,8 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
 
 enum : int32_t { CONV_RELU = 1, CONV_DROPOUT = 2, CONV_OUT_F32 = 4,
-                 CONV_ACCUM = 8 };     // with CONV_OUT_F32: out += result (input gradients of 1x1 layers accumulate in place)
+                 CONV_ACCUM = 8,       // with CONV_OUT_F32: out += result (input gradients of 1x1 layers accumulate in place)
+                 CONV_NT_OUT = 16 };   // bf16 outputs stored non-temporally (set by launch_conv_igemm, BOD_NT_STORES)
 
 struct ConvArgs {
     ConvGroup g[3];
