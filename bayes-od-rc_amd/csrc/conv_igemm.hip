@@ -667,6 +667,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             // the next K-tile's k-step-0 fragments behind steps 9..12 (same staged rows, one further: resident since the group's
             // first barrier) or, at a group's last K-tile, behind the barrier (steps 14, 15: the next group's rows)
             bf16x8 Ar[4], Bc[2][4];
+            // uniform inputs of the in-loop Philox set-up, pinned in scalar registers: a kernel-argument load inside the loop makes the
+            // compiler wait lgkmcnt(0) behind it, which also drains the fragment reads in flight
+            uint32_t ph_lid16 = (uint32_t)G.layer_id << 16, ph_sbase = a.sample_base;
+            asm volatile("" : "+s"(ph_lid16), "+s"(ph_sbase));
             // weight offsets of the K-tiles one and two ahead: K-tile t is tap t % 9 of channel chunk t / 9
             int wo1 = a.cin * 2, tap1 = 1, wo2 = 2 * a.cin * 2, tap2 = 2;
             auto w_advance = [&](int& wo, int& tap) { if (++tap == 9) { tap = 0; wo += BK * 2 - 8 * a.cin * 2; } else wo += a.cin * 2; };
@@ -701,7 +705,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);
                         ph.c0 = (uint32_t)rr;
                         const uint32_t ry = (uint32_t)((unsigned long long)rr >> 32);
-                        ph.c2 = (a.sample_base + (ry & 0xFFFFu)) | ((uint32_t)G.layer_id << 16);
+                        ph.c2 = (ph_sbase + (ry & 0xFFFFu)) | ph_lid16;
                         ph.c3 = ph_img + (ry >> 16);
                         ph.k0 = ph_k0; ph.k1 = ph_k1;
                         if (sidx == 0) philox_rounds(ph, 1);
