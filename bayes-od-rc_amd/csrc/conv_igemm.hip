@@ -624,7 +624,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // K-tile t+1 go out behind steps 15 (of t-1), 1, 3, 5 (of t) and are waited for in front of step 14 of t; the next
         // group's extended rows behind steps 7, 9, 11 of the group's first K-tile and 7, 9 of its second.
         // ------------------------------------------------------------------------------------------------------------------
-        constexpr bool MB = M16 && ABL != 9 && ABL != 2;      // every build of the 16x16x32 loop but ABL 9 (the round-2 loop, top-of-K-tile barrier: A/B) and the no-staging ablation
+        constexpr bool MB = M16 && ABL != 9;                  // every build of the 16x16x32 loop but ABL 9 (the round-2 loop, top-of-K-tile barrier: A/B)
         [[maybe_unused]] constexpr int AHEAD = 2;             // A fragments fetched this many steps ahead (ring of four; three ahead measured 0.3-0.5 % slower)
         if constexpr (MB) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -773,7 +773,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             const int slot = st >> 1;
                             __builtin_amdgcn_sched_barrier(0);
                             // (two pieces right behind the barrier and the others a slot earlier: no difference, A/B on one box)
-                            if (slot < 3) { if (w1) dma_w(slot + 1, wo1, (kt + 1) & 1); }
+                            if (ABL == 2) {}                     // (ablation: no staging after the first K-tile)
+                            else if (slot < 3) { if (w1) dma_w(slot + 1, wo1, (kt + 1) & 1); }
                             else if (slot == 7) { if (w2) dma_w(0, wo2, kt & 1); }
                             else if ((kxc == 0 && slot < 6) || (kxc == 1 && slot < 5)) {
                                 const int I = kxc == 0 ? slot - 3 : slot;          // pieces 0..2 in the group's first K-tile, 3..4 in its second
@@ -1709,6 +1710,126 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         phase_stamp<ABL>(tstamp, 3);        // Philox mask + LDS tile writes
         __syncthreads();
         phase_stamp<ABL>(tstamp, 4);        // barrier
+        if constexpr (ABL == 10) {
+            // ---- bottleneck chain (ConvGroup.ch_*): the tile in LDS is t2 = relu(2b) [128 pixels][CM channels].  Per pass of 128 output
+            // channels: the shortcut's pixels come in by LDS-DMA into the pass tile Y [128][128] while the wave multiplies its 32 pixels
+            // with the 2c weights (A fragments straight from global memory: L2-resident, 32-128 KB per layer); relu(acc + bias +
+            // shortcut) is written over the shortcut in place, the pass goes out as 16-byte row pieces, and -- on the same bf16 values,
+            // read back from the wave's own rows -- the next block's 2a accumulates its partial sums over this pass's 128 channels.
+            // Same MFMA shape, k order and epilogue arithmetic as the separate 2c / 2a launches: bit-identical planes.
+            static_assert(!XR && !SPLIT && BP == 128 && (BC == 64 || BC == 128) && THREADS == 256, "chain epilogue: 64x128 / 128x128 tiles");
+            constexpr int CM = BC, CPRM = CM / 8, T2B = BP * CM * 2, KS2 = CM / 16, F3 = CM / 32;
+            static_assert(T2B + 128 * 256 <= Cfg::MAIN, "chain epilogue does not fit the staging area");
+            char* Yt = smem + T2B;
+            const int C2 = G.ch_c2, npass = C2 / 128;
+            const int mypix = wave * 32 + frow;
+            bf16x8 b2[KS2];
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+                b2[ks] = *reinterpret_cast<const bf16x8*>(smem + mypix * (CM * 2) + ((((ks * 2 + fhalf) ^ mypix) & (CPRM - 1)) << 4));
+            const bool has3 = G.ch_w3 != nullptr;
+            f32x16 acc3[F3];
+#pragma unroll
+            for (int f = 0; f < F3; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[f][r] = 0.f;
+            const uint16_t* w2 = reinterpret_cast<const uint16_t*>(G.ch_w2);
+            const uint16_t* w3 = reinterpret_cast<const uint16_t*>(G.ch_w3);
+            const char* resb = reinterpret_cast<const char*>(G.ch_res);
+            uint16_t* outb = reinterpret_cast<uint16_t*>(G.ch_out);
+            for (int q = 0; q < npass; ++q) {
+                // shortcut pixels of this pass -> Y (piece (pixel, physical chunk pc) holds logical chunk pc ^ pixel)
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int qi = it * THREADS + tid, pixl = qi >> 4, pc = qi & 15, cp = (pc ^ pixl) & 15;
+                    const int off = s_off[pixl] < 0 ? 0 : s_off[pixl];
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(resb + ((size_t)off * C2 + q * 128 + cp * 8) * 2),
+                                                     LDS_PTR(Yt + (it * THREADS + wave * 64) * 16), 16, 0, 0);
+                }
+                // one 32-channel fragment at a time (16 accumulator registers live: the kernel keeps the base build's residency); the
+                // first fragment's MFMAs run while the shortcut pieces are in flight
+                auto gemm2 = [&](int f) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(w2 + (size_t)(q * 128 + f * 32 + frow) * CM + ks * 16 + fhalf * 8);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2[ks], acc, 0, 0, 0);
+                    }
+                    return acc;
+                };
+                auto finish = [&](int f, const f32x16& acc) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = f * 32 + g4 * 8 + fhalf * 4;
+                        char* pp = Yt + mypix * 256 + ((((col >> 3) ^ mypix) & 15) << 4) + (col & 7) * 2;
+                        const uint2 r = *reinterpret_cast<const uint2*>(pp);
+                        const float4 bv = *reinterpret_cast<const float4*>(G.ch_b2 + q * 128 + col);
+                        // (the separate 2c launch: fma(acc, 1, bias), += shortcut * 1, ReLU, round)
+                        float v0 = __builtin_fmaf(acc[g4 * 4 + 0], 1.0f, bv.x), v1 = __builtin_fmaf(acc[g4 * 4 + 1], 1.0f, bv.y);
+                        float v2 = __builtin_fmaf(acc[g4 * 4 + 2], 1.0f, bv.z), v3 = __builtin_fmaf(acc[g4 * 4 + 3], 1.0f, bv.w);
+                        v0 += bf16_to_f32(r.x & 0xFFFFu) * 1.0f; v1 += bf16_to_f32(r.x >> 16) * 1.0f;
+                        v2 += bf16_to_f32(r.y & 0xFFFFu) * 1.0f; v3 += bf16_to_f32(r.y >> 16) * 1.0f;
+                        uint2 o;
+                        o.x = relu_bf16x2_pk(pack_bf16x2(v0, v1)); o.y = relu_bf16x2_pk(pack_bf16x2(v2, v3));
+                        *reinterpret_cast<uint2*>(pp) = o;
+                    }
+                };
+                {
+                    const f32x16 a0 = gemm2(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                      // every wave's shortcut pieces have landed
+                    finish(0, a0);
+                }
+#pragma unroll 1
+                for (int f = 1; f < 4; ++f) { const f32x16 af_ = gemm2(f); finish(f, af_); }
+                if (has3) {                               // next block's 2a on this pass's 128 channels (own rows: no barrier needed)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(Yt + mypix * 256 + ((((ks * 2 + fhalf) ^ mypix) & 15) << 4));
+#pragma unroll
+                        for (int f = 0; f < F3; ++f) {
+                            const bf16x8 af = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(f * 32 + frow) * C2 + q * 128 + ks * 16 + fhalf * 8);
+                            acc3[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, yb, acc3[f], 0, 0, 0);
+                        }
+                    }
+                }
+                __syncthreads();                          // the pass tile is complete
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int qi = it * THREADS + tid, pixl = qi >> 4, pc = qi & 15, cp = (pc ^ pixl) & 15;
+                    const int off = s_off[pixl];
+                    if (off < 0) continue;
+                    *reinterpret_cast<uint4*>(outb + (size_t)off * C2 + q * 128 + cp * 8) = *reinterpret_cast<const uint4*>(Yt + qi * 16);
+                }
+                __syncthreads();                          // ... and read: the next pass may overwrite it
+            }
+            if (has3) {
+                // t1' = relu(acc3 + bias) -> bf16 -> the t2 region (every wave read its t2 fragments long ago) -> row pieces
+#pragma unroll
+                for (int f = 0; f < F3; ++f)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = f * 32 + g4 * 8 + fhalf * 4;
+                        const float4 bv = *reinterpret_cast<const float4*>(G.ch_b3 + col);
+                        uint2 o;
+                        o.x = relu_bf16x2_pk(pack_bf16x2(__builtin_fmaf(acc3[f][g4 * 4 + 0], 1.0f, bv.x), __builtin_fmaf(acc3[f][g4 * 4 + 1], 1.0f, bv.y)));
+                        o.y = relu_bf16x2_pk(pack_bf16x2(__builtin_fmaf(acc3[f][g4 * 4 + 2], 1.0f, bv.z), __builtin_fmaf(acc3[f][g4 * 4 + 3], 1.0f, bv.w)));
+                        *reinterpret_cast<uint2*>(smem + mypix * (CM * 2) + ((((col >> 3) ^ mypix) & (CPRM - 1)) << 4) + (col & 7) * 2) = o;
+                    }
+                __syncthreads();
+                uint16_t* out3 = reinterpret_cast<uint16_t*>(G.ch_out3);
+#pragma unroll
+                for (int it = 0; it < BP * CPRM / THREADS; ++it) {
+                    const int qi = it * THREADS + tid, pixl = qi / CPRM, pc = qi % CPRM, cp = (pc ^ pixl) & (CPRM - 1);
+                    const int off = s_off[pixl];
+                    if (off < 0) continue;
+                    *reinterpret_cast<uint4*>(out3 + (size_t)off * CM + cp * 8) = *reinterpret_cast<const uint4*>(smem + qi * 16);
+                }
+            }
+            return;
+        }
         if (fuse && G.agg_kind != AGG_NONE) {
             // ---- fused 1x1 + MC aggregation: all of a wave's output fragments stay in registers until every wave has read
             // the activation tile; its LDS then becomes the fp32 output tile [row][ystride] the reduction walks
@@ -1817,8 +1938,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 
 // One tile per workgroup.  XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous
 // range of pixel tiles so that neighbouring tiles (which share their 3x3 halo rows) share an L2.
+// (the bottleneck-chain build, ABL 10, is memory-bound and must keep the base kernel's residency: 3 / 2 workgroups per CU at 64 / 128 couts)
 template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
-__global__ __launch_bounds__(64 * WC * WP) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1)) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int bx = blockIdx.x, gz = blockIdx.z;
     {
@@ -1986,7 +2108,19 @@ static bool conv_big_tile_pays(const ConvArgs& a) {
     const long tiles = (long)((a.M + 255) / 256) * (a.cout_pad / 256) * (a.groups > 0 ? a.groups : 1);
     if (a.flags & CONV_OUT_F32) return (a.flags & CONV_ACCUM) && f32_min_tiles > 0 && tiles >= f32_min_tiles;
     if (a.fan_count > 1) return tiles >= 1024;        // (fan-out layer: -1 % at 513 tiles, +0.5 % from 1 026 on)
+    // BOD_SMALL_TILE_MAXK=k (A/B aid): layers whose reduction is at most k (taps * cin: the memory-bound 1x1 layers of res2 / res3
+    // have 64 / 128) take the 128x128 tile, two workgroups per CU, whatever their tile count
+    static const int small_maxk = getenv("BOD_SMALL_TILE_MAXK") ? atoi(getenv("BOD_SMALL_TILE_MAXK")) : 0;
+    if (small_maxk > 0 && a.taps > 0 && a.cin > 0 && a.taps * a.cin <= small_maxk && !a.xreuse && a.fan_count <= 1) return false;
     return tiles >= 384;
+}
+
+bool conv_igemm_uses_big_tile(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
+    bool big = conv_big_tile_pays(a);
+    if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);
+    if (forced == 128) big = false;
+    return big;
 }
 
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a) {
@@ -2028,6 +2162,15 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.split) {                                   // bf16x3: fused 1x1 (+ aggregation) on the row-reuse loop only, no ablation builds, no fan-out on the row-reuse loop
         if (a.variant != 0 || a.cin % 128 != 0 || (a.xreuse && (a.xreuse != 2 || a.fan_count > 1))) return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g) if (a.g[g].w2 && !a.xreuse) return hipErrorInvalidValue;   // the fused 1x1 lives in the row-reuse kernel's epilogue
+    }
+    // bottleneck chain (ConvGroup.ch_w2): one cout tile holding all couts, 128-pixel tiles, bf16, no split-K
+    if (a.g[0].ch_w2) {
+        if (a.groups != 1 || big || a.split || a.xreuse || a.ksplit > 1 || a.variant != 0 || a.fan_count > 1 || (a.flags & (CONV_OUT_F32 | CONV_DROPOUT)) ||
+            !(a.flags & CONV_RELU) || a.g[0].res || a.g[0].out_relu || a.g[0].w2 || a.g[0].ch_c2 % 128 != 0 || a.cout_valid != a.cout_pad)
+            return hipErrorInvalidValue;
+        if (a.cout_pad == 64) return launch_cfg<64, 128, 1, 4, 10>(a, s);
+        if (a.cout_pad == 128) return launch_cfg<128, 128, 2, 2, 10>(a, s);
+        return hipErrorInvalidValue;
     }
     if (a.ksplit > 1) {
         if ((a.cin / 64) % a.ksplit != 0 || !a.partial || a.xreuse || a.fan_count > 1 || (a.flags & CONV_DROPOUT) || a.variant != 0)

@@ -461,11 +461,75 @@ bod_status build_plan(bod_context* h) {
         BODCHK(new_plane(h, &oa, B, hh, ww, f3));
         BODCHK(new_plane(h, &ob, B, hh, ww, f3));
         bool use_a = true;
+        // Bottleneck chain (stages 2 and 3, bf16 inference): a block's 3x3 conv `2b` keeps its tile in LDS and runs the block's 1x1
+        // expansion `2c` (+ shortcut + ReLU) and the NEXT block's 1x1 reduction `2a` on it (conv_igemm.hip, ConvGroup.ch_*): the two
+        // narrow intermediates never reach HBM -- 1.3 KB instead of 2 KB per pixel and block, two launches fewer.  The 3x3 comes FIRST
+        // in the fused chain, so only the narrow t1 plane is re-read with a halo; t1 is double-buffered (the fused launch reads one
+        // t1 plane with halos while it writes the next block's).  BOD_CHAIN_FUSION=0: the three separate launches (A/B; bit-identical).
+        // Measured per block at 256 frames of 512x512 (BOD_TRACE_OPS): stage 2 (64 -> 256 channels) 2.23 -> 1.99 ms, its last block
+        // 1.67 -> 1.45; stage 3 (128 -> 512) 1.33 -> 1.59 ms -- four shortcut passes per 128-pixel tile, each opening with an exposed
+        // LDS-DMA round trip, cost more than the bytes they save -- so stage 3 is chained only on request (BOD_CHAIN_FUSION=3).
+        int chain_stages = 2;
+        if (const char* e = getenv("BOD_CHAIN_FUSION")) chain_stages = atoi(e);
+        bool chain_ok = h->es == 2 && !h->split && !train_mode && ((st == 2 && chain_stages >= 1) || (st == 3 && chain_stages >= 3));
+        Plane t1alt;
+        if (chain_ok) BODCHK(new_plane(h, &t1alt, B, hh, ww, f1));
+        bool t1_ready = false;                  // the previous block's fused launch already produced this block's t1
         for (const char* bl = blocks[st]; *bl; ++bl) {
             char cb[64], bb[64];
             snprintf(cb, sizeof cb, "res%d%c_branch", st, *bl);
             snprintf(bb, sizeof bb, "bn%d%c_branch", st, *bl);
             const std::string c_(cb), b_(bb);
+            if (chain_ok) {
+                Plane& out = use_a ? oa : ob;
+                const bool first = *bl == 'a';
+                if (!t1_ready) BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, first ? first_stride : 1, false, true, nullptr));
+                if (first) BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
+                BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
+                Op& op2b = h->ops.back();
+                const Plane& shortcut = first ? sc : x;
+                const bool can = op2b.conv.ksplit <= 1 && !conv_igemm_uses_big_tile(op2b.conv) && op2b.conv.cout_pad == f1 && (f1 == 64 || f1 == 128);
+                if (!can) {                      // (split-K at batch 1, ...): the separate launches
+                    BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &shortcut));
+                    t1_ready = false;
+                } else {
+                    PackedConv p2c;
+                    BODCHK(pack_conv(h, c_ + "2c", b_ + "2c", 64, &p2c));
+                    if (p2c.cin != f1 || p2c.cout != f3 || p2c.taps != 1 || p2c.cout_pad != f3)
+                        return h->fail(BOD_ERR_INVALID_ARG, "conv '%s2c' must be 1x1 %d->%d", cb, f1, f3);
+                    ConvGroup& G = op2b.conv.g[0];
+                    G.ch_w2 = p2c.w; G.ch_b2 = p2c.bias; G.ch_res = shortcut.d; G.ch_out = out.d; G.ch_c2 = f3;
+                    op2b.flops += 2.0 * op2b.conv.M * (double)f3 * f1;
+                    op2b.name += "+2c"; op2b.wname[1] = c_ + "2c"; op2b.bnname[1] = b_ + "2c";
+                    t1_ready = false;
+                    if (bl[1] != 0) {            // the next block of the stage: its 2a (stride 1) rides along, into the other t1 plane
+                        char nb[64], nbb[64];
+                        snprintf(nb, sizeof nb, "res%d%c_branch2a", st, bl[1]);
+                        snprintf(nbb, sizeof nbb, "bn%d%c_branch2a", st, bl[1]);
+                        PackedConv p2a;
+                        BODCHK(pack_conv(h, nb, nbb, 64, &p2a));
+                        if (p2a.cin != f3 || p2a.cout != f1 || p2a.taps != 1 || p2a.cout_pad != f1)
+                            return h->fail(BOD_ERR_INVALID_ARG, "conv '%s' must be 1x1 %d->%d", nb, f3, f1);
+                        G.ch_w3 = p2a.w; G.ch_b3 = p2a.bias; G.ch_out3 = t1alt.d;
+                        op2b.flops += 2.0 * op2b.conv.M * (double)f1 * f3;
+                        op2b.name += std::string("+") + nb; op2b.wname[2] = nb; op2b.bnname[2] = nbb;
+                        std::swap(t1, t1alt);
+                        t1_ready = true;
+                    }
+                }
+                if (first && (st == 3 || st == 4)) {
+                    taps[st] = out;
+                    Plane fresh;
+                    BODCHK(new_plane(h, &fresh, B, hh, ww, f3));
+                    x = out;
+                    if (use_a) oa = fresh; else ob = fresh;
+                    use_a = !use_a;
+                    continue;
+                }
+                x = out;
+                use_a = !use_a;
+                continue;
+            }
             if (train_mode) {                   // training keeps every activation: fresh planes per block
                 BODCHK(new_plane(h, &t1, B, hh, ww, f1));
                 BODCHK(new_plane(h, &t2, B, hh, ww, f1));

@@ -41,6 +41,13 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     int32_t agg_C;         // classes (AGG_CLS) -- 4 or 8
     float* agg_out;
     const float* anchors;  // [A,4] (v,u,h,w): box decode of AGG_BOX
+    // Bottleneck chain (ResNet stages 2-3, bf16 inference; 64x128 / 128x128 tiles whose cout tile holds ALL couts of this 3x3 conv):
+    // the finished tile of this group's conv -- a block's `2b` -- stays in LDS and feeds the block's 1x1 expansion `2c`
+    // (ch_w2: [ch_c2][cout] bf16, + bias + shortcut ch_res + ReLU -> plane ch_out) and, on that result, the NEXT block's 1x1
+    // reduction `2a` (ch_w3: [cout][ch_c2] bf16, + bias + ReLU -> plane ch_out3; optional).  All planes share this conv's output
+    // geometry (pixel index = RowEnt.out_off); the 2b output itself is not stored.  feature_extractor.py:195-213,283-309.
+    const void* ch_w2; const float* ch_b2; const void* ch_res; void* ch_out; int32_t ch_c2;
+    const void* ch_w3; const float* ch_b3; void* ch_out3;
 };
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
 
@@ -100,6 +107,7 @@ struct PerDeviceOnce {
 
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible
+bool conv_igemm_uses_big_tile(const ConvArgs& a);         // true => the 256x256 tile (any cout); false => 128-pixel tiles
 void conv_igemm_phase_cycles(unsigned long long* out16, bool reset);   // instrumented build (variant 90)
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
 

@@ -25,6 +25,8 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb0EE",     # backbone / FPN, big tile
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb0EE",     # fan-out layer, small layers, split-K
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb0EE",
+    "conv_igemm_kernelILi64ELi128ELi1ELi4ELi10ELb0ELb0EE",     # bottleneck chain (2b -> 2c + shortcut -> next 2a), stage 2 / stage 3
+    "conv_igemm_kernelILi128ELi128ELi2ELi2ELi10ELb0ELb0EE",
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb1EE",     # bf16x3 precision: the three tile configurations
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",

@@ -144,16 +144,21 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
     # head-tower conv (median of 3 after a warm-up) and keep the fastest
     import torch.nn.functional as F
     ncpu = os.cpu_count() or 1
-    probe_x = torch.randn(n, 256, hw[0] // 8, hw[1] // 8)
+    # (the probe walks ALL FIVE pyramid levels of one tower conv at the MC batch: on 128-core hosts the biggest pool wins the P3 map
+    # alone and loses the whole forward to the 32x32 .. 4x4 maps, where its fork/join costs more than the conv -- 0.17 instead of 0.4-0.6
+    # frames/s on round 3's boxes with the single-map probe)
+    probe_xs = [torch.randn(n, 256, max(1, -(-hw[0] // (1 << l))), max(1, -(-hw[1] // (1 << l)))) for l in range(3, 8)]
     best = (float("inf"), 1)
     for cand in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(cand)
         with torch.no_grad():
-            F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
+            for px in probe_xs:
+                F.conv2d(px, tw["pyramid_classification_0"][0], padding=1)
             ts = []
             for _ in range(3):
                 t0 = time.perf_counter()
-                F.conv2d(probe_x, tw["pyramid_classification_0"][0], padding=1)
+                for px in probe_xs:
+                    F.conv2d(px, tw["pyramid_classification_0"][0], padding=1)
                 ts.append(time.perf_counter() - t0)
         dt = sorted(ts)[1]
         if dt < best[0]:

@@ -26,6 +26,12 @@ def test_production_conv_kernels_do_not_spill(conv_object, tmp_path):
     guard.check_no_spills(meta)
     for want in guard.PRODUCTION:
         assert any(want in n for n in meta), want
+    # the bottleneck-chain builds must keep the residency of the kernels they replace: 3 / 2 workgroups (waves per SIMD) per CU
+    for n, f in meta.items():
+        if "ELi64ELi128ELi1ELi4ELi10E" in n:
+            assert f["vgpr_count"] <= 168, (n, f)
+        if "ELi128ELi128ELi2ELi2ELi10E" in n:
+            assert f["vgpr_count"] <= 256, (n, f)
     # the 8-wave 256x256 tiles run two waves per SIMD: at most 256 registers per lane
     for n, f in meta.items():
         if any(w in n for w in guard.PRODUCTION) and "ILi256ELi256ELi2ELi4E" in n:
