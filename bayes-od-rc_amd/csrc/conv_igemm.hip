@@ -1776,13 +1776,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         *reinterpret_cast<uint2*>(pp) = o;
                     }
                 };
+                // (requesting the next 2a's 16 weight fragments of the pass here, ahead of their use, needs two workgroups per CU instead
+                // of three -- 64 more registers -- and measured 0.7 ms slower per 256 frames than fetching them three at a time)
+                constexpr bool PRE3 = false;
+                bf16x8 a3[1];
                 {
                     const f32x16 a0 = gemm2(0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();                      // every wave's shortcut pieces have landed
                     finish(0, a0);
                 }
-#pragma unroll 1
+#pragma unroll
                 for (int f = 1; f < 4; ++f) { const f32x16 af_ = gemm2(f); finish(f, af_); }
                 if (has3) {                               // next block's 2a on this pass's 128 channels (own rows: no barrier needed)
 #pragma unroll
@@ -1790,7 +1794,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         const bf16x8 yb = *reinterpret_cast<const bf16x8*>(Yt + mypix * 256 + ((((ks * 2 + fhalf) ^ mypix) & 15) << 4));
 #pragma unroll
                         for (int f = 0; f < F3; ++f) {
-                            const bf16x8 af = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(f * 32 + frow) * C2 + q * 128 + ks * 16 + fhalf * 8);
+                            bf16x8 af;
+                            if constexpr (PRE3) af = a3[ks * 2 + f];
+                            else af = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(f * 32 + frow) * C2 + q * 128 + ks * 16 + fhalf * 8);
                             acc3[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, yb, acc3[f], 0, 0, 0);
                         }
                     }
