@@ -117,8 +117,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         cur ^= 1;
     }
 
-    // ---- epilogue: bias (+residual) (+ReLU) (+dropout, optional N-way fan-out) -> fp32
-    const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT;
+    // ---- epilogue: bias (+residual) (+ReLU) (+dropout, optional N-way fan-out) -> fp32; CONV_ACCUM adds to what the output
+    // already holds (the input-gradient GEMMs of the fp32 training handle)
+    const bool relu = a.flags & CONV_RELU, drop = a.flags & CONV_DROPOUT, accum = a.flags & CONV_ACCUM;
     const float* res = reinterpret_cast<const float*>(G.res);
     float* out = reinterpret_cast<float*>(G.out);
     float* out_relu = reinterpret_cast<float*>(G.out_relu);
@@ -161,6 +162,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
                         w[3] = (w1 >> 16) >= a.drop_threshold ? v[3] * a.drop_scale : 0.f;
                     }
                     const size_t o = ((size_t)e0.z + (size_t)n * a.fan_stride) * a.out_cstride + co;
+                    if (accum) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (co + q < a.cout_valid) w[q] += out[o + q];
+                    }
                     if (vec_ok) {
                         *reinterpret_cast<float4*>(out + o) = make_float4(w[0], w[1], w[2], w[3]);
                         if (out_relu)

@@ -1091,8 +1091,8 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
         (c.mc_ensemble_size > 0 && c.mc_sample_base + c.mc_samples > c.mc_ensemble_size))
         return bail(h->fail(BOD_ERR_INVALID_ARG, "mc_sample_base=%d / mc_samples=%d / mc_ensemble_size=%d inconsistent",
                             c.mc_sample_base, c.mc_samples, c.mc_ensemble_size));
-    if (c.training && (c.precision != BOD_PRECISION_BF16 || c.mc_samples != 1))
-        return bail(h->fail(BOD_ERR_INVALID_ARG, "training handles run in bf16 precision with mc_samples = 1 (dropout stays on)"));
+    if (c.training && ((c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32) || c.mc_samples != 1))
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "training handles run in bf16 (or, for gradient verification, fp32) precision with mc_samples = 1 (dropout stays on)"));
     if (c.backbone_depth != 0 && c.backbone_depth != 50 && c.backbone_depth != 101)
         return bail(h->fail(BOD_ERR_INVALID_ARG, "backbone_depth must be 50 or 101, got %d", c.backbone_depth));
     if (c.num_classes != 4 && c.num_classes != 8)

@@ -236,7 +236,7 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 // Training-step building blocks (train_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
-                                   int taps, int KW, bool append_ones_row, hipStream_t s);
+                                   int taps, int KW, bool append_ones_row, hipStream_t s, bool f32 = false);
 hipError_t launch_fill_row_bf16(void* row, int n_set, int n_total, float value, hipStream_t s);
 
 struct FoldArgs {
@@ -250,6 +250,7 @@ struct FoldArgs {
     uint16_t* w_bwd;            // [(tap, ci)][cout_pad] bf16 (or nullptr)
     uint16_t* w_flip;           // [cin][taps, flipped][cout_pad] bf16: the input gradient of a stride-1 SAME layer as a convolution (or nullptr)
     float* b_fwd;               // folded bias [cout_pad]
+    int32_t f32;                // fp32 training handle: the three packings above hold float (same layouts)
 };
 struct ActBwdArgs {
     const float* dout;          // gradient of the layer output, laid out like the output buffer
@@ -261,6 +262,7 @@ struct ActBwdArgs {
     uint16_t* dzt;              // the same values transposed, [cout_pad][Kpad] (columns M..Kpad-1 zero), or nullptr
     int32_t M, cout, cout_pad, out_cstride, res_cstride, Kpad;
     float scale;                // dropout keep scale (1 without dropout)
+    int32_t f32;                // fp32 training handle: out_bf16 / dz / dzp hold float, dzt is not written
 };
 struct UnfoldArgs {
     const float* dwp;           // [(taps*cin) + 1][cout]: folded-weight gradient, last row = folded-bias gradient
@@ -277,10 +279,10 @@ hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s);
 hipError_t launch_fold_pack_all(const FoldArgs* device_array, int count, long max_elems, hipStream_t s);
 // *wrote_transpose tells the caller whether a.dzt was produced by the same launch (tile form) or still needs a transpose pass
 hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s, bool* wrote_transpose = nullptr);
-hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s);
+hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s, bool f32 = false);
 hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin, int in_cstride, hipStream_t s);
 hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,
-                                     int pool_plane, hipStream_t s);
+                                     int pool_plane, hipStream_t s, bool f32 = false);
 hipError_t launch_unfold_grad(const UnfoldArgs& a, hipStream_t s);
 hipError_t launch_l2_grad(const float* w, float* g, long n, float rate, float* loss_acc, hipStream_t s);
 hipError_t launch_sumsq(const float* g, long n, float* acc, float* partial1024, hipStream_t s);

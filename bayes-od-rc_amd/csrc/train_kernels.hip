@@ -10,17 +10,21 @@
 
 // out[(tap*C + c)][m] = in[(rows[m].in_off + ky*rows[m].in_pitch + kx) * cstride + c]   (rows == nullptr: in_off = m)
 // for m < M, zero for M <= m < Kpad.  64 x 64 (m x c) tiles through LDS: reads are contiguous in c, writes in m.
-__global__ __launch_bounds__(256) void gather_transpose_kernel(const uint16_t* in, const RowEnt* rows, uint16_t* out,
+template <typename T> struct OneOf;
+template <> struct OneOf<uint16_t> { static __device__ uint16_t v() { return (uint16_t)0x3F80; } };      // bf16 1.0
+template <> struct OneOf<float> { static __device__ float v() { return 1.0f; } };
+template <typename T>
+__global__ __launch_bounds__(256) void gather_transpose_kernel(const T* in, const RowEnt* rows, T* out,
                                                                int M, int Kpad, int C, int cstride, int KW, int ones_row) {
-    __shared__ uint16_t tile[64][66];
+    __shared__ T tile[64][65 + (sizeof(T) == 2)];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
     if (ones_row >= 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64 && m0 + (int)threadIdx.x < Kpad)
-        out[(size_t)ones_row * Kpad + m0 + threadIdx.x] = m0 + (int)threadIdx.x < M ? (uint16_t)0x3F80 : (uint16_t)0;      // bf16 1.0: the bias-gradient row
+        out[(size_t)ones_row * Kpad + m0 + threadIdx.x] = m0 + (int)threadIdx.x < M ? OneOf<T>::v() : (T)0;      // 1.0: the bias-gradient row
     const int ky = tap / KW, kx = tap - ky * KW;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 4 rows of 64 threads
     for (int r = ty; r < 64; r += 4) {
         const int m = m0 + r, c = c0 + tx;
-        uint16_t v = 0;
+        T v = (T)0;
         if (m < M && c < C) {
             long pix = m;
             if (rows) { const RowEnt e = rows[m]; pix = (long)e.in_off + (long)ky * e.in_pitch + kx; }
@@ -105,9 +109,14 @@ __global__ void fill_row_bf16_kernel(uint16_t* row, int n_set, int n_total, uint
 }
 
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,
-                                   int taps, int KW, bool append_ones_row, hipStream_t s) {
+                                   int taps, int KW, bool append_ones_row, hipStream_t s, bool f32) {
     const int ones_row = append_ones_row ? taps * C : -1;
     dim3 grid((Kpad + 63) / 64, (C + 63) / 64, taps);
+    if (f32) {                                    // fp32 training handle (gradient verification mode): the generic form only
+        hipLaunchKernelGGL(gather_transpose_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const float*>(in), rows,
+                           reinterpret_cast<float*>(out), M, Kpad, C, cstride, KW, ones_row);
+        return hipGetLastError();
+    }
     if (C % 8 == 0 && cstride % 8 == 0 && Kpad % 8 == 0) {
         hipLaunchKernelGGL(gather_transpose_vec_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
                            reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, ones_row);
@@ -119,7 +128,7 @@ hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out
                            reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, NR, ones_row);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(gather_transpose_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
+    hipLaunchKernelGGL(gather_transpose_kernel<uint16_t>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in), rows,
                        reinterpret_cast<uint16_t*>(out), M, Kpad, C, cstride, KW, ones_row);
     return hipGetLastError();
 }
@@ -141,8 +150,28 @@ __device__ __forceinline__ uint16_t f2bf_dev(float f) {
     return (uint16_t)(u >> 16);
 }
 
+template <typename T> struct El;
+template <> struct El<uint16_t> { static __device__ __forceinline__ float ld(uint16_t v) { return bf2f_dev(v); } static __device__ __forceinline__ uint16_t st(float f) { return f2bf_dev(f); } };
+template <> struct El<float> { static __device__ __forceinline__ float ld(float v) { return v; } static __device__ __forceinline__ float st(float f) { return f; } };
+
 // Per step: fp32 master weights (HWIO) + BatchNorm parameters -> the forward packing [cout_pad][taps][cin] (bf16), the
 // folded bias (fp32) and the input-gradient packing [(tap, ci)][cout_pad] (bf16, no flip: it is used as a plain GEMM).
+// one folded weight into the layer's packings (i = its index in the forward layout [cout_pad][taps][cin]); fp32 packings for
+// the fp32 training handle, bf16 otherwise
+__device__ __forceinline__ void fold_store(const FoldArgs& a, long i, int t, int ci, int co, float v) {
+    const size_t ib = ((size_t)t * a.cin + ci) * a.cout_pad + co, ifl = ((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co;
+    if (a.w_fwd32 && co < a.cout) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;      // stem: fp32 [tap*cin][cout]
+    if (a.f32) {
+        if (a.w_fwd) reinterpret_cast<float*>(a.w_fwd)[i] = v;
+        if (a.w_bwd) reinterpret_cast<float*>(a.w_bwd)[ib] = v;
+        if (a.w_flip) reinterpret_cast<float*>(a.w_flip)[ifl] = v;
+    } else {
+        if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
+        if (a.w_bwd) a.w_bwd[ib] = f2bf_dev(v);
+        if (a.w_flip) a.w_flip[ifl] = f2bf_dev(v);
+    }
+}
+
 __global__ __launch_bounds__(256) void fold_pack_kernel(FoldArgs a) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long n = (long)a.cout_pad * a.taps * a.cin;
@@ -155,10 +184,7 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(FoldArgs a) {
             const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
             v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
         }
-        if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
-        if (a.w_fwd32) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;      // stem: fp32 [tap*cin][cout]
-        if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
-        if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
+        fold_store(a, i, t, ci, co, v);
     }
     if (i < a.cout_pad) {
         float b = 0.f;
@@ -173,20 +199,24 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(FoldArgs a) {
 // dZ[m][co] (dense bf16, cout_pad columns) = dOut[out_off(m)][co] * (mask from the stored output); the same value is
 // what the residual input of the layer receives (out = act(conv + res)), scattered with atomics because a nearest-
 // upsampled residual (FPN) is read by several output pixels.
+template <typename T>
 __global__ __launch_bounds__(256) void act_backward_gather_kernel(ActBwdArgs a) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)a.M * a.cout_pad) return;
     const int m = (int)(i / a.cout_pad), co = (int)(i % a.cout_pad);
+    const T* out_act = reinterpret_cast<const T*>(a.out_bf16);
+    T* dz = reinterpret_cast<T*>(a.dz);
+    T* dzp = reinterpret_cast<T*>(a.dzp);
     float g = 0.f;
     if (co < a.cout) {
         const RowEnt e = a.rows[m];
         const size_t o = (size_t)e.out_off * a.out_cstride + co;
         g = a.dout[o];
-        if (a.out_bf16) { if (bf2f_dev(a.out_bf16[o]) == 0.f) g = 0.f; else g *= a.scale; }
+        if (out_act) { if (El<T>::ld(out_act[o]) == 0.f) g = 0.f; else g *= a.scale; }
         if (a.dres && g != 0.f) atomicAdd(a.dres + (size_t)e.res_off * a.res_cstride + co, g);
-        if (a.dzp) a.dzp[o] = f2bf_dev(g);
+        if (dzp) dzp[o] = El<T>::st(g);
     }
-    a.dz[i] = f2bf_dev(g);
+    dz[i] = El<T>::st(g);
 }
 
 // 8 channels per thread (cout, cout_pad and both pixel strides multiples of 8)
@@ -287,9 +317,10 @@ __global__ __launch_bounds__(256) void act_backward_tile_kernel(ActBwdArgs a) {
 }
 
 // second consumer of a layer's output through its ReLU'd copy (P6 -> relu -> P7): dOut += dOutRelu * [out > 0]
-__global__ __launch_bounds__(256) void relu_merge_kernel(const float* dout_relu, const uint16_t* out, float* dout, long n) {
+template <typename T>
+__global__ __launch_bounds__(256) void relu_merge_kernel(const float* dout_relu, const T* out, float* dout, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && bf2f_dev(out[i]) > 0.f) dout[i] += dout_relu[i];
+    if (i < n && El<T>::ld(out[i]) > 0.f) dout[i] += dout_relu[i];
 }
 
 // col2im: dIn[(in_off(m) + ky*pitch + kx)][ci] += dXcol[m][(tap, ci)]
@@ -310,7 +341,30 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* dxcol, const R
 
 // ZeroPadding2D((1,2)) + MaxPool 3x3 s2 backward: the gradient goes to the first maximum of the window in row-major
 // scan order (the element the forward kernel's strict '>' scan keeps); masked by the stem's ReLU.
-__global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t* stem_out, const float* dpool, uint16_t* dz, int B, int ih, int iw,
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<uint16_t>(const uint16_t* p, float v[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __uint_as_float((w[k >> 1] >> ((k & 1) * 16)) << 16);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float g[8]);
+template <> __device__ __forceinline__ void store8<uint16_t>(uint16_t* p, const float g[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf_dev(g[2 * k]) | ((uint32_t)f2bf_dev(g[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float g[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(g[0], g[1], g[2], g[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(g[4], g[5], g[6], g[7]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_backward_kernel(const T* stem_out, const float* dpool, T* dz, int B, int ih, int iw,
                                                                  int oh, int ow, int pool_pitch, int pool_plane) {
     // one thread per stem pixel and 8 channels: sum the pooled gradients of the (up to 4) windows whose arg-max it is
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -318,12 +372,11 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t*
     if (i >= n) return;
     const int c = (int)(i & 7) * 8;
     const int x = (int)((i >> 3) % iw), y = (int)((i >> 3) / iw % ih), b = (int)((i >> 3) / ((long)iw * ih));
-    const uint4 vq = *reinterpret_cast<const uint4*>(stem_out + i * 8);
-    const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
     float v[8], g[8];
+    load8<T>(stem_out + i * 8, v);
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = __uint_as_float((vw[k >> 1] >> ((k & 1) * 16)) << 16); g[k] = 0.f; any |= v[k] > 0.f; }
+    for (int k = 0; k < 8; ++k) { g[k] = 0.f; any |= v[k] > 0.f; }
     if (any) {
         // windows (oy, ox) cover padded rows 2oy..2oy+2 (pad 1 on top) and padded cols 2ox..2ox+2 (pad 2 on the left)
         for (int oy = y / 2; oy <= (y + 1) / 2 && oy < oh; ++oy) {
@@ -336,16 +389,13 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t*
                 for (int wy = 0; wy < 3; ++wy)
                     for (int wx = 0; wx < 3; ++wx) {
                         const int sy = 2 * oy + wy - 1, sx = 2 * ox + wx - 2;
-                        uint4 uq = make_uint4(0u, 0u, 0u, 0u);                   // zero padding (inputs are post-ReLU)
+                        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // zero padding (inputs are post-ReLU)
                         if (sy >= 0 && sy < ih && sx >= 0 && sx < iw)
-                            uq = *reinterpret_cast<const uint4*>(stem_out + (((size_t)b * ih + sy) * iw + sx) * 64 + c);
-                        const uint32_t uw[4] = {uq.x, uq.y, uq.z, uq.w};
+                            load8<T>(stem_out + (((size_t)b * ih + sy) * iw + sx) * 64 + c, u);
                         const bool before = sy < y || (sy == y && sx < x);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const float u = __uint_as_float((uw[k >> 1] >> ((k & 1) * 16)) << 16);
-                            if (u > v[k] || (u == v[k] && before)) first[k] = false;
-                        }
+                        for (int k = 0; k < 8; ++k)
+                            if (u[k] > v[k] || (u[k] == v[k] && before)) first[k] = false;
                     }
                 const float* dp = dpool + ((size_t)b * pool_plane + (size_t)(oy + 1) * pool_pitch + (ox + 1)) * 64 + c;
                 const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
@@ -355,10 +405,7 @@ __global__ __launch_bounds__(256) void stem_pool_backward_kernel(const uint16_t*
             }
         }
     }
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf_dev(g[2 * k]) | ((uint32_t)f2bf_dev(g[2 * k + 1]) << 16);
-    *reinterpret_cast<uint4*>(dz + i * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    store8<T>(dz + i * 8, g);
 }
 
 // dW'[n = (tap, ci)][co] and db'[co] (row N-1) of the folded layer -> gradients of the master parameters:
@@ -473,7 +520,7 @@ __global__ __launch_bounds__(256) void fold_pack_all_kernel(const FoldArgs* all)
             }
             a.b_fwd[i] = b;
         }
-    if (a.w_fwd32 || (a.cin & 63) || (a.cout_pad & 63)) {             // the stem (fp32 [tap*cin][cout], 3 input channels): element-wise
+    if (a.w_fwd32 || a.f32 || (a.cin & 63) || (a.cout_pad & 63)) {             // the stem (fp32 [tap*cin][cout], 3 input channels): element-wise
         const long n = (long)a.cout_pad * a.taps * a.cin;
         for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
             const int ci = (int)(i % a.cin);
@@ -484,10 +531,7 @@ __global__ __launch_bounds__(256) void fold_pack_all_kernel(const FoldArgs* all)
                 const float s = a.gamma ? a.gamma[co] / sqrtf(a.var[co] + a.eps) : 1.0f;
                 v = a.kernel[((size_t)t * a.cin + ci) * a.cout + co] * s;
             }
-            if (a.w_fwd) a.w_fwd[i] = f2bf_dev(v);
-            if (a.w_fwd32 && co < a.cout) a.w_fwd32[((size_t)t * a.cin + ci) * a.cout + co] = v;
-            if (a.w_bwd) a.w_bwd[((size_t)t * a.cin + ci) * a.cout_pad + co] = f2bf_dev(v);
-            if (a.w_flip) a.w_flip[((size_t)ci * a.taps + (a.taps - 1 - t)) * a.cout_pad + co] = f2bf_dev(v);
+            fold_store(a, i, t, ci, co, v);
         }
         return;
     }
@@ -528,6 +572,11 @@ hipError_t launch_fold_pack(const FoldArgs& a, hipStream_t s) {
 }
 hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s, bool* wrote_transpose) {
     if (wrote_transpose) *wrote_transpose = false;
+    if (a.f32) {                                  // fp32 training handle: one thread per element, fp32 dZ (the caller transposes)
+        const long n = (long)a.M * a.cout_pad;
+        hipLaunchKernelGGL(act_backward_gather_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.dzt && a.cout % 8 == 0 && a.cout_pad % 64 == 0 && a.out_cstride % 8 == 0 && a.Kpad % 64 == 0) {
         hipLaunchKernelGGL(act_backward_tile_kernel, dim3(a.Kpad / 64, a.cout_pad / 64), dim3(256), 0, s, a);
         if (wrote_transpose) *wrote_transpose = true;
@@ -540,11 +589,12 @@ hipError_t launch_act_backward_gather(const ActBwdArgs& a, hipStream_t s, bool* 
         return hipGetLastError();
     }
     const long n = (long)a.M * a.cout_pad;
-    hipLaunchKernelGGL(act_backward_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(act_backward_gather_kernel<uint16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s) {
-    hipLaunchKernelGGL(relu_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout_relu, reinterpret_cast<const uint16_t*>(out), dout, n);
+hipError_t launch_relu_merge(const float* dout_relu, const void* out, float* dout, long n, hipStream_t s, bool f32) {
+    if (f32) hipLaunchKernelGGL(relu_merge_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout_relu, reinterpret_cast<const float*>(out), dout, n);
+    else hipLaunchKernelGGL(relu_merge_kernel<uint16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout_relu, reinterpret_cast<const uint16_t*>(out), dout, n);
     return hipGetLastError();
 }
 hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int M, int taps, int KW, int cin, int in_cstride, hipStream_t s) {
@@ -553,9 +603,11 @@ hipError_t launch_col2im(const float* dxcol, const RowEnt* rows, float* din, int
     return hipGetLastError();
 }
 hipError_t launch_stem_pool_backward(const void* stem_out, const float* dpool, void* dz, int B, int ih, int iw, int oh, int ow, int pool_pitch,
-                                     int pool_plane, hipStream_t s) {
+                                     int pool_plane, hipStream_t s, bool f32) {
     const long n = (long)B * ih * iw * 8;
-    hipLaunchKernelGGL(stem_pool_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(stem_out), dpool,
+    if (f32) hipLaunchKernelGGL(stem_pool_backward_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float*>(stem_out), dpool,
+                                reinterpret_cast<float*>(dz), B, ih, iw, oh, ow, pool_pitch, pool_plane);
+    else hipLaunchKernelGGL(stem_pool_backward_kernel<uint16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(stem_out), dpool,
                        reinterpret_cast<uint16_t*>(dz), B, ih, iw, oh, ow, pool_pitch, pool_plane);
     return hipGetLastError();
 }

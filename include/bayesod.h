@@ -77,7 +77,9 @@ typedef struct {
     int32_t training;            /* 1: the handle also runs training steps (bod_train_step):
                                     every layer keeps its activation, dropout is on with mc_samples = 1
                                     (retinanet_model.py:113-147, training branch), fp32 master weights, gradients
-                                    and Adam moments live on the device.  bf16 precision only.                 */
+                                    and Adam moments live on the device.  precision = BOD_PRECISION_BF16 (the product) or
+                                    BOD_PRECISION_FP32 (the gradient-verification mode: same executor on fp32 tensors and
+                                    the exact-fp32 MFMA kernel; meets float64 autograd element-wise).           */
     int32_t backbone_depth;      /* 0 / 50: ResNet-50, the reference's only backbone (feature_extractor.py:6-9).  101: stage 4 with
                                     1 ConvBlock + 22 IdentityBlocks (layer names res4a .. res4w) -- BASELINE config 5's
                                     "ResNet-101", which has no counterpart in the reference.             */
