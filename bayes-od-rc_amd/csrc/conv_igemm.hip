@@ -2062,6 +2062,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     }
     if (a.flags & CONV_OUT_F32) {                    // fp32 result (weight gradients): per-channel validity
         float* o32 = reinterpret_cast<float*>(G.out) + (size_t)e.out_off * a.out_cstride + co;
+        if (a.flags & CONV_ACCUM) {                  // input gradients of the training step accumulate in place
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (co + k < a.cout_valid) o32[k] += v[k];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (co + k < a.cout_valid) o32[k] = v[k];
         return;
