@@ -210,6 +210,157 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __rest
     }
 }
 
+// Round 3: the same arithmetic (same MFMAs in the same order per accumulator: bit-identical outputs) with the operand reuse
+// the kernel above lacks.  There every MFMA reads its weight fragment (1 KB) AND a quarter of a pixel fragment from LDS --
+// 1.25 KB per MFMA against the 0.5 KB per MFMA slot the LDS pipe delivers to four SIMDs -- so the launch ran at the LDS issue
+// rate (1.85 ms at 256 frames of 512x512, 167 TF/s).  Here a task is 256 pixels of one output row, a wave owns 64 of them x
+// 64 channels = 4 x 4 fragments, ALL weights live in registers (11 k-steps x 4 cout fragments = 176 VGPRs, loaded once per
+// block through LDS) and a pixel fragment read from LDS feeds four MFMAs: 0.25 KB of LDS per MFMA.  One block per CU (about
+// 330 registers per lane); 16 independent accumulators per wave keep the matrix pipe issuing at one wave per SIMD.  The staging
+// is vectorised (16-byte loads, hardware bf16 packs, 8-byte LDS writes) and the outputs leave as whole 128-byte pixel rows
+// through a per-wave LDS tile.  Measured at 256 frames of 512x512: op trace 1.42-1.86 -> 1.19-1.39 ms; in the pipelined step
+// the backbone stage moves by 0.2 ms (25.5 -> 25.3): the old kernel's steady-state time is the low end of its trace range.
+constexpr int SR_SEG = 256;                               // output pixels per task (4 waves x 4 fragments x 16)
+constexpr int SR_ROWF = 2 * SR_SEG * 3 + 5 * 3 + 5;       // 1556 floats: (2*255+7)*3 = 1551 real + 3 zero-weight k slots, padded
+constexpr int SR_ROWE = 1560;                             // uint16 per staged LDS row
+constexpr int SR_PLANE = 7 * SR_ROWE;                     // one (hi or lo) plane of a buffer
+constexpr int SR_LDS_BYTES = 2 * 2 * SR_PLANE * 2;        // [buffer][hi / lo][ky][element] = 87 360 B; the weight table aliases buffer 1
+constexpr int SR_LDS_TOTAL = SR_LDS_BYTES + 4 * 8192;     // + one 8 KB epilogue tile per wave
+
+__global__ __launch_bounds__(256, 1) void stem_conv_bf16_row_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                                    int B, int H, int W, int oh, int ow) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sr_smem[];
+    uint16_t* patch = sr_smem;                                          // [buf][plane][ky][SR_ROWE]
+    uint16_t (*wl)[SB_WROW] = reinterpret_cast<uint16_t (*)[SB_WROW]>(sr_smem + 2 * SR_PLANE);   // inside buffer 1, dead before its first use
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < 64 * SB_WROW; i += 256) {
+        const int co = i / SB_WROW, kp = i % SB_WROW;
+        const int c = kp >> 3, t = kp & 7, ky = c / 3, j = (c % 3) * 8 + t;
+        wl[co][kp] = (c < 21 && j < 21) ? (uint16_t)f32_to_bf16_a(w[(ky * 21 + j) * 64 + co]) : (uint16_t)0;
+    }
+    float bv[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[f][r] = bias[f * 16 + lq * 4 + r];
+
+    const int segs = (ow + SR_SEG - 1) / SR_SEG;
+    const int ntasks = B * oh * segs;
+    // staging: 16-byte loads of four consecutive row floats (rows start 16-byte aligned and end on a multiple of four floats:
+    // the launcher requires W % 4 == 0), the hi / lo split on the hardware pack v_cvt_pk_bf16_f32 (round-to-nearest-even, the
+    // same values as f32_to_bf16_a on finite inputs), 8-byte LDS writes
+    constexpr int ROWQ = SR_ROWF / 4;                                   // 389 quads per row
+    constexpr int PER = (7 * ROWQ + 255) / 256;                         // 11 staged quads per thread
+    static_assert(PER <= 11, "one staged quad per k-step");
+    auto fetch = [&](int task, float4 (&stage)[PER]) {
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        const float* src = img + ((size_t)b * H + 2 * oy) * W * 3 + (size_t)seg * SR_SEG * 2 * 3;
+        const int valid = W * 3 - seg * SR_SEG * 2 * 3;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / ROWQ, c = (i - r * ROWQ) * 4;
+            stage[q] = (i < 7 * ROWQ && c < valid) ? *reinterpret_cast<const float4*>(src + (size_t)r * W * 3 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
+    auto commit_piece = [&](int buf, int q, const float4 (&stage)[PER]) {      // one staged quad -> LDS as hi / lo bf16
+        uint16_t* pb = patch + buf * 2 * SR_PLANE;
+        const int i = tid + q * 256;
+        if (i >= 7 * ROWQ) return;
+        const int r = i / ROWQ, c = (i - r * ROWQ) * 4;
+        const float4 v = stage[q];
+        const uint32_t h0 = pk(v.x, v.y), h1 = pk(v.z, v.w);
+        const uint32_t l0 = pk(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xFFFF0000u));
+        const uint32_t l1 = pk(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xFFFF0000u));
+        *reinterpret_cast<uint2*>(pb + r * SR_ROWE + c) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pb + SR_PLANE + r * SR_ROWE + c) = make_uint2(l0, l1);
+    };
+    const int role = lq >> 1, k1 = lq & 1;                              // this lane's B source: plane, chunk parity
+    // (Measured and not kept: the next patch's conversion + LDS writes one quad per k-step behind that step's MFMAs, with one or
+    // two register stages -- 1.95 ms against 1.39 ms for the plain order below: at one wave per SIMD the interleaved VALU / LDS
+    // traffic delays the MFMA issue more than the overlap returns.)
+    float4 stage[PER];
+    int task = blockIdx.x, buf = 0;
+    const int g = gridDim.x;
+    if (task < ntasks) {
+        fetch(task, stage);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) commit_piece(0, q, stage);
+    }
+    __syncthreads();
+    stem_bf16x8_t aqr[11][4];
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) aqr[s][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wl[f * 16 + li][(2 * s + k1) * 8]);
+    __syncthreads();                                                    // the table's LDS becomes buffer 1
+    for (; task < ntasks; task += g, buf ^= 1) {
+        const int nxt = task + g;
+        if (nxt < ntasks) fetch(nxt, stage);
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[f][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const uint16_t* pb = patch + (buf * 2 + role) * SR_PLANE + (wave * 64 + li) * 6;
+        // (Measured and not kept: reading the four pixel fragments of k-step s+1 in front of the 16 MFMAs of step s, pinned with a
+        // scheduling barrier -- 1.62 ms against 1.39 ms for the compiler's own order below.)
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int c = 2 * s + k1;
+            const int cc = c < 21 ? c : 20;                             // chunk 21 has zero weights: any finite data will do
+            const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                union { uint32_t u[4]; stem_bf16x8_t v; } bq;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(pb + p * 96 + ky * SR_ROWE + j0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq.u[t] = src[t];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqr[s][f], bq.v, acc[f][p], 0, 0, 0);
+            }
+        }
+        const int seg = task % segs, oy = (task / segs) % oh, b = task / (segs * oh);
+        // epilogue through a per-wave LDS tile [64 pixels][128 B] (16-byte chunks XOR-swizzled by the pixel): a lane's 8-byte
+        // pieces of four channels become whole 128-byte pixel rows, stored 16 B per lane = 1 KB contiguous per instruction
+        // (the wave's 64 pixels are 8 KB contiguous in the NHWC plane; the accumulator layout gave 32-byte pieces per pixel)
+        char* et = reinterpret_cast<char*>(sr_smem) + SR_LDS_BYTES + wave * 8192;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int px = p * 16 + li;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                uint2 pkd;
+                pkd.x = pk(fmaxf(acc[f][p][0] + bv[f][0], 0.f), fmaxf(acc[f][p][1] + bv[f][1], 0.f));
+                pkd.y = pk(fmaxf(acc[f][p][2] + bv[f][2], 0.f), fmaxf(acc[f][p][3] + bv[f][3], 0.f));
+                const int chunk = f * 2 + (lq >> 1);
+                *reinterpret_cast<uint2*>(et + px * 128 + ((chunk ^ (px & 7)) << 4) + (lq & 1) * 8) = pkd;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int ox0 = seg * SR_SEG + wave * 64;
+            char* orow = reinterpret_cast<char*>(out + (((size_t)b * oh + oy) * ow + ox0) * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int px = i * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(et + px * 128 + ((ch ^ (px & 7)) << 4));
+                if (ox0 + px < ow) *reinterpret_cast<uint4*>(orow + px * 128 + ch * 16) = v;
+            }
+        }
+        if (nxt < ntasks) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) commit_piece(buf ^ 1, q, stage);
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s) {
     const int segs = (ow + ST_SEG - 1) / ST_SEG;
@@ -218,8 +369,24 @@ hipError_t launch_stem_conv(const float* img, const float* w, const float* bias,
     static const bool f32_stem = getenv("BOD_STEM_F32") && atoi(getenv("BOD_STEM_F32")) == 1;     // A/B aid: the exact-fp32 kernel in bf16 mode
     if (out_f32) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
     else if (f32_stem) hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
-    else hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(ntasks < 768 ? ntasks : 768), dim3(256), 0, s, img, w, bias,
-                            reinterpret_cast<uint16_t*>(out), B, H, W, oh, ow);
+    else {
+        static const bool old_stem = getenv("BOD_STEM_SEG64") && atoi(getenv("BOD_STEM_SEG64")) == 1;   // A/B aid: the 64-pixel-task kernel (bit-identical outputs)
+        if (old_stem || (W & 3)) {
+            hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(ntasks < 768 ? ntasks : 768), dim3(256), 0, s, img, w, bias,
+                               reinterpret_cast<uint16_t*>(out), B, H, W, oh, ow);
+            return hipGetLastError();
+        }
+        static PerDeviceOnce once;
+        bool& attr_set = *once.slot();
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_bf16_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS_TOTAL);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        const int rtasks = B * oh * ((ow + SR_SEG - 1) / SR_SEG);
+        hipLaunchKernelGGL(stem_conv_bf16_row_kernel, dim3(rtasks < 256 ? rtasks : 256), dim3(256), SR_LDS_TOTAL, s, img, w, bias,
+                           reinterpret_cast<uint16_t*>(out), B, H, W, oh, ow);
+    }
     return hipGetLastError();
 }
 

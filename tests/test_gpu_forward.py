@@ -325,3 +325,39 @@ def test_bottleneck_chain_fusion_is_bit_identical():
             continue
         assert fused[k].shape == plain[k].shape and np.abs(plain[k]).max() > 0, k
         assert np.array_equal(fused[k], plain[k]), k
+
+
+def test_row_task_stem_kernel_is_bit_identical():
+    """The bf16-mode stem runs 256-pixel row tasks with the weights in registers since round 3 (aux_kernels.hip,
+    stem_conv_bf16_row_kernel: same MFMAs in the same k order per accumulator, hardware round-to-nearest-even packs).
+    BOD_STEM_SEG64=1 runs the 64-pixel-task kernel it replaces: the pyramid must not differ by one bit -- square frames, a
+    row of more than one 256-pixel segment with a ragged tail (624 -> 309 outputs), and a width that is not a multiple of
+    four (the launcher then keeps the old kernel in both runs)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b in (('a', (128, 128), 3), ('b', (192, 624), 2), ('c', (96, 1160), 1), ('d', (128, 126), 1)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=1))\n"
+            "    eng.load_weights(synthetic.make_weights())\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=4), seed=1, first_image_id=0)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for old in ("0", "1"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, BOD_STEM_SEG64=old), capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) == 20
+    for k in sorted(outs[0]):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k
