@@ -16,5 +16,8 @@ Pinning status:
     tests or fixtures.  The restatement follows the reference source plus the documented op
     semantics and is cross-checked by a second, independent restatement
     (``oracle/torch_ref.py``: PyTorch-CPU fp32 with explicit padding) and by hand-derivable
-    known answers.
+    known answers.  ``bayes_od.py`` is additionally checked against the reference's own
+    ``bayes_od_inference`` SOURCE executed under a NumPy stand-in for TensorFlow
+    (tests/test_reference_transcription.py): a transcription check of formulas and branches,
+    which leaves the op semantics -- and therefore the "unpinned" label -- where they were.
 """

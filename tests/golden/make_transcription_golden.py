@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Runs the reference's OWN ``bayes_od_inference`` (src/retina_net/experiments/inference_utils.py:13-217, with the box helpers of
+src/retina_net/anchor_generator/box_utils.py it calls) under the NumPy stand-in for TensorFlow in tests/tools/tf_numpy_shim.py and
+stores inputs + outputs as ``tests/golden/posterior_transcription.npz``.  Build container only (``/root/reference`` must exist);
+data out, no reference source text.
+
+What the vectors pin: the TRANSCRIPTION of the reference function into oracle/bayes_od.py -- formulas, axes, mixing weights,
+branches (Dirichlet / Gaussian priors on and off, full / diagonal aleatoric covariance, no covariance head, KITTI rescale, both
+ranking methods).  What they do not pin: TensorFlow op semantics (stand-ins), ``Categorical.sample`` (the oracle's injected
+uniforms) and the soft-NMS (oracle/nms.py is called) -- see the stand-in's header.
+
+The model call is replaced by a stub returning seeded prediction tensors (the function's first statement is
+``prediction_dict = model(image, train_val_test='testing')``).
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("BAYESOD_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+
+CASES = [
+    # name, N, A, C, covar head, use_full_covar, dirichlet, gaussian, ranking, dataset
+    ("bdd_full", 10, 64, 8, True, True, "non_informative", "isotropic", "score", "bdd"),
+    ("bdd_diag", 10, 64, 8, True, False, "non_informative", "isotropic", "score", "bdd"),
+    ("bdd_nocov", 6, 48, 8, False, False, "non_informative", "isotropic", "score", "bdd"),
+    # (gaussian prior 'None' cannot be captured: the reference then leaves the likelihood means rank 2 and its own
+    #  tf.squeeze(gaussian_posterior_means, axis=2) at :204-205 raises -- under TensorFlow as under NumPy.  The build returns the
+    #  likelihood in that configuration, tests/test_bayes_oracle.py::test_posterior_known_answers.)
+    ("bdd_nodirichlet", 10, 64, 8, True, True, "None", "isotropic", "score", "bdd"),
+    ("bdd_entropy", 10, 64, 8, True, True, "non_informative", "isotropic", "joint_entropy", "bdd"),
+    ("kitti_full", 30, 48, 4, True, True, "non_informative", "isotropic", "score", "kitti"),
+    ("kitti_entropy", 30, 48, 4, True, True, "non_informative", "isotropic", "joint_entropy", "kitti"),
+]
+
+
+def make_inputs(seed, n, a, c, covar):
+    rng = np.random.default_rng(seed)
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)          # float32-valued inputs (stored as float32), float64 arithmetic
+    cls = rng.normal(0, 2.0, (n, a, c))
+    cls[:, : a // 2, : c - 1] += 3.0 * np.eye(c - 1)[rng.integers(0, c - 1, a // 2)][None]      # half the anchors lean to a foreground class
+    box = rng.normal(0, 0.3, (n, a, 4))
+    anchors = np.concatenate([rng.uniform(40, 300, (a, 2)), rng.uniform(20, 120, (a, 2))], axis=1)
+    pred = {"anchors_class_predictions": f32(cls), "anchors_box_predictions": f32(box)}
+    if covar:
+        raw = rng.normal(0, 0.4, (n, a, 4, 4))
+        pred["anchors_box_covar_predictions"] = f32(np.tril(raw))                              # fill_triangular output: lower triangle
+    uniforms = f32(rng.uniform(size=(a, 30)))
+    return pred, f32(anchors), uniforms
+
+
+def main():
+    import tf_numpy_shim
+    tf_numpy_shim.install()
+    sys.path.insert(0, REF)
+    from src.retina_net.experiments import inference_utils as ref
+    import src.core.constants as constants
+
+    out = {}
+    for ci, (name, n, a, c, covar, full, dirich, gauss, ranking, dataset) in enumerate(CASES):
+        pred, anchors, uniforms = make_inputs(100 + ci, n, a, c, covar)
+        cfg = {"ranking_method": ranking, "dirichlet_prior": {"type": dirich},
+               "gaussian_prior": {"type": gauss, "isotropic_variance": 100000.0}}
+        nms_cfg = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
+        net_hw = (384, 1248) if dataset == "kitti" else (512, 512)
+        sample = {constants.IMAGE_NORMALIZED_KEY: np.zeros((1, net_hw[0], net_hw[1], 3), np.float32),
+                  constants.ANCHORS_KEY: anchors[None],
+                  constants.ORIGINAL_IM_SIZE_KEY: np.asarray([[375, 1242, 3]], np.float64)}
+        tf_numpy_shim.set_uniforms(uniforms)
+        model = lambda image, train_val_test=None, p=pred: dict(p)
+        counts, means, covs, nms_idx, iou = ref.bayes_od_inference(model, sample, cfg, nms_cfg, use_full_covar=full, dataset_name=dataset)
+        for k, v in pred.items():
+            out["%s.in.%s" % (name, k)] = v.astype(np.float32)
+        out[name + ".in.anchors"], out[name + ".in.uniforms"] = anchors.astype(np.float32), uniforms.astype(np.float32)
+        out[name + ".out.counts"], out[name + ".out.means"], out[name + ".out.covs"] = np.asarray(counts), np.asarray(means), np.asarray(covs)
+        out[name + ".out.iou"], out[name + ".out.nms"] = np.asarray(iou), np.asarray(nms_idx)
+        print(name, "kept", np.asarray(counts).shape[0], "of", a, "nms", len(nms_idx))
+    tf_numpy_shim.set_uniforms(None)
+    np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "posterior_transcription.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

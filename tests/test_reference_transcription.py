@@ -1,0 +1,85 @@
+"""CPU: oracle/bayes_od.py against vectors produced by the reference's OWN ``bayes_od_inference`` source
+(src/retina_net/experiments/inference_utils.py:13-217) executed under a NumPy stand-in for TensorFlow
+(tests/tools/tf_numpy_shim.py, tests/golden/make_transcription_golden.py -> tests/golden/posterior_transcription.npz).
+
+This is a TRANSCRIPTION check: formulas, axes, mixing weights and branches of the reference function as written.  It does not
+pin TensorFlow's op semantics (stand-ins), the categorical sampler (the oracle's injected uniforms) or the soft-NMS
+(oracle/nms.py is what the stand-in calls): the oracle stays "parity unpinned" for SURVEY rows a1-a15."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import bayes_od, geometry, nms
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden", "posterior_transcription.npz")
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _cases():
+    import make_transcription_golden as gen
+    return gen.CASES
+
+
+@pytest.mark.parametrize("case", _cases(), ids=[c[0] for c in _cases()])
+def test_oracle_posterior_equals_the_reference_source_run_under_the_numpy_stand_in(case):
+    name, n, a, c, covar, full, dirich, gauss, ranking, dataset = case
+    z = np.load(GOLDEN)
+    pred = {k: z["%s.in.%s" % (name, k)].astype(np.float64)
+            for k in ("anchors_class_predictions", "anchors_box_predictions", "anchors_box_covar_predictions") if "%s.in.%s" % (name, k) in z.files}
+    assert ("anchors_box_covar_predictions" in pred) == covar
+    anchors, uniforms = z[name + ".in.anchors"].astype(np.float64), z[name + ".in.uniforms"].astype(np.float64)
+    cfg = {"ranking_method": ranking, "dirichlet_prior": {"type": dirich}, "gaussian_prior": {"type": gauss, "isotropic_variance": 100000.0}}
+    net = (384, 1248, 3) if dataset == "kitti" else (512, 512, 3)
+    out = bayes_od.bayes_od_posterior(pred, anchors, uniforms, cfg, use_full_covar=full, dataset_name=dataset, orig_size=(375, 1242, 3),
+                                      net_size=net, dtype=np.float64)
+    counts, means, covs = z[name + ".out.counts"], z[name + ".out.means"], z[name + ".out.covs"]
+    assert out["counts"].shape == counts.shape and 0 < counts.shape[0] < a            # some anchors filtered as background, some kept
+    assert np.array_equal(out["counts"], counts)                                      # Dirichlet posterior counts: exact
+    np.testing.assert_allclose(out["means"], means, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(out["covs"], covs, rtol=1e-9, atol=1e-12)
+    # bbox_iou_vuvu of the posterior corners with themselves (the affinity matrix of the clustering stage)
+    np.testing.assert_allclose(geometry.bbox_iou_vuvu(out["corners"], out["corners"]), z[name + ".out.iou"], rtol=1e-9, atol=1e-12)
+    # the ranking scores (max posterior score or the joint-entropy information gain) order the soft-NMS: same centres, same order
+    idx = nms.soft_nms(out["corners"], out["ranking"], max_output_size=100, iou_threshold=0.5, soft_nms_sigma=0.5)[0]
+    assert np.array_equal(np.asarray(idx), z[name + ".out.nms"])
+
+
+def test_the_gaussian_prior_none_branch_of_the_reference_raises():
+    """Finding of the transcription run: with gaussian_prior 'None' the reference keeps the likelihood means rank 2 and its own
+    tf.squeeze(..., axis=2) (:204-205) raises.  The build returns the likelihood instead (test_bayes_oracle.py)."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference tree not present (GPU box)")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import tf_numpy_shim; tf_numpy_shim.install()\n"
+            "sys.path.insert(0, '/root/reference')\n"
+            "import make_transcription_golden as gen\n"
+            "from src.retina_net.experiments import inference_utils as ref\n"
+            "import src.core.constants as constants\n"
+            "pred, anchors, u = gen.make_inputs(1, 4, 16, 8, True)\n"
+            "tf_numpy_shim.set_uniforms(u)\n"
+            "cfg = {'ranking_method': 'score', 'dirichlet_prior': {'type': 'None'}, 'gaussian_prior': {'type': 'None'}}\n"
+            "sample = {constants.IMAGE_NORMALIZED_KEY: np.zeros((1, 64, 64, 3)), constants.ANCHORS_KEY: anchors[None]}\n"
+            "try:\n"
+            "    ref.bayes_od_inference(lambda x, train_val_test=None: dict(pred), sample, cfg, {'max_output_size': 10, 'iou_threshold': 0.5, 'soft_nms_sigma': 0.5}, True, 'bdd')\n"
+            "except Exception as e:\n"
+            "    print('RAISED', type(e).__name__); sys.exit(0)\n"
+            "sys.exit(3)\n" % (os.path.dirname(HERE), os.path.join(HERE, "tools"), os.path.join(HERE, "golden")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "RAISED" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_vectors_regenerate_from_the_reference_source(tmp_path):
+    """Build container only: the committed vectors are what the reference source produces today."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference tree not present (GPU box)")
+    path = str(tmp_path / "regen.npz")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_transcription_golden.py"), path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(GOLDEN), np.load(path)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE: a NumPy stand-in for the handful of TensorFlow / TensorFlow-Probability calls that
+``bayes_od_inference`` makes (src/retina_net/experiments/inference_utils.py:13-277 and the box helpers it calls in
+src/retina_net/anchor_generator/box_utils.py), so that the reference's OWN SOURCE can be executed in the build container --
+which has no TensorFlow -- and its results compared with oracle/bayes_od.py (tests/golden/make_transcription_golden.py,
+tests/test_reference_transcription.py).
+
+What this pins and what it does not.  It pins the TRANSCRIPTION: every formula, axis, transpose, mixing weight and branch of
+the reference function is executed as written, so a mis-restated line in the oracle shows up.  It does NOT pin TensorFlow's
+op semantics -- each stand-in below follows the op's documented behaviour as the builder read it -- and the two stochastic /
+library pieces are injected: ``Categorical.sample`` draws from the oracle's uniforms and
+``tf.image.non_max_suppression_with_scores`` calls oracle/nms.py.  The oracle therefore stays "parity unpinned" for a1-a15.
+
+Never imported by the product; never shipped to the GPU box as anything but this file (the reference source it runs stays
+under /root/reference).
+"""
+import sys
+import types
+
+import numpy as np
+
+
+def _arr(x):
+    return x if isinstance(x, np.ndarray) else np.asarray(x)
+
+
+class _Categorical:
+    """tfp.distributions.Categorical(probs=p): .sample(n) -> [n, *batch] class indices.  The draws come from the uniforms
+    installed with ``set_uniforms`` by the oracle's rule: class = first c with cumsum(p)[c] > u * cumsum(p)[C-1]."""
+    uniforms = None
+
+    def __init__(self, probs=None, logits=None):
+        assert probs is not None and logits is None
+        self.probs = _arr(probs)
+
+    def sample(self, n):
+        u = _Categorical.uniforms
+        assert u is not None and u.shape == (self.probs.shape[0], n), "install uniforms [A, n] first"
+        a, c = self.probs.shape
+        cdf = np.zeros_like(self.probs)
+        acc = np.zeros(a, dtype=self.probs.dtype)
+        for j in range(c):
+            acc = acc + self.probs[:, j]
+            cdf[:, j] = acc
+        t = u.astype(self.probs.dtype) * cdf[:, -1:]
+        cls = np.minimum((cdf[:, None, :] <= t[:, :, None]).sum(axis=2), c - 1)
+        return cls.T.astype(np.int64)                      # [n, A]
+
+
+def set_uniforms(u):
+    _Categorical.uniforms = None if u is None else np.asarray(u)
+
+
+def _one_hot(indices, depth, on_value=1.0, off_value=0.0, axis=None, dtype=None):
+    idx = _arr(indices)
+    depth = int(depth)
+    out = np.where(idx[..., None] == np.arange(depth), on_value, off_value)
+    assert axis in (None, -1)
+    return out.astype(dtype or np.result_type(type(on_value), np.float32))
+
+
+def _boolean_mask(tensor, mask, axis=0):
+    t, m = _arr(tensor), _arr(mask).astype(bool)
+    axis = int(axis or 0)
+    assert m.ndim == 1
+    return np.compress(m, t, axis=axis)
+
+
+def _set_diag(x, diagonal):
+    out = np.array(_arr(x), copy=True)
+    d = _arr(diagonal)
+    n = min(out.shape[-2], out.shape[-1])
+    i = np.arange(n)
+    out[..., i, i] = d
+    return out
+
+
+def _diag_part(x):
+    return np.diagonal(_arr(x), axis1=-2, axis2=-1).copy()
+
+
+def _tensor_diag(d):
+    d = _arr(d)
+    assert d.ndim == 1
+    return np.diag(d)
+
+
+def _matmul(a, b, transpose_a=False, transpose_b=False):
+    a, b = _arr(a), _arr(b)
+    if transpose_a:
+        a = np.swapaxes(a, -1, -2)
+    if transpose_b:
+        b = np.swapaxes(b, -1, -2)
+    return np.matmul(a, b)
+
+
+def _softmax(x, axis=-1):
+    x = _arr(x)
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def _tile(x, multiples):
+    return np.tile(_arr(x), [int(m) for m in _arr(multiples).reshape(-1)])
+
+
+def _cast(x, dtype):
+    return _arr(x).astype(dtype)
+
+
+def _nms_with_scores(boxes, scores, max_output_size, iou_threshold=0.5, score_threshold=float("-inf"), soft_nms_sigma=0.0):
+    from oracle import nms as oracle_nms
+    idx, sc = oracle_nms.soft_nms(_arr(boxes), _arr(scores), max_output_size=int(max_output_size), iou_threshold=float(iou_threshold),
+                                  soft_nms_sigma=float(soft_nms_sigma))[:2]
+    return np.asarray(idx), np.asarray(sc)
+
+
+def install():
+    """Puts the stand-in modules into sys.modules (``tensorflow``, ``tensorflow_probability``)."""
+    tf = types.ModuleType("tensorflow")
+    tf.function = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    tf.float32, tf.float64, tf.int32, tf.int64 = np.float32, np.float64, np.int32, np.int64
+    tf.shape = lambda x: np.asarray(_arr(x).shape, dtype=np.int32)
+    tf.size = lambda x: np.int32(_arr(x).size)
+    tf.cast = _cast
+    tf.exp = lambda x: np.exp(_arr(x))
+    tf.equal = lambda a, b: np.equal(a, b)
+    tf.not_equal = lambda a, b: np.not_equal(a, b)
+    tf.maximum = lambda a, b: np.maximum(a, b)
+    tf.minimum = lambda a, b: np.minimum(a, b)
+    tf.argmax = lambda x, axis=None: np.argmax(_arr(x), axis=axis).astype(np.int64)
+    tf.reduce_mean = lambda x, axis=None, keepdims=False: np.mean(_arr(x), axis=axis, keepdims=keepdims)
+    tf.reduce_sum = lambda x, axis=None, keepdims=False: np.sum(_arr(x), axis=axis, keepdims=keepdims)
+    tf.reduce_max = lambda x, axis=None, keepdims=False: np.max(_arr(x), axis=axis, keepdims=keepdims)
+    tf.reduce_min = lambda x, axis=None, keepdims=False: np.min(_arr(x), axis=axis, keepdims=keepdims)
+    tf.one_hot = _one_hot
+    tf.boolean_mask = _boolean_mask
+    tf.zeros_like = lambda x: np.zeros_like(_arr(x))
+    tf.ones_like = lambda x: np.ones_like(_arr(x))
+    tf.matmul = _matmul
+    tf.tile = _tile
+    tf.expand_dims = lambda x, axis: np.expand_dims(_arr(x), axis)
+    tf.squeeze = lambda x, axis=None: np.squeeze(_arr(x), axis=axis)
+    tf.transpose = lambda x, perm=None: np.transpose(_arr(x), perm)
+    tf.stack = lambda xs, axis=0: np.stack([_arr(x) for x in xs], axis=axis)
+    tf.split = lambda x, n, axis=0: np.split(_arr(x), n, axis=axis)
+    tf.clip_by_value = lambda x, lo, hi: np.clip(_arr(x), lo, hi)
+    tf.nn = types.SimpleNamespace(softmax=_softmax)
+    tf.math = types.SimpleNamespace(log=lambda x: np.log(_arr(x)))
+    tf.linalg = types.SimpleNamespace(inv=lambda x: np.linalg.inv(_arr(x)), det=lambda x: np.linalg.det(_arr(x)), diag_part=_diag_part,
+                                      set_diag=_set_diag, tensor_diag=_tensor_diag)
+    tf.image = types.SimpleNamespace(non_max_suppression_with_scores=_nms_with_scores)
+    tf.keras = types.SimpleNamespace()
+    tfp = types.ModuleType("tensorflow_probability")
+    tfp.distributions = types.SimpleNamespace(Categorical=_Categorical)
+    sys.modules["tensorflow"] = tf
+    sys.modules["tensorflow_probability"] = tfp
+    for name, typ in (("int", int), ("float", float), ("bool", bool)):      # numpy aliases a few reference helpers still use
+        if not hasattr(np, name):
+            setattr(np, name, typ)
+    return tf, tfp
