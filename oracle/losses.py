@@ -1,7 +1,8 @@
 """Oracle restatement of the training-loss FORWARD of the reference (SURVEY.md row a19, App. A.10;
 BASELINE config 5): ``RetinaNetModel.get_loss`` (src/retina_net/models/retinanet_model.py:151-328)
 and ``SoftmaxFocalLoss.call`` (src/core/losses.py:30-61).  TF/Keras half => parity unpinned; checked by
-hand-derivable known answers (tests/test_losses_oracle.py)."""
+hand-derivable known answers (tests/test_losses_oracle.py) and, as a transcription check, against the reference's own
+``get_loss`` source run under a NumPy stand-in for TensorFlow / Keras (tests/test_reference_transcription.py)."""
 import numpy as np
 
 from . import geometry

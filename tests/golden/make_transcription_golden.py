@@ -53,6 +53,35 @@ def make_inputs(seed, n, a, c, covar):
     return pred, f32(anchors), uniforms
 
 
+LOSS_CASES = [
+    # name, B, A, C, loss_names, loss_weights  (configs/retinanet_bdd_covar.yaml: classification 5.0 / regression_covar 1.0)
+    ("loss_huber", 2, 40, 8, ["classification", "regression"], [5.0, 1.0]),
+    ("loss_var", 2, 40, 8, ["classification", "regression_var"], [5.0, 1.0]),
+    ("loss_covar", 3, 40, 8, ["classification", "regression_covar"], [5.0, 1.0]),
+    ("loss_covar_nopos", 1, 24, 4, ["classification", "regression_covar"], [1.0, 2.0]),
+]
+
+
+def make_loss_inputs(seed, b, a, c, with_pos=True):
+    rng = np.random.default_rng(seed)
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    anchors = np.concatenate([rng.uniform(40, 300, (a, 2)), rng.uniform(20, 120, (a, 2))], axis=1)
+    pos = (rng.uniform(size=(b, a)) < (0.2 if with_pos else 0.0)).astype(np.float64)
+    neg = ((rng.uniform(size=(b, a)) < 0.5) & (pos == 0)).astype(np.float64)
+    cls_t = np.zeros((b, a, c))
+    cls_t[..., c - 1] = 1.0
+    fg = rng.integers(0, c - 1, (b, a))
+    for i in range(b):
+        idx = np.nonzero(pos[i])[0]
+        cls_t[i, idx, c - 1] = 0.0
+        cls_t[i, idx, fg[i, idx]] = 1.0
+    sample = {"anchors": f32(anchors)[None], "positive_anchors_mask": pos, "negative_anchors_mask": neg,
+              "anchors_class_targets": cls_t, "anchors_box_targets": f32(rng.normal(0, 0.8, (b, a, 4)))}
+    pred = {"anchors_class_predictions": f32(rng.normal(0, 2.0, (b, a, c))), "anchors_box_predictions": f32(rng.normal(0, 0.8, (b, a, 4))),
+            "anchors_box_covar_predictions": f32(np.tril(rng.normal(0, 0.5, (b, a, 4, 4))))}
+    return sample, pred
+
+
 def main():
     import tf_numpy_shim
     tf_numpy_shim.install()
@@ -80,6 +109,23 @@ def main():
         out[name + ".out.iou"], out[name + ".out.nms"] = np.asarray(iou), np.asarray(nms_idx)
         print(name, "kept", np.asarray(counts).shape[0], "of", a, "nms", len(nms_idx))
     tf_numpy_shim.set_uniforms(None)
+    # ---- RetinaNetModel.get_loss (retinanet_model.py:151-328) with SoftmaxFocalLoss (src/core/losses.py:30-61): the method is
+    # called on a bare object carrying the four attributes its __init__ sets (:24-35), no network is built
+    from src.retina_net.models import retinanet_model as rm
+    import types
+    keras = sys.modules["tensorflow"].keras
+    for ci, (name, b, a, c, names, weights) in enumerate(LOSS_CASES):
+        sample, pred = make_loss_inputs(200 + ci, b, a, c, with_pos="nopos" not in name)
+        holder = types.SimpleNamespace(focal_loss=rm.SoftmaxFocalLoss(gamma=2.0, label_smoothing_epsilon=0.001, reduction=keras.losses.Reduction.NONE),
+                                       huber_loss=keras.losses.Huber(reduction=keras.losses.Reduction.NONE, name="huber_loss"),
+                                       loss_names=names, loss_weights=weights)
+        total, parts = rm.RetinaNetModel.get_loss(holder, sample, pred)
+        for k, v in list(sample.items()) + list(pred.items()):
+            out["%s.in.%s" % (name, k)] = np.asarray(v, np.float32)
+        out[name + ".out.total"] = np.float64(total)
+        for k, v in parts.items():
+            out["%s.out.%s" % (name, k)] = np.float64(v)
+        print(name, float(total), {k: float(v) for k, v in parts.items()})
     np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "posterior_transcription.npz"), **out)
 
 

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from oracle import bayes_od, geometry, nms
+from oracle import bayes_od, geometry, losses, nms
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden", "posterior_transcription.npz")
@@ -46,6 +46,33 @@ def test_oracle_posterior_equals_the_reference_source_run_under_the_numpy_stand_
     # the ranking scores (max posterior score or the joint-entropy information gain) order the soft-NMS: same centres, same order
     idx = nms.soft_nms(out["corners"], out["ranking"], max_output_size=100, iou_threshold=0.5, soft_nms_sigma=0.5)[0]
     assert np.array_equal(np.asarray(idx), z[name + ".out.nms"])
+
+
+def _loss_cases():
+    import make_transcription_golden as gen
+    return gen.LOSS_CASES
+
+
+@pytest.mark.parametrize("case", _loss_cases(), ids=[c[0] for c in _loss_cases()])
+def test_oracle_loss_equals_the_reference_get_loss_run_under_the_numpy_stand_in(case):
+    """RetinaNetModel.get_loss (retinanet_model.py:151-328) + SoftmaxFocalLoss.call (src/core/losses.py:30-61), executed from the
+    reference's source on a bare object (no network), against oracle/losses.py: the focal term, the three regression kinds
+    (Huber on targets; Huber on decoded boxes weighted by exp(-log D), without / with the Frobenius norm of the unit-diagonal L),
+    the normalisation by max(1, positives) and a batch without positives."""
+    name, b, a, c, names, weights = case
+    z = np.load(GOLDEN)
+    g = lambda k: z["%s.in.%s" % (name, k)].astype(np.float64)
+    sample = {k: g(k) for k in ("anchors", "positive_anchors_mask", "negative_anchors_mask", "anchors_class_targets", "anchors_box_targets")}
+    pred = {k: g(k) for k in ("anchors_class_predictions", "anchors_box_predictions", "anchors_box_covar_predictions")}
+    total, parts = losses.get_loss(sample, pred, names, weights, label_smoothing=0.001, dtype=np.float64)
+    want = {k.split(".out.")[1]: float(z[k]) for k in z.files if k.startswith(name + ".out.")}
+    assert set(parts) | {"total"} == set(want), (sorted(parts), sorted(want))
+    for k, v in parts.items():
+        assert abs(float(v) - want[k]) <= 1e-10 * max(1.0, abs(want[k])), (k, float(v), want[k])
+    # (the reference accumulates total_loss from tf.constant(0.0), a float32)
+    assert abs(float(total) - want["total"]) <= 2e-6 * max(1.0, abs(want["total"])), (float(total), want["total"])
+    if "nopos" in name:
+        assert want["reg_loss"] == 0.0 and want["cls_loss"] > 0
 
 
 def test_the_gaussian_prior_none_branch_of_the_reference_raises():

@@ -114,6 +114,71 @@ def _nms_with_scores(boxes, scores, max_output_size, iou_threshold=0.5, score_th
     return np.asarray(idx), np.asarray(sc)
 
 
+class _NameScope:
+    def __init__(self, *a, **k):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _Reduction:
+    NONE, SUM, AUTO, SUM_OVER_BATCH_SIZE = "none", "sum", "auto", "sum_over_batch_size"
+
+
+class _Loss:
+    """keras.losses.Loss with reduction NONE: __call__ returns call()'s per-sample values unreduced."""
+
+    def __init__(self, reduction=_Reduction.AUTO, name=None):
+        assert reduction == _Reduction.NONE, "only Reduction.NONE is stood in for"
+        self.reduction, self.name = reduction, name
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        assert sample_weight is None
+        return self.call(_arr(y_true), _arr(y_pred))
+
+
+class _CategoricalCrossentropy(_Loss):
+    """from_logits=True, label_smoothing=e: y = y_true * (1 - e) + e / C;  loss = -sum_c y * log_softmax(logits)."""
+
+    def __init__(self, from_logits=False, label_smoothing=0, reduction=_Reduction.AUTO, name="categorical_crossentropy"):
+        super().__init__(reduction=reduction, name=name)
+        assert from_logits
+        self.label_smoothing = label_smoothing
+
+    def call(self, y_true, y_pred):
+        c = y_true.shape[-1]
+        y = y_true * (1.0 - self.label_smoothing) + self.label_smoothing / c
+        z = y_pred - y_pred.max(axis=-1, keepdims=True)
+        ls = z - np.log(np.exp(z).sum(axis=-1, keepdims=True))
+        return -(y * ls).sum(axis=-1)
+
+
+class _Huber(_Loss):
+    """keras.losses.Huber as the reference USES it (retinanet_model.py:215-226: the result is reduced over axis 2 afterwards, so it
+    must still have that axis): the element-wise form of TensorFlow 2.0 / 2.1, the version the reference's README names --
+    0.5 e^2 for |e| <= delta, delta |e| - 0.5 delta^2 beyond.  (Later releases average over the last axis inside the loss.)"""
+
+    def __init__(self, delta=1.0, reduction=_Reduction.AUTO, name="huber_loss"):
+        super().__init__(reduction=reduction, name=name)
+        self.delta = delta
+
+    def call(self, y_true, y_pred):
+        e = y_pred - y_true
+        a = np.abs(e)
+        return np.where(a <= self.delta, 0.5 * e * e, self.delta * a - 0.5 * self.delta * self.delta)
+
+
+class _Anything:
+    """keras.layers.X / keras.regularizers.X ...: class bodies of the model files only need the names to exist at import."""
+
+    def __getattr__(self, name):
+        return type(name, (object,), {"__init__": lambda self, *a, **k: None})
+
+
 def install():
     """Puts the stand-in modules into sys.modules (``tensorflow``, ``tensorflow_probability``)."""
     tf = types.ModuleType("tensorflow")
@@ -149,7 +214,16 @@ def install():
     tf.linalg = types.SimpleNamespace(inv=lambda x: np.linalg.inv(_arr(x)), det=lambda x: np.linalg.det(_arr(x)), diag_part=_diag_part,
                                       set_diag=_set_diag, tensor_diag=_tensor_diag)
     tf.image = types.SimpleNamespace(non_max_suppression_with_scores=_nms_with_scores)
-    tf.keras = types.SimpleNamespace()
+    tf.name_scope = _NameScope
+    tf.constant = lambda v, dtype=None: np.asarray(v, dtype=dtype or (np.float32 if isinstance(v, float) else None))
+    tf.divide = lambda x, y, name=None: _arr(x) / y
+    tf.pow = lambda x, y: np.power(_arr(x), y)
+    tf.identity = lambda x: x
+    tf.linalg.norm = lambda x, ord="fro", axis=None: np.sqrt((_arr(x) ** 2).sum(axis=axis))
+    tf.keras = types.SimpleNamespace(
+        Model=type("Model", (object,), {"__init__": lambda self, *a, **k: None}), layers=_Anything(), regularizers=_Anything(),
+        backend=types.SimpleNamespace(learning_phase=lambda: 0),
+        losses=types.SimpleNamespace(Loss=_Loss, Reduction=_Reduction, CategoricalCrossentropy=_CategoricalCrossentropy, Huber=_Huber))
     tfp = types.ModuleType("tensorflow_probability")
     tfp.distributions = types.SimpleNamespace(Categorical=_Categorical)
     sys.modules["tensorflow"] = tf
