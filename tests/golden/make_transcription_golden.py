@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs the reference's OWN ``bayes_od_inference`` (src/retina_net/experiments/inference_utils.py:13-217, with the box helpers of
 src/retina_net/anchor_generator/box_utils.py it calls) under the NumPy stand-in for TensorFlow in tests/tools/tf_numpy_shim.py and
-stores inputs + outputs as ``tests/golden/posterior_transcription.npz``.  Build container only (``/root/reference`` must exist);
+stores inputs + outputs as ``tests/golden/reference_transcription.npz``.  Build container only (``/root/reference`` must exist);
 data out, no reference source text.
 
 What the vectors pin: the TRANSCRIPTION of the reference function into oracle/bayes_od.py -- formulas, axes, mixing weights,
@@ -82,6 +82,69 @@ def make_loss_inputs(seed, b, a, c, with_pos=True):
     return sample, pred
 
 
+FORWARD_CASES = [
+    # name, (H, W), MC samples, seed  -- one frame each (tf.tile over a batch of one = the oracle's per-frame repeat)
+    ("fwd_64_n3", (64, 64), 3, 11),
+    ("fwd_96x128_n2", (96, 128), 2, 12),
+    ("fwd_64_n1", (64, 64), 1, 13),            # mc_dropout_samples = 1: dropout off (retinanet_model.py:74-77)
+]
+
+
+def forward_inputs(hw, seed):
+    """Seeded weights and one normalised frame (the product's synthetic helpers: deterministic, so only outputs are stored)."""
+    sys.path.insert(0, ROOT)
+    from bayes_od_rc_amd import synthetic
+    return synthetic.make_weights(cls_fg_bias=-2.0), synthetic.make_frames(1, hw[0], hw[1], seed=seed).astype(np.float64)
+
+
+def forward_masks(hw, n, dropout_seed=5, image_id=0):
+    """The oracle's Philox keep masks as the (sample, layer id) -> [P, 256] callback oracle/network.py takes."""
+    from oracle import philox
+    sizes = []
+    h, w = hw
+    # pyramid level sizes p3..p7 for an H x W frame (SAME stride-2 chain from the stride-8 map)
+    lh, lw = -(-h // 8), -(-w // 8)
+    for _ in range(5):
+        sizes.append(lh * lw)
+        lh, lw = -(-lh // 2), -(-lw // 2)
+    ptotal = int(sum(sizes))
+    cache = {}
+
+    def km(sample, lid):
+        if (sample, lid) not in cache:
+            cache[(sample, lid)] = philox.dropout_keep_mask(dropout_seed, image_id, sample, lid, ptotal, 256, 0.3)
+        return cache[(sample, lid)]
+    return km, sizes
+
+
+def run_reference_forward(ref_model_module, yaml_model_config, weights, frame, n, hw):
+    """RetinaNetModel(model_config)(frame, 'testing') from the reference's source, layers standing in (tf_numpy_shim)."""
+    import copy
+    import tf_numpy_shim
+    from oracle.network import HEAD_ID
+    cfg = copy.deepcopy(yaml_model_config)
+    cfg["mc_dropout_samples"] = n
+    tf_numpy_shim.set_weights(weights)
+    model = ref_model_module.RetinaNetModel(cfg)
+    km, sizes = forward_masks(hw, n)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for head, hdr in (("cls", model.cls_header), ("reg", model.reg_header), ("cov", model.cov_header)):
+        for attr, obj in vars(hdr).items():
+            if attr.startswith("drop_"):
+                obj.tag = (head, int(attr.split("_")[1]) - 1)
+
+    def hook(layer, call_index, x):
+        head, k = layer.tag
+        lid = HEAD_ID[head] * 4 + k
+        nn, h, w, c = x.shape
+        assert nn == n and h * w == sizes[call_index], (x.shape, call_index, sizes)
+        return np.stack([km(s, lid)[offs[call_index]:offs[call_index + 1]] for s in range(n)]).reshape(n, h, w, c)
+    tf_numpy_shim.set_dropout_hook(hook)
+    out = model(frame, train_val_test="testing")
+    tf_numpy_shim.set_weights(None)
+    return out, km
+
+
 def main():
     import tf_numpy_shim
     tf_numpy_shim.install()
@@ -126,7 +189,21 @@ def main():
         for k, v in parts.items():
             out["%s.out.%s" % (name, k)] = np.float64(v)
         print(name, float(total), {k: float(v) for k, v in parts.items()})
-    np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "posterior_transcription.npz"), **out)
+    # ---- RetinaNetModel.__init__ / call('testing') (retinanet_model.py:18-112) with FeatureExtractor, FeatureDecoder and the three
+    # headers built and called from the reference's source (~600 lines of wiring); Keras layers stand in (see the stand-in's header)
+    import yaml
+    with open(os.path.join(REF, "src", "retina_net", "configs", "retinanet_bdd_covar.yaml")) as fp:
+        model_cfg = yaml.safe_load(fp)["model_config"]
+    model_cfg["header"]["num_classes"] = 7                 # config_utils.setup (:77-87): the 7 BDD categories, 3 scales x 3 aspect ratios
+    model_cfg["header"]["anchors_per_location"] = 9
+    import src.core.constants as constants
+    for name, hw, n, seed in FORWARD_CASES:
+        weights, frame = forward_inputs(hw, seed)
+        pred, _ = run_reference_forward(rm, model_cfg, weights, frame, n, hw)
+        for k in (constants.ANCHORS_CLASS_PREDICTIONS_KEY, constants.ANCHORS_BOX_PREDICTIONS_KEY, constants.ANCHORS_COVAR_PREDICTIONS_KEY):
+            out["%s.out.%s" % (name, k)] = np.asarray(pred[k], np.float32)           # (wiring errors are O(1): float32 storage is plenty)
+        print(name, {k: np.asarray(v).shape for k, v in pred.items()})
+    np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "reference_transcription.npz"), **out)
 
 
 if __name__ == "__main__":

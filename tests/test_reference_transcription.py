@@ -1,6 +1,6 @@
 """CPU: oracle/bayes_od.py against vectors produced by the reference's OWN ``bayes_od_inference`` source
 (src/retina_net/experiments/inference_utils.py:13-217) executed under a NumPy stand-in for TensorFlow
-(tests/tools/tf_numpy_shim.py, tests/golden/make_transcription_golden.py -> tests/golden/posterior_transcription.npz).
+(tests/tools/tf_numpy_shim.py, tests/golden/make_transcription_golden.py -> tests/golden/reference_transcription.npz).
 
 This is a TRANSCRIPTION check: formulas, axes, mixing weights and branches of the reference function as written.  It does not
 pin TensorFlow's op semantics (stand-ins), the categorical sampler (the oracle's injected uniforms) or the soft-NMS
@@ -15,7 +15,7 @@ import pytest
 from oracle import bayes_od, geometry, losses, nms
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = os.path.join(HERE, "golden", "posterior_transcription.npz")
+GOLDEN = os.path.join(HERE, "golden", "reference_transcription.npz")
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
@@ -73,6 +73,39 @@ def test_oracle_loss_equals_the_reference_get_loss_run_under_the_numpy_stand_in(
     assert abs(float(total) - want["total"]) <= 2e-6 * max(1.0, abs(want["total"])), (float(total), want["total"])
     if "nopos" in name:
         assert want["reg_loss"] == 0.0 and want["cls_loss"] > 0
+
+
+def _forward_cases():
+    import make_transcription_golden as gen
+    return gen.FORWARD_CASES
+
+
+@pytest.mark.parametrize("case", _forward_cases(), ids=[c[0] for c in _forward_cases()])
+def test_oracle_forward_equals_the_reference_model_wiring_run_under_the_layer_stand_ins(case):
+    """RetinaNetModel.__init__ + call('testing') with FeatureExtractor / ConvBlock / IdentityBlock, FeatureDecoder and the three
+    headers CONSTRUCTED AND CALLED from the reference's source (retinanet_model.py:18-112, feature_extractor.py, feature_decoder.py,
+    multitask_headers.py), Keras layers standing in with oracle/network.py's primitives and the oracle's Philox masks: checks the
+    wiring of oracle/network.py -- block order and strides, the taps, the FPN merges (m4 is upsampled into p3, not p4), P6 from C5
+    and P7 from relu(P6), RegHeader's three convolutions, MC tiling, dropout placement and on/off rule, the anchor-major reshape /
+    level concat, fill_triangular -- not the primitives themselves."""
+    import make_transcription_golden as gen
+    from oracle import network
+    name, hw, n, seed = case
+    z = np.load(GOLDEN)
+    weights, frame = gen.forward_inputs(hw, seed)
+    km, _ = gen.forward_masks(hw, n)
+    out = network.retinanet_forward(weights, frame, n, 8, mode="literal", dtype=np.float64, keep_masks=km)
+    for k in ("anchors_class_predictions", "anchors_box_predictions", "anchors_box_covar_predictions"):
+        want = z["%s.out.%s" % (name, k)].astype(np.float64)
+        assert out[k].shape == want.shape, (k, out[k].shape, want.shape)
+        assert np.abs(want).max() > 0
+        np.testing.assert_allclose(out[k], want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+    if n > 1:                      # MC samples differ (dropout on) ...
+        assert np.abs(out["anchors_class_predictions"][0] - out["anchors_class_predictions"][1]).max() > 1e-3
+    # ... and with one sample the reference turns dropout off: compare with a second evaluation without masks
+    if n == 1:
+        again = network.retinanet_forward(weights, frame, 1, 8, mode="literal", dtype=np.float64, keep_masks=None)
+        assert np.array_equal(again["anchors_box_predictions"], out["anchors_box_predictions"])
 
 
 def test_the_gaussian_prior_none_branch_of_the_reference_raises():

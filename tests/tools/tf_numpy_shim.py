@@ -173,10 +173,135 @@ class _Huber(_Loss):
 
 
 class _Anything:
-    """keras.layers.X / keras.regularizers.X ...: class bodies of the model files only need the names to exist at import."""
+    """keras.regularizers.X / keras.initializers.X ...: constructor arguments of the layers that the forward pass never reads."""
 
     def __getattr__(self, name):
         return type(name, (object,), {"__init__": lambda self, *a, **k: None})
+
+
+# ---- Keras layers for the model files (feature_extractor.py, feature_decoder.py, multitask_headers.py, retinanet_model.py):
+# the reference's __init__ / call graphs are executed as written; what a LAYER computes comes from oracle/network.py's primitives
+# (the builder's reading of the Keras / TF op semantics, SURVEY App. A) and the weights from ``set_weights``.  The comparison
+# therefore checks the WIRING -- which tensor feeds which layer, strides, names, the RegHeader's uncalled conv, MC tiling,
+# reshape / concat order -- not the primitives.
+_WEIGHTS = {}
+_DROPOUT_HOOK = [None]
+
+
+def set_weights(w):
+    _WEIGHTS.clear()
+    _WEIGHTS.update(w or {})
+
+
+def set_dropout_hook(fn):
+    """fn(dropout_layer, call_index, x) -> keep mask broadcastable to x (bool / 0-1)."""
+    _DROPOUT_HOOK[0] = fn
+
+
+class _Layer:
+    def __init__(self, *a, name=None, **k):
+        self.name = name
+
+    def __call__(self, *a, **k):
+        return self.call(*a, **k)
+
+
+class _Model(_Layer):
+    pass
+
+
+class _Conv2D(_Layer):
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", use_bias=True, activation=None, name=None, **k):
+        super().__init__(name=name)
+        assert activation in (None, "linear")
+        self.filters, self.kernel_size, self.use_bias = filters, tuple(np.atleast_1d(kernel_size)), use_bias
+        self.stride = int(np.atleast_1d(strides)[0])
+        assert all(int(v) == self.stride for v in np.atleast_1d(strides))
+        self.padding = padding
+
+    def call(self, x):
+        from oracle import network
+        w = _WEIGHTS[self.name]
+        k = np.asarray(w["kernel"], dtype=x.dtype)
+        assert k.shape[0] == self.kernel_size[0] and k.shape[-1] == self.filters, (self.name, k.shape, self.kernel_size, self.filters)
+        b = np.asarray(w["bias"], dtype=x.dtype) if (self.use_bias and w.get("bias") is not None) else None
+        return network.conv2d(x, k, b, self.stride, self.padding)
+
+
+class _BatchNormalization(_Layer):
+    def call(self, x, training=False):
+        from oracle import network
+        assert training is False or training == 0
+        return network.batchnorm_eval(x, _WEIGHTS[self.name])
+
+
+class _ZeroPadding2D(_Layer):
+    def __init__(self, padding=(1, 1), name=None, **k):
+        super().__init__(name=name)
+        self.padding = padding
+
+    def call(self, x):
+        ph, pw = self.padding                      # Keras: a tuple of 2 ints = symmetric (height, width) padding
+        return np.pad(x, ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+
+
+class _MaxPooling2D(_Layer):
+    def __init__(self, pool_size=(2, 2), strides=None, padding="valid", name=None, **k):
+        super().__init__(name=name)
+        self.pool, self.strides = tuple(pool_size), tuple(strides or pool_size)
+        assert padding == "valid"
+
+    def call(self, x):
+        (kh, kw), (sh, sw) = self.pool, self.strides
+        _, h, w, _ = x.shape
+        oh, ow = (h - kh) // sh + 1, (w - kw) // sw + 1
+        out = None
+        for ky in range(kh):
+            for kx in range(kw):
+                p = x[:, ky:ky + (oh - 1) * sh + 1:sh, kx:kx + (ow - 1) * sw + 1:sw, :]
+                out = p if out is None else np.maximum(out, p)
+        return out
+
+
+class _ReLU(_Layer):
+    def call(self, x):
+        return np.maximum(x, 0)
+
+
+class _Dropout(_Layer):
+    def __init__(self, rate=0.5, name=None, **k):
+        super().__init__(name=name)
+        self.rate, self.calls = rate, 0
+
+    def call(self, x, training=False):
+        i = self.calls
+        self.calls += 1
+        if not training:
+            return x
+        keep = _DROPOUT_HOOK[0](self, i, x)
+        return x * x.dtype.type(np.float32(1.0 / (1.0 - self.rate))) * np.asarray(keep, dtype=x.dtype)
+
+
+class _Layers(_Anything):
+    Conv2D, BatchNormalization, ZeroPadding2D, MaxPooling2D, ReLU, Dropout = _Conv2D, _BatchNormalization, _ZeroPadding2D, _MaxPooling2D, _ReLU, _Dropout
+
+    @staticmethod
+    def add(tensors, name=None):
+        out = tensors[0]
+        for t in tensors[1:]:
+            out = out + t
+        return out
+
+
+def _resize(images, size, method=None, name=None):
+    from oracle import network
+    assert method == "nearest"
+    return network.resize_nearest(_arr(images), int(size[0]), int(size[1]))
+
+
+def _fill_triangular(x):
+    from oracle import network
+    return network.fill_triangular_4(_arr(x))
 
 
 def install():
@@ -220,12 +345,17 @@ def install():
     tf.pow = lambda x, y: np.power(_arr(x), y)
     tf.identity = lambda x: x
     tf.linalg.norm = lambda x, ord="fro", axis=None: np.sqrt((_arr(x) ** 2).sum(axis=axis))
+    tf.concat = lambda xs, axis=0: np.concatenate([_arr(x) for x in xs], axis=axis)
+    tf.reshape = lambda x, shape: np.reshape(_arr(x), [int(v) for v in shape])
+    tf.image.resize = _resize
+    tf.image.ResizeMethod = types.SimpleNamespace(NEAREST_NEIGHBOR="nearest")
     tf.keras = types.SimpleNamespace(
-        Model=type("Model", (object,), {"__init__": lambda self, *a, **k: None}), layers=_Anything(), regularizers=_Anything(),
+        Model=_Model, layers=_Layers(), regularizers=_Anything(), initializers=_Anything(),
         backend=types.SimpleNamespace(learning_phase=lambda: 0),
         losses=types.SimpleNamespace(Loss=_Loss, Reduction=_Reduction, CategoricalCrossentropy=_CategoricalCrossentropy, Huber=_Huber))
     tfp = types.ModuleType("tensorflow_probability")
     tfp.distributions = types.SimpleNamespace(Categorical=_Categorical)
+    tfp.math = types.SimpleNamespace(fill_triangular=_fill_triangular)
     sys.modules["tensorflow"] = tf
     sys.modules["tensorflow_probability"] = tfp
     for name, typ in (("int", int), ("float", float), ("bool", bool)):      # numpy aliases a few reference helpers still use
