@@ -189,6 +189,21 @@ def main():
         for k, v in parts.items():
             out["%s.out.%s" % (name, k)] = np.float64(v)
         print(name, float(total), {k: float(v) for k, v in parts.items()})
+    # ---- validation_utils.post_process_predictions (src/retina_net/experiments/validation_utils.py:10-77): the deterministic
+    # validation path (f4) -- one forward pass, arg-max background filter, soft-NMS on the top score, KITTI rescale
+    from src.retina_net.experiments import validation_utils as vu
+    for ci, dataset in enumerate(("bdd", "kitti")):
+        name = "val_" + dataset
+        pred, anchors, _ = make_inputs(300 + ci, 1, 80, 8 if dataset == "bdd" else 4, False)
+        net_hw = (384, 1248) if dataset == "kitti" else (512, 512)
+        sample = {constants.ANCHORS_KEY: anchors[None], constants.IMAGE_NORMALIZED_KEY: np.zeros((1, net_hw[0], net_hw[1], 3), np.float32),
+                  constants.ORIGINAL_IM_SIZE_KEY: np.asarray([[375, 1242, 3]], np.float64)}
+        classes, corners = vu.post_process_predictions(sample, pred, dataset_name=dataset)
+        out[name + ".in.anchors"] = anchors.astype(np.float32)
+        for k, v in pred.items():
+            out["%s.in.%s" % (name, k)] = v.astype(np.float32)
+        out[name + ".out.classes"], out[name + ".out.corners"] = np.asarray(classes, np.float64), np.asarray(corners, np.float64)
+        print(name, np.asarray(classes).shape, np.asarray(corners).shape)
     # ---- RetinaNetModel.__init__ / call('testing') (retinanet_model.py:18-112) with FeatureExtractor, FeatureDecoder and the three
     # headers built and called from the reference's source (~600 lines of wiring); Keras layers stand in (see the stand-in's header)
     import yaml

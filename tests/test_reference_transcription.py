@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from oracle import bayes_od, geometry, losses, nms
+from oracle import bayes_od, geometry, losses, nms, validation
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden", "reference_transcription.npz")
@@ -106,6 +106,22 @@ def test_oracle_forward_equals_the_reference_model_wiring_run_under_the_layer_st
     if n == 1:
         again = network.retinanet_forward(weights, frame, 1, 8, mode="literal", dtype=np.float64, keep_masks=None)
         assert np.array_equal(again["anchors_box_predictions"], out["anchors_box_predictions"])
+
+
+@pytest.mark.parametrize("dataset", ["bdd", "kitti"])
+def test_oracle_validation_post_process_equals_the_reference_source(dataset):
+    """validation_utils.post_process_predictions (:10-77) from the reference's source against oracle/validation.py."""
+    z = np.load(GOLDEN)
+    name = "val_" + dataset
+    anchors = z[name + ".in.anchors"].astype(np.float64)
+    cls, box = z[name + ".in.anchors_class_predictions"].astype(np.float64)[0], z[name + ".in.anchors_box_predictions"].astype(np.float64)[0]
+    net = (384, 1248) if dataset == "kitti" else (512, 512)
+    classes, corners, info = validation.post_process_predictions(anchors, box, cls, dataset_name=dataset, net_hw=net, orig_hw=(375, 1242), dtype=np.float64)
+    want_c, want_b = z[name + ".out.classes"], z[name + ".out.corners"]
+    assert classes.shape == want_c.shape and 0 < want_c.shape[0] < anchors.shape[0]
+    np.testing.assert_allclose(classes, want_c, rtol=1e-12, atol=1e-15)
+    # (the reference casts the image / original sizes to float32 before dividing: 1e-6 on the KITTI rescale)
+    np.testing.assert_allclose(corners, want_b, rtol=1e-6 if dataset == "kitti" else 1e-12, atol=1e-9)
 
 
 def test_the_gaussian_prior_none_branch_of_the_reference_raises():

@@ -345,6 +345,7 @@ def install():
     tf.pow = lambda x, y: np.power(_arr(x), y)
     tf.identity = lambda x: x
     tf.linalg.norm = lambda x, ord="fro", axis=None: np.sqrt((_arr(x) ** 2).sum(axis=axis))
+    tf.gather = lambda params, indices, axis=0: np.take(_arr(params), np.asarray(indices, dtype=np.int64), axis=axis)
     tf.concat = lambda xs, axis=0: np.concatenate([_arr(x) for x in xs], axis=axis)
     tf.reshape = lambda x, shape: np.reshape(_arr(x), [int(v) for v in shape])
     tf.image.resize = _resize
