@@ -371,7 +371,7 @@ hipError_t launch_stem_conv(const float* img, const float* w, const float* bias,
     else if (f32_stem) hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(grid), dim3(256), 0, s, img, w, bias, out, B, H, W, oh, ow);
     else {
         static const bool old_stem = getenv("BOD_STEM_SEG64") && atoi(getenv("BOD_STEM_SEG64")) == 1;   // A/B aid: the 64-pixel-task kernel (bit-identical outputs)
-        if (old_stem || (W & 3)) {
+        if (old_stem || (W & 3) || (reinterpret_cast<uintptr_t>(img) & 15)) {            // (16-byte row loads: rows of W*3 floats from a 16-byte aligned base)
             hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(ntasks < 768 ? ntasks : 768), dim3(256), 0, s, img, w, bias,
                                reinterpret_cast<uint16_t*>(out), B, H, W, oh, ow);
             return hipGetLastError();
