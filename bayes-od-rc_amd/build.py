@@ -102,6 +102,7 @@ def build(force=False, verbose=True):
         # the tower loop (kernel_guard.py) -- a compiler bump that breaks either fails the build instead of shipping
         kernel_guard = _load_guard()
         regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
+        regs.update(kernel_guard.verify_aux(os.path.join(obj_dir, "aux_kernels.o")))
         if verbose:
             print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]

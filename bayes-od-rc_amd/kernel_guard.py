@@ -244,6 +244,20 @@ def check_asm_lds_reads(body, want, min_reads=60):
     return checked
 
 
+# kernels of aux_kernels.o that run close to the register file's limit (one block per CU, ~490 VGPRs + AGPRs): no spills either
+AUX_PRODUCTION = ["stem_conv_bf16_row_kernel"]
+
+
+def verify_aux(host_obj, wanted=AUX_PRODUCTION):
+    """No-spill guard on a built aux_kernels.o.  Raises GuardError; returns {kernel: registers}."""
+    with tempfile.TemporaryDirectory() as wd:
+        co = extract_device_object(host_obj, wd)
+        meta = kernel_metadata(co)
+        check_no_spills(meta, wanted)
+        # (.vgpr_count is the unified total on gfx950: architectural + accumulator registers)
+        return {n: f.get("vgpr_count", -1) for n, f in meta.items() if any(w in n for w in wanted)}
+
+
 def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
     """All guards on a built conv_igemm.o.  Raises GuardError; returns {kernel: vgpr_count} of the production kernels."""
     with tempfile.TemporaryDirectory() as wd:

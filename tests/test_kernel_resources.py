@@ -38,6 +38,15 @@ def test_production_conv_kernels_do_not_spill(conv_object, tmp_path):
             assert f["vgpr_count"] + f.get("agpr_count", 0) <= 256, (n, f)
 
 
+def test_row_task_stem_kernel_does_not_spill():
+    """The bf16 stem keeps all 44 weight fragments in registers (one block per CU): close to the register file's limit."""
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    build_mod.build(verbose=False)
+    regs = guard.verify_aux(os.path.join(build_mod.LIB_DIR, "obj", "aux_kernels.o"))
+    assert len(regs) == 1 and 256 < list(regs.values())[0] <= 512, regs
+
+
 def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(conv_object, tmp_path):
     """The row-reuse tower loop issues its MFMAs as inline asm with the accumulators tied in place.  The compiler neither knows
     their result latency nor inserts the wait states a real MFMA would get, so any compiler-generated instruction that reads or
