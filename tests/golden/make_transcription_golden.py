@@ -117,6 +117,38 @@ def forward_masks(hw, n, dropout_seed=5, image_id=0):
     return km, sizes
 
 
+def run_reference_training_forward(ref_model_module, yaml_model_config, weights, frames, hw, seed=3, first_image_id=10):
+    """RetinaNetModel(...)(frames, 'training') (retinanet_model.py:113-147): dropout on, one pass over the un-tiled batch; the masks are
+    the ones oracle/torch_train.py uses (sample 0 of image first_image_id + i)."""
+    import copy
+    import tf_numpy_shim
+    from oracle import philox
+    from oracle.network import HEAD_ID
+    cfg = copy.deepcopy(yaml_model_config)
+    tf_numpy_shim.set_weights(weights)
+    model = ref_model_module.RetinaNetModel(cfg)
+    _, sizes = forward_masks(hw, 1)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    ptotal = int(offs[-1])
+    b = frames.shape[0]
+    for head, hdr in (("cls", model.cls_header), ("reg", model.reg_header), ("cov", model.cov_header)):
+        for attr, obj in vars(hdr).items():
+            if attr.startswith("drop_"):
+                obj.tag = (head, int(attr.split("_")[1]) - 1)
+
+    def hook(layer, call_index, x):
+        head, k = layer.tag
+        lid = HEAD_ID[head] * 4 + k
+        nn, h, w, c = x.shape
+        assert nn == b and h * w == sizes[call_index]
+        return np.stack([philox.dropout_keep_mask(seed, first_image_id + i, 0, lid, ptotal, 256, 0.3)[offs[call_index]:offs[call_index + 1]]
+                         for i in range(b)]).reshape(b, h, w, c)
+    tf_numpy_shim.set_dropout_hook(hook)
+    out = model(frames, train_val_test="training")
+    tf_numpy_shim.set_weights(None)
+    return out
+
+
 def run_reference_forward(ref_model_module, yaml_model_config, weights, frame, n, hw):
     """RetinaNetModel(model_config)(frame, 'testing') from the reference's source, layers standing in (tf_numpy_shim)."""
     import copy
@@ -218,6 +250,15 @@ def main():
         for k in (constants.ANCHORS_CLASS_PREDICTIONS_KEY, constants.ANCHORS_BOX_PREDICTIONS_KEY, constants.ANCHORS_COVAR_PREDICTIONS_KEY):
             out["%s.out.%s" % (name, k)] = np.asarray(pred[k], np.float32)           # (wiring errors are O(1): float32 storage is plenty)
         print(name, {k: np.asarray(v).shape for k, v in pred.items()})
+    # the training-mode call on a batch of two frames (what oracle/torch_train.py, the training step's oracle, restates in PyTorch)
+    sys.path.insert(0, ROOT)
+    from bayes_od_rc_amd import synthetic
+    weights = synthetic.make_weights(cls_fg_bias=-2.0)
+    frames = synthetic.make_frames(2, 64, 64, seed=5).astype(np.float64)
+    pred = run_reference_training_forward(rm, model_cfg, weights, frames, (64, 64))
+    for k in (constants.ANCHORS_CLASS_PREDICTIONS_KEY, constants.ANCHORS_BOX_PREDICTIONS_KEY, constants.ANCHORS_COVAR_PREDICTIONS_KEY):
+        out["train_fwd.out.%s" % k] = np.asarray(pred[k], np.float32)
+    print("train_fwd", {k: np.asarray(v).shape for k, v in pred.items()})
     np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "reference_transcription.npz"), **out)
 
 

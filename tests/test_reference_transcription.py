@@ -124,6 +124,27 @@ def test_oracle_validation_post_process_equals_the_reference_source(dataset):
     np.testing.assert_allclose(corners, want_b, rtol=1e-6 if dataset == "kitti" else 1e-12, atol=1e-9)
 
 
+def test_training_oracle_forward_equals_the_reference_training_mode_call():
+    """RetinaNetModel.call(x, 'training') (retinanet_model.py:113-147) from the reference's source on two frames against
+    oracle/torch_train.forward -- the PyTorch restatement under the training step's autograd oracle (f1): dropout on at one pass
+    over the un-tiled batch, literal BatchNorm in inference mode, same Philox masks."""
+    import torch
+    from bayes_od_rc_amd import synthetic
+    from oracle import network, torch_train
+    z = np.load(GOLDEN)
+    weights = synthetic.make_weights(cls_fg_bias=-2.0)
+    frames = synthetic.make_frames(2, 64, 64, seed=5)
+    tw, _ = torch_train.prepare(weights, torch.float64)
+    with torch.no_grad():
+        cls, box, cov = torch_train.forward(tw, frames, 3, 10, 8, dtype=torch.float64)
+    got = {"anchors_class_predictions": cls.numpy(), "anchors_box_predictions": box.numpy(),
+           "anchors_box_covar_predictions": network.fill_triangular_4(cov.numpy())}
+    for k, v in got.items():
+        want = z["train_fwd.out." + k].astype(np.float64)
+        assert v.shape == want.shape, (k, v.shape, want.shape)
+        np.testing.assert_allclose(v, want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+
+
 def test_the_gaussian_prior_none_branch_of_the_reference_raises():
     """Finding of the transcription run: with gaussian_prior 'None' the reference keeps the likelihood means rank 2 and its own
     tf.squeeze(..., axis=2) (:204-205) raises.  The build returns the likelihood instead (test_bayes_oracle.py)."""
