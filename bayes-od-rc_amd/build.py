@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libbayesod_hip.so")
 SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_igemm_f32.hip", []),
+    ("conv_pointwise.hip", []),
     ("aux_kernels.hip", []),
     # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
     ("post_kernels.hip", ["-ffp-contract=off"]),
@@ -103,6 +104,7 @@ def build(force=False, verbose=True):
         kernel_guard = _load_guard()
         regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
         regs.update(kernel_guard.verify_aux(os.path.join(obj_dir, "aux_kernels.o")))
+        regs.update(kernel_guard.verify_pointwise(os.path.join(obj_dir, "conv_pointwise.o")))
         if verbose:
             print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]

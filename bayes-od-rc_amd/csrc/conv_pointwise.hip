@@ -1,0 +1,225 @@
+// Pointwise (1x1) convolutions of the backbone as a STREAMING kernel (round 3).
+//
+// The generic implicit-GEMM kernel (conv_igemm.hip) runs a 1x1 layer as a chain of dependent memory phases per tile -- K-tile DMA,
+// MFMAs, shortcut DMA into the tile image, add, store -- on a CU that holds nothing else (one 256x256 tile, its staging LDS
+// aliased by the output tile): res3's `2c` layers move 2.4 GB in 0.68 ms = 3.5 TB/s, 21 us per tile for 3.6 us of MFMAs.  For
+// reductions of at most 256 channels this kernel turns the tile loop inside out:
+//
+//   * persistent workgroups of 4 waves; a workgroup keeps ONE 128-channel cout tile for its whole life, so its weights live in
+//     registers as MFMA A fragments (K/4 VGPRs per lane) and are never read again;
+//   * it walks pixel tiles of BP pixels; the input rows and the shortcut rows of tile t+1 are in flight (LDS-DMA into the other
+//     half of two double buffers) while tile t is multiplied, finished in LDS (the shortcut tile is overwritten in place) and
+//     stored as whole 256-byte pieces of pixel rows; two or three workgroups share a CU;
+//   * same instruction (v_mfma_f32_32x32x16_bf16), same k order, same epilogue arithmetic (fma with the bias, + shortcut, hardware
+//     round-to-nearest-even pack, ReLU on the packed words) as the generic kernel: outputs are bit-identical
+//     (tests/test_gpu_forward.py::test_pointwise_kernel_is_bit_identical, BOD_POINTWISE=0 plans the generic launches).
+//
+// LDS-DMA completion is invisible to the compiler: the loop waits with explicit s_waitcnt vmcnt(n) where n counts exactly the
+// vector-memory instructions issued behind the DMA pieces it needs (the next tile's pieces and one row-table load); the output stores
+// of the previous tile are older than those and are therefore waited for as well (no assumption about the return order of loads
+// against stores).
+#include "kernels.h"
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(8))) short pw_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float pw_f32x16;
+
+#define PW_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PW_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ uint4 pw_sink[64];                     // where the stores of a tail tile's invalid pixels go (one 16-byte slot per lane)
+
+__device__ __forceinline__ uint32_t pw_pack(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint32_t pw_relu(uint32_t w) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ float pw_bf2f(uint32_t v) { return __uint_as_float(v << 16); }
+
+template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int K, int BP, bool RES, int WGS>
+__global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int ptiles, int ctiles, int pstride) {
+    constexpr int CPX = K * 2 / 16;               // 16-byte chunks per input pixel row
+    constexpr int XB = BP * K * 2;                // bytes of one input buffer
+    constexpr int RB = BP * 256;                  // bytes of one shortcut / output buffer (128 channels per pixel)
+    constexpr int NXP = BP * CPX / 256;           // input DMA pieces per thread
+    constexpr int NRP = BP * 16 / 256;            // shortcut pieces (and output stores) per thread
+    constexpr int FP = BP / 32, KS = K / 16;
+    static_assert(NXP >= 1 && NRP >= 1 && BP % 32 == 0 && (CPX & 7) == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char pw_smem[];
+    char* const xbuf = pw_smem;                   // [2][BP][K] bf16, chunk-swizzled
+    char* const rbuf = pw_smem + 2 * XB;          // [2][BP][128] bf16, chunk-swizzled
+    int4* const meta = reinterpret_cast<int4*>(pw_smem + 2 * XB + 2 * RB);      // [3][BP] {in_off, out_off, res_off, valid}
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const ConvGroup& G = a.g[0];
+    // workgroups that share a pixel tile (one per cout tile) sit on the SAME XCD (block b runs on XCD b % 8): the input rows they all
+    // read are fetched into one L2 once
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int ct = jb % ctiles, p0 = (jb / ctiles) * 8 + xcd;
+    const int c0 = ct * 128;
+    const int nt = p0 < ptiles ? (ptiles - p0 + pstride - 1) / pstride : 0;
+    if (nt == 0) return;
+
+    auto load_ent = [&](int t) {                  // row-table entry of this thread's pixel (tid % BP) of the workgroup's tile t
+        const int tt = t < nt ? t : nt - 1;
+        int m = (p0 + tt * pstride) * BP + (tid % BP);
+        const int valid = m < a.M;
+        m = valid ? m : a.M - 1;
+        const int4 e = *reinterpret_cast<const int4*>(&a.rows[m]);
+        return make_int4(e.x, e.z, e.w, valid);   // in_off, out_off, res_off
+    };
+    auto issue = [&](int t) {                     // LDS-DMA of tile t's input rows (and shortcut rows) into buffer t & 1
+        const int4* mt = meta + (t % 3) * BP;
+        char* xb = xbuf + (t & 1) * XB;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int q = i * 256 + tid, row = q / CPX, cp = q % CPX;
+            const int c = cp ^ (row & 7);
+            const char* src = reinterpret_cast<const char*>(G.in) + ((size_t)mt[row].x * a.in_cstride + G.in_coff + c * 8) * 2;
+            __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(xb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        if (RES) {
+            char* rb = rbuf + (t & 1) * RB;
+#pragma unroll
+            for (int i = 0; i < NRP; ++i) {
+                const int q = i * 256 + tid, row = q >> 4, cp = q & 15;
+                const int c = cp ^ (row & 7);
+                const char* src = reinterpret_cast<const char*>(G.res) + ((size_t)mt[row].z * a.res_cstride + c0 + c * 8) * 2;
+                __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(rb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: row tables of tiles 0 and 1, tile 0's DMA, the weights and the bias into registers
+    {
+        const int4 e0 = load_ent(0), e1 = load_ent(1);
+        if (tid < BP) { meta[tid] = e0; meta[BP + tid] = e1; }
+    }
+    __syncthreads();
+    issue(0);
+    asm volatile("" ::: "memory");
+    pw_bf16x8 wf[KS];
+    {
+        const char* wrow = reinterpret_cast<const char*>(G.w) + ((size_t)(c0 + wave * 32 + frow) * K + fhalf * 8) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const pw_bf16x8*>(wrow + ks * 32);
+    }
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(G.bias + c0 + wave * 32 + g * 8 + fhalf * 4);
+    const bool relu = a.flags & CONV_RELU;
+
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                          // meta of tile t+1 visible; the buffers of tile t+1 (= of tile t-1) are free
+        const bool more = t + 1 < nt;
+        if (more) issue(t + 1);
+        asm volatile("" ::: "memory");
+        const int4 ent = load_ent(t + 2);
+        asm volatile("" ::: "memory");
+        // tile t's pieces (and everything older) have landed once only the pieces just issued and the row-table load are outstanding
+        if (more) pw_wait_vm<NXP + (RES ? NRP : 0) + 1>(); else pw_wait_vm<1>();
+        __syncthreads();
+
+        const char* xb = xbuf + (t & 1) * XB;
+        char* rb = rbuf + (t & 1) * RB;
+        pw_f32x16 acc[FP];
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int px = j * 32 + frow;
+                const pw_bf16x8 b = *reinterpret_cast<const pw_bf16x8*>(xb + px * (K * 2) + (((ks * 2 + fhalf) ^ (px & 7)) << 4));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], b, acc[j], 0, 0, 0);
+            }
+        // ---- finish in LDS: the lane's four consecutive channels of a pixel are 8 bytes of the (shortcut) tile, overwritten in place
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int px = j * 32 + frow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                char* p = rb + px * 256 + (((wave * 4 + g) ^ (px & 7)) << 4) + fhalf * 8;
+                float v0 = __builtin_fmaf(acc[j][g * 4 + 0], 1.0f, bv[g].x), v1 = __builtin_fmaf(acc[j][g * 4 + 1], 1.0f, bv[g].y);
+                float v2 = __builtin_fmaf(acc[j][g * 4 + 2], 1.0f, bv[g].z), v3 = __builtin_fmaf(acc[j][g * 4 + 3], 1.0f, bv[g].w);
+                if (RES) {
+                    const uint2 r = *reinterpret_cast<const uint2*>(p);
+                    v0 += pw_bf2f(r.x & 0xFFFFu) * 1.0f; v1 += pw_bf2f(r.x >> 16) * 1.0f;
+                    v2 += pw_bf2f(r.y & 0xFFFFu) * 1.0f; v3 += pw_bf2f(r.y >> 16) * 1.0f;
+                }
+                uint2 o;
+                o.x = pw_pack(v0, v1); o.y = pw_pack(v2, v3);
+                if (relu) { o.x = pw_relu(o.x); o.y = pw_relu(o.y); }
+                *reinterpret_cast<uint2*>(p) = o;
+            }
+        }
+        __syncthreads();
+        {
+            const int4* mt = meta + (t % 3) * BP;
+#pragma unroll
+            for (int i = 0; i < NRP; ++i) {
+                const int q = i * 256 + tid, row = q >> 4, cp = q & 15;
+                const int c = cp ^ (row & 7);
+                const uint4 v = *reinterpret_cast<const uint4*>(rb + q * 16);
+                const int4 e = mt[row];
+                uint4* dst = e.w ? reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + (size_t)e.y * a.out_cstride + c0 + c * 8) : &pw_sink[lane];
+                *dst = v;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (tid < BP) meta[((t + 2) % 3) * BP + tid] = ent;     // (the compiler waits for the load; visible after the next barrier)
+    }
+}
+
+template <int K, int BP, bool RES, int WGS>
+static hipError_t pw_launch_cfg(const ConvArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * BP * K * 2 + 2 * BP * 256 + 3 * BP * 16;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
+    auto kern = pw_conv_kernel<K, BP, RES, WGS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ptiles = (a.M + BP - 1) / BP, ctiles = a.cout_pad / 128;
+    const int slots = 256 * WGS;                            // MI355X: 256 CUs
+    int pstride = std::min(slots / ctiles, ptiles) / 8 * 8; // pixel-tile lanes: a multiple of the 8 XCDs
+    if (pstride < 8) pstride = 8;
+    hipLaunchKernelGGL(kern, dim3(pstride * ctiles), dim3(256), LDS, s, a, ptiles, ctiles, pstride);
+    return hipGetLastError();
+}
+
+// true when the launch was taken by the pointwise kernel
+bool conv_pointwise_eligible(const ConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("BOD_POINTWISE"); return !e || atoi(e) != 0; }();
+    if (!on) return false;
+    const ConvGroup& g = a.g[0];
+    if (a.variant != 0 || a.split || a.xreuse || a.ksplit > 1 || a.groups != 1 || a.taps != 1 || a.fan_count > 1) return false;
+    if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
+    if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind) return false;
+    if (a.cin != 64 && a.cin != 128 && a.cin != 256) return false;
+    if (a.cout_pad % 128 != 0 || a.cout_valid != a.cout_pad) return false;
+    if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7) || (g.res && (a.res_cstride & 7))) return false;
+    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : 32768; }();   // (tests lower it)
+    if (a.M < min_m) return false;                          // persistent workgroups need a few tiles each
+    return true;
+}
+
+hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
+    const bool res = a.g[0].res != nullptr;
+    if (a.cin == 64) return res ? pw_launch_cfg<64, 64, true, 3>(a, s) : pw_launch_cfg<64, 64, false, 3>(a, s);
+    if (a.cin == 128) return res ? pw_launch_cfg<128, 64, true, 2>(a, s) : pw_launch_cfg<128, 64, false, 2>(a, s);
+    return res ? pw_launch_cfg<256, 32, true, 3>(a, s) : pw_launch_cfg<256, 32, false, 3>(a, s);
+}

@@ -233,6 +233,11 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
                                 hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// Streaming pointwise (1x1) convolution for reductions of <= 256 channels (conv_pointwise.hip); launch_conv_igemm routes eligible
+// launches there (BOD_POINTWISE=0: off)
+bool conv_pointwise_eligible(const ConvArgs& a);
+hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
+
 // Training-step building blocks (train_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_gather_transpose(const void* in, const RowEnt* rows, void* out, int M, int Kpad, int C, int cstride,

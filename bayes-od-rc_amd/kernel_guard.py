@@ -258,6 +258,20 @@ def verify_aux(host_obj, wanted=AUX_PRODUCTION):
         return {n: f.get("vgpr_count", -1) for n, f in meta.items() if any(w in n for w in wanted)}
 
 
+# conv_pointwise.o: the streaming 1x1 kernels share a CU two or three at a time, which only works while they stay inside their
+# register budget without spilling
+POINTWISE_PRODUCTION = ["pw_conv_kernelILi64ELi64E", "pw_conv_kernelILi128ELi64E", "pw_conv_kernelILi256ELi32E"]
+
+
+def verify_pointwise(host_obj):
+    regs = verify_aux(host_obj, POINTWISE_PRODUCTION)
+    for n, v in regs.items():
+        cap = 256 if "ILi128ELi64E" in n else 168          # two / three workgroups of four waves per CU
+        if v > cap:
+            raise GuardError("%s uses %d registers: more than the %d that keep its workgroups co-resident" % (n, v, cap))
+    return regs
+
+
 def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
     """All guards on a built conv_igemm.o.  Raises GuardError; returns {kernel: vgpr_count} of the production kernels."""
     with tempfile.TemporaryDirectory() as wd:

@@ -361,3 +361,41 @@ def test_row_task_stem_kernel_is_bit_identical():
     for k in sorted(outs[0]):
         assert np.array_equal(outs[0][k], outs[1][k]), k
         assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k
+
+
+def test_pointwise_kernel_is_bit_identical():
+    """1x1 layers that reduce at most 256 channels run on the streaming pointwise kernel since round 3 (conv_pointwise.hip:
+    persistent workgroups, weights in registers, the next tile's rows in flight; same MFMA shape, k order and epilogue
+    arithmetic as the generic kernel).  BOD_POINTWISE=0 plans the generic launches: pyramid and raw head outputs must not differ
+    by one bit -- all three reduction widths (64 / 128 / 256), with and without shortcut, stride-2 layers, ragged last tiles,
+    ResNet-50 and -101 (BOD_POINTWISE_MIN_M=1 sends small test shapes down the pointwise path too)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b, depth in (('a', (128, 128), 3, 50), ('b', (96, 160), 1, 50), ('c', (192, 624), 2, 50), ('d', (128, 128), 2, 101), ('e', (256, 256), 9, 50)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=2, backbone_depth=depth))\n"
+            "    eng.load_weights(synthetic.make_weights(depth=depth))\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=3), seed=11, first_image_id=2)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    for k, v in zip('cbv', eng.get_raw()): out['%%s_%%s' %% (tag, k)] = v\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_POINTWISE=on, BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) == 40
+    for k in sorted(outs[0]):
+        assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
+        assert np.isfinite(outs[0][k]).all(), k

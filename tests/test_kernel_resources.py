@@ -47,6 +47,15 @@ def test_row_task_stem_kernel_does_not_spill():
     assert len(regs) == 1 and 256 < list(regs.values())[0] <= 512, regs
 
 
+def test_pointwise_kernels_keep_their_residency():
+    """The streaming 1x1 kernels (conv_pointwise.hip): no spills, and few enough registers for 2 / 3 workgroups per CU."""
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    build_mod.build(verbose=False)
+    regs = guard.verify_pointwise(os.path.join(build_mod.LIB_DIR, "obj", "conv_pointwise.o"))
+    assert len(regs) == 6, regs
+
+
 def test_inline_asm_mfma_accumulators_are_untouched_inside_the_tower_loop(conv_object, tmp_path):
     """The row-reuse tower loop issues its MFMAs as inline asm with the accumulators tied in place.  The compiler neither knows
     their result latency nor inserts the wait states a real MFMA would get, so any compiler-generated instruction that reads or
