@@ -2165,6 +2165,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_pointwise_eligible(a)) return launch_conv_pointwise(a, s);   // streaming 1x1 kernel (bit-identical)
+    if (!forced && !(a.flags & CONV_NT_OUT) && conv_slide3x3_eligible(a)) return launch_conv_slide3x3(a, s);     // sliding-window 3x3, 64 -> 64 (bit-identical)
     bool big = conv_big_tile_pays(a);
     if (a.fan_count > 1 && fan_out_small_tile()) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);

@@ -15,9 +15,9 @@
 //     (tests/test_gpu_forward.py::test_pointwise_kernel_is_bit_identical, BOD_POINTWISE=0 plans the generic launches).
 //
 // LDS-DMA completion is invisible to the compiler: the loop waits with explicit s_waitcnt vmcnt(n) where n counts exactly the
-// vector-memory instructions issued behind the DMA pieces it needs (the next tile's pieces and one row-table load); the output stores
-// of the previous tile are older than those and are therefore waited for as well (no assumption about the return order of loads
-// against stores).
+// vector-memory instructions issued behind the DMA pieces it needs (the previous tile's output stores, the next tile's pieces, the
+// row-table loads): vmcnt retires in issue order on gfx9 -- the same model the compiler's own wait insertion uses -- so the stores of
+// tile t-1 stay in flight under tile t's MFMAs.
 #include "kernels.h"
 #include <algorithm>
 
@@ -125,8 +125,11 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
         asm volatile("" ::: "memory");
         const int4 ent = load_ent(t + 2);
         asm volatile("" ::: "memory");
-        // tile t's pieces (and everything older) have landed once only the pieces just issued and the row-table load are outstanding
-        if (more) pw_wait_vm<NXP + (RES ? NRP : 0) + 1>(); else pw_wait_vm<1>();
+        // tile t's pieces have landed once at most the instructions issued BEHIND them are outstanding (vmcnt retires in issue order on
+        // gfx9, the model the compiler's own wait insertion uses): this iteration's pieces + row-table load and, from the second tile
+        // on, the previous iteration's row-table load and output stores -- which thereby stay in flight under this tile's MFMAs
+        if (more) { if (t > 0) pw_wait_vm<1 + NRP + NXP + (RES ? NRP : 0) + 1>(); else pw_wait_vm<NXP + (RES ? NRP : 0) + 1>(); }
+        else pw_wait_vm<1>();
         __syncthreads();
 
         const char* xb = xbuf + (t & 1) * XB;
@@ -225,4 +228,161 @@ hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
     if (a.cin == 64) return res ? pw_launch_cfg<64, 64, true, 3>(a, s) : pw_launch_cfg<64, 64, false, 3>(a, s);
     if (a.cin == 128) return res ? pw_launch_cfg<128, 64, true, 2>(a, s) : pw_launch_cfg<128, 64, false, 2>(a, s);
     return res ? pw_launch_cfg<256, 32, true, 3>(a, s) : pw_launch_cfg<256, 32, false, 3>(a, s);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Sliding-window 3x3 (stride 1, SAME), 64 -> 64 channels: ResNet stage 2's `2b` layers.  The generic kernel stages a 128-pixel tile's
+// input rows once per TAP (nine K-tiles, each a fresh LDS-DMA of the same pixels shifted by one): 4.8 GB through L2 for a layer
+// that reads 0.53 GB, 0.68 ms.  Here a workgroup owns a 64-pixel-wide column strip of one image and walks DOWN it: the three input
+// rows of an output row live in a four-slot LDS ring, so moving one row down loads ONE new input row (64 + 2 halo pixels) while
+// the current row is multiplied -- every input pixel is staged once (+3 % halo).  All 36 weight fragments of a wave (32 couts x
+// 576 k) live in registers; four waves = 2 cout halves x 2 pixel fragments.  Same MFMA (32x32x16), same k order (taps outer, 16-
+// channel steps inner within the single 64-channel chunk) and epilogue as the generic kernel: bit-identical.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int LEAD>
+__global__ __launch_bounds__(256, 2) void slide3x3_c64_kernel(const ConvArgs a, int nstrips, int xsegs) {
+    constexpr int SLOT = 66 * 128;                // bytes per ring slot: 64 + 2 halo pixels x 64 channels
+    constexpr int RING = LEAD == 1 ? 4 : 6;       // rows y .. y+2 in use + LEAD rows landing / in flight (a power of two for one row ahead)
+    constexpr int OB = 64 * 128;                  // one output row tile [64 px][64 ch] bf16
+    extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+    char* const ring = sl_smem;                   // [RING][SLOT]
+    char* const obuf = sl_smem + RING * SLOT;     // [2][OB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int wc = wave & 1, wp = wave >> 1;      // cout half, pixel fragment
+    const ConvGroup& G = a.g[0];
+    const int H = a.plane_h, W = a.plane_w;
+
+    // weights: A fragments of couts wc*32 .. +31 for all 36 k-steps (tap-major, 4 x 16 channels per tap)
+    pw_bf16x8 wf[36];
+    {
+        const char* wrow = reinterpret_cast<const char*>(G.w) + ((size_t)(wc * 32 + frow) * 576 + fhalf * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) wf[k] = *reinterpret_cast<const pw_bf16x8*>(wrow + k * 32);
+    }
+    float4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(G.bias + wc * 32 + g * 8 + fhalf * 4);
+    const bool relu = a.flags & CONV_RELU;
+
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int b = strip / xsegs, xs = strip - b * xsegs;
+        const int x0 = xs * 64, nv = min(64, W - x0);                  // valid pixels of this strip's rows
+        const int m00 = (b * H) * W + x0;
+        const int4 e0 = *reinterpret_cast<const int4*>(&a.rows[m00]);  // in_off, in_pitch, out_off, res_off
+        const int out_pitch = H > 1 ? a.rows[m00 + W].out_off - e0.z : 0;
+        const long in0 = (long)e0.x;                                   // pixel index of the window origin of output (b, 0, x0)
+        const int in_pitch = e0.y;
+        // DMA of input row `ir` (relative to the strip's first input row) into ring slot ir % RING: 528 16-byte pieces, pixel = piece / 8,
+        // chunk swizzled by the pixel.  Waves 1-3 issue two instructions per row, wave 0 a third one for the last 16 pieces.
+        auto issue_row = [&](int ir) {
+            char* slot = ring + (ir % RING) * SLOT;
+            auto piece = [&](int i) {
+                const int q = i * 256 + tid;
+                int px = q >> 3;
+                const int cp = q & 7;
+                const int c = cp ^ (px & 7);
+                px = px < nv + 2 ? px : 0;                             // (pieces past the row's halo re-read its first pixel)
+                const char* src = reinterpret_cast<const char*>(G.in) + (((size_t)(in0 + (long)ir * in_pitch + px)) * a.in_cstride + G.in_coff + c * 8) * 2;
+                __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(slot + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            };
+            piece(0); piece(1);
+            if (wave == 0 && lane < 16) piece(2);
+        };
+        __syncthreads();                          // the previous strip's last reads of the ring / output tiles are done
+        issue_row(0); issue_row(1); issue_row(2);
+        if (LEAD == 2 && H >= 2) issue_row(3);
+        for (int y = 0; y < H; ++y) {
+            const bool pre = y + LEAD < H;        // row y+2+LEAD exists (the padded plane has H+2 rows)
+            if (pre) issue_row(y + 2 + LEAD);
+            asm volatile("" ::: "memory");
+            // rows y .. y+2 have landed once at most the instructions issued BEHIND row y+2's pieces are outstanding (vmcnt retires in
+            // issue order): the pieces of rows y+3 and y+4 (D each: 3 on wave 0, 2 elsewhere) and the two stores of each of the last
+            // two output rows.  The last two rows of a strip wait for everything.
+            if (!pre) pw_wait_vm<0>();
+            else if (LEAD == 2) {
+                if (wave == 0) { if (y == 0) pw_wait_vm<6>(); else if (y == 1) pw_wait_vm<8>(); else pw_wait_vm<10>(); }
+                else { if (y == 0) pw_wait_vm<4>(); else if (y == 1) pw_wait_vm<6>(); else pw_wait_vm<8>(); }
+            } else {
+                if (wave == 0) { if (y == 0) pw_wait_vm<3>(); else pw_wait_vm<5>(); }
+                else { if (y == 0) pw_wait_vm<2>(); else pw_wait_vm<4>(); }
+            }
+            __syncthreads();
+            pw_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const char* slot = ring + ((y + ky) % RING) * SLOT;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int px = wp * 32 + frow + kx;
+                        const pw_bf16x8 bf = *reinterpret_cast<const pw_bf16x8*>(slot + px * 128 + (((ks * 2 + fhalf) ^ (px & 7)) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(ky * 3 + kx) * 4 + ks], bf, acc, 0, 0, 0);
+                    }
+            }
+            char* ob = obuf + (y & 1) * OB;
+            {
+                const int px = wp * 32 + frow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pw_pack(__builtin_fmaf(acc[g * 4 + 0], 1.0f, bv[g].x), __builtin_fmaf(acc[g * 4 + 1], 1.0f, bv[g].y));
+                    o.y = pw_pack(__builtin_fmaf(acc[g * 4 + 2], 1.0f, bv[g].z), __builtin_fmaf(acc[g * 4 + 3], 1.0f, bv[g].w));
+                    if (relu) { o.x = pw_relu(o.x); o.y = pw_relu(o.y); }
+                    *reinterpret_cast<uint2*>(ob + px * 128 + (((wc * 4 + g) ^ (px & 7)) << 4) + fhalf * 8) = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = i * 256 + tid, px = q >> 3, cp = q & 7;
+                const int c = cp ^ (px & 7);
+                const uint4 v = *reinterpret_cast<const uint4*>(ob + q * 16);
+                uint4* dst = px < nv ? reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + ((size_t)e0.z + (size_t)y * out_pitch + px) * a.out_cstride + c * 8)
+                                     : &pw_sink[lane];
+                *dst = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+bool conv_slide3x3_eligible(const ConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("BOD_SLIDE3X3"); return !e || atoi(e) != 0; }();
+    if (!on) return false;
+    const ConvGroup& g = a.g[0];
+    if (a.variant != 0 || a.split || a.xreuse || a.ksplit > 1 || a.groups != 1 || a.taps != 9 || a.KW != 3 || a.fan_count > 1) return false;
+    if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
+    if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind || g.res) return false;
+    if (a.cin != 64 || a.cout_pad != 64 || a.cout_valid != 64 || a.plane_h < 1 || a.plane_w < 1) return false;
+    if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7)) return false;
+    if (a.M % (a.plane_h * a.plane_w) != 0) return false;
+    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : 32768; }();
+    return a.M >= min_m;
+}
+
+hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s) {
+    constexpr int LDS = 6 * 66 * 128 + 2 * 64 * 128;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(slide3x3_c64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(slide3x3_c64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int xsegs = (a.plane_w + 63) / 64;
+    const int nstrips = a.M / (a.plane_h * a.plane_w) * xsegs;
+    // rows of prefetch: one (default) or two (BOD_SLIDE_LEAD=2).  Measured per 256-frame step, same box: backbone 22.96 ms with one row
+    // ahead, 23.11-23.17 with two (a sixth ring slot and longer wait chains for nothing: the row in flight is not what a row waits for),
+    // 23.69 on the generic kernel
+    static const int lead = [] { const char* e = getenv("BOD_SLIDE_LEAD"); return e ? atoi(e) : 1; }();
+    if (lead == 2) hipLaunchKernelGGL(slide3x3_c64_kernel<2>, dim3(std::min(nstrips, 512)), dim3(256), LDS, s, a, nstrips, xsegs);
+    else hipLaunchKernelGGL(slide3x3_c64_kernel<1>, dim3(std::min(nstrips, 512)), dim3(256), 4 * 66 * 128 + 2 * 64 * 128, s, a, nstrips, xsegs);
+    return hipGetLastError();
 }

@@ -337,6 +337,7 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
     op.name = name; op.wname[0] = name; op.bnname[0] = bn;
     op.same_geom = stride == 1 && same && pc.taps == 9 && pc.kw == 3 && in.base == out.base && in.bstride == out.bstride && in.pitch == out.pitch &&
                    in.h == out.h && in.w == out.w;
+    if (stride == 1 && same && pc.taps == 9 && pc.kw == 3 && in.h == out.h && in.w == out.w) { op.conv.plane_h = out.h; op.conv.plane_w = out.w; }
     // Split-K for layers with too few output tiles to fill the chip and a long reduction (P6 always; most of
     // stage 3-5 at batch 1): enough splits for >= ~256 workgroups, each keeping >= 4 K-tiles.
     static const bool splitk_on = [] { const char* e = getenv("BOD_CONV_SPLITK"); return !e || atoi(e) != 0; }();
@@ -469,7 +470,11 @@ bod_status build_plan(bod_context* h) {
         // Measured per block at 256 frames of 512x512 (BOD_TRACE_OPS): stage 2 (64 -> 256 channels) 2.23 -> 1.99 ms, its last block
         // 1.67 -> 1.45; stage 3 (128 -> 512) 1.33 -> 1.59 ms -- four shortcut passes per 128-pixel tile, each opening with an exposed
         // LDS-DMA round trip, cost more than the bytes they save -- so stage 3 is chained only on request (BOD_CHAIN_FUSION=3).
-        int chain_stages = 2;
+        // Later in round 3 the separate launches got their own streaming kernels (conv_pointwise.hip: the 1x1 expansion with the next
+        // tile's rows in flight, the 64 -> 64 3x3 as a sliding window): per 256-frame step the chained stage 2 measures 23.1-23.6 ms of
+        // backbone against 22.4-23.1 unchained on the same boxes, so the chain is OFF by default now (BOD_CHAIN_FUSION=2: stage 2,
+        // =3: stages 2 and 3; the kernel, its guard entries and its bit-identity test stay).
+        int chain_stages = 0;
         if (const char* e = getenv("BOD_CHAIN_FUSION")) chain_stages = atoi(e);
         bool chain_ok = h->es == 2 && !h->split && !train_mode && ((st == 2 && chain_stages >= 1) || (st == 3 && chain_stages >= 3));
         Plane t1alt;

@@ -97,6 +97,9 @@ struct ConvArgs {
     // (conv_igemm.hip); cin, in_cstride, res_cstride, in_coff and -- for non-fp32 outputs -- out_cstride count SLOTS (2 per
     // channel), cout_pad / cout_valid stay in channels.
     int32_t split;
+    // Output plane geometry of a plane -> plane convolution whose row table is ordered (image, y, x): rows per image and pixels per
+    // row (0 = unknown).  The sliding-window 3x3 kernel (conv_pointwise.hip) walks column strips with it.
+    int32_t plane_h, plane_w;
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
@@ -237,6 +240,9 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 // launches there (BOD_POINTWISE=0: off)
 bool conv_pointwise_eligible(const ConvArgs& a);
 hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
+// Sliding-window 3x3 stride-1 SAME convolution, 64 -> 64 channels (ResNet stage 2's `2b`; conv_pointwise.hip, BOD_SLIDE3X3=0: off)
+bool conv_slide3x3_eligible(const ConvArgs& a);
+hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s);
 
 // Training-step building blocks (train_kernels.hip)
 // ------------------------------------------------------------------------------------------------

@@ -260,13 +260,13 @@ def verify_aux(host_obj, wanted=AUX_PRODUCTION):
 
 # conv_pointwise.o: the streaming 1x1 kernels share a CU two or three at a time, which only works while they stay inside their
 # register budget without spilling
-POINTWISE_PRODUCTION = ["pw_conv_kernelILi64ELi64E", "pw_conv_kernelILi128ELi64E", "pw_conv_kernelILi256ELi32E"]
+POINTWISE_PRODUCTION = ["pw_conv_kernelILi64ELi64E", "pw_conv_kernelILi128ELi64E", "pw_conv_kernelILi256ELi32E", "slide3x3_c64_kernelILi1E"]
 
 
 def verify_pointwise(host_obj):
     regs = verify_aux(host_obj, POINTWISE_PRODUCTION)
     for n, v in regs.items():
-        cap = 256 if "ILi128ELi64E" in n else 168          # two / three workgroups of four waves per CU
+        cap = 256 if ("ILi128ELi64E" in n or "slide3x3" in n) else 168          # two / three workgroups of four waves per CU
         if v > cap:
             raise GuardError("%s uses %d registers: more than the %d that keep its workgroups co-resident" % (n, v, cap))
     return regs
