@@ -215,6 +215,8 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
     // (512-channel reductions measured on this kernel -- 128 weight registers, one workgroup per CU: +0.55 ms per 256-frame step
     //  against the generic kernel, which already moves those layers at 4.5 TB/s; not kept)
     if (a.cin != 64 && a.cin != 128 && a.cin != 256) return false;
+    // (64-channel cout tiles -- stage 2's `2a` reductions -- measured on this kernel: no difference to the generic 64x128 tiles, three
+    //  workgroups per CU, that run them now; not kept)
     if (a.cout_pad % 128 != 0 || a.cout_valid != a.cout_pad) return false;
     if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7) || (g.res && (a.res_cstride & 7))) return false;
     static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : 32768; }();   // (tests lower it)
