@@ -43,19 +43,29 @@ __device__ __forceinline__ float pw_bf2f(uint32_t v) { return __uint_as_float(v 
 
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int K, int BP, bool RES, int WGS>
-__global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int ptiles, int ctiles, int pstride) {
+// BC = 128 (four waves) is the kernel described above.  BC = 256 with NEXT (eight waves, one workgroup per CU) is the fused form of
+// ResNet stage 2: the cout tile spans ALL 256 channels of a pixel, so the NEXT block's 1x1 reduction `2a` (256 -> 64, + bias + ReLU,
+// ConvGroup.ch_w3 / ch_b3 / ch_out3) is computed from the finished tile while it is still in LDS -- the 2.1 GB block output is
+// written once and read once (by the next shortcut) instead of twice, and the next block's `2a` launch disappears.  The `2a` MFMAs
+// read the stored bf16 values of the tile in ascending k order like the generic kernel would from memory: bit-identical.
+template <int K, int BP, bool RES, int WGS, int BC = 128, bool NEXT = false>
+__global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, int ptiles, int ctiles, int pstride) {
+    constexpr int THREADS = BC * 2;               // one wave per 32 couts
     constexpr int CPX = K * 2 / 16;               // 16-byte chunks per input pixel row
+    constexpr int RCH = BC / 8;                   // 16-byte chunks per row of the shortcut / output tile
     constexpr int XB = BP * K * 2;                // bytes of one input buffer
-    constexpr int RB = BP * 256;                  // bytes of one shortcut / output buffer (128 channels per pixel)
-    constexpr int NXP = BP * CPX / 256;           // input DMA pieces per thread
-    constexpr int NRP = BP * 16 / 256;            // shortcut pieces (and output stores) per thread
+    constexpr int RB = BP * BC * 2;               // bytes of one shortcut / output buffer (BC channels per pixel)
+    constexpr int NXP = BP * CPX / THREADS;       // input DMA pieces per thread
+    constexpr int NRP = BP * RCH / THREADS;       // shortcut pieces (and output stores) per thread
     constexpr int FP = BP / 32, KS = K / 16;
-    static_assert(NXP >= 1 && NRP >= 1 && BP % 32 == 0 && (CPX & 7) == 0, "tile shape");
+    constexpr int C2 = 64, KS2 = BC / 16;         // NEXT: couts and k-steps of the fused 2a
+    constexpr int NTP = NEXT ? BP * (C2 / 8) / THREADS : 0;     // NEXT: stores of the 2a tile per thread
+    static_assert(NXP >= 1 && NRP >= 1 && BP % 32 == 0 && (CPX & 7) == 0 && (!NEXT || (BC == 256 && BP == 64 && NTP == 1)), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char pw_smem[];
     char* const xbuf = pw_smem;                   // [2][BP][K] bf16, chunk-swizzled
-    char* const rbuf = pw_smem + 2 * XB;          // [2][BP][128] bf16, chunk-swizzled
+    char* const rbuf = pw_smem + 2 * XB;          // [2][BP][BC] bf16, chunk-swizzled
     int4* const meta = reinterpret_cast<int4*>(pw_smem + 2 * XB + 2 * RB);      // [3][BP] {in_off, out_off, res_off, valid}
+    char* const tbuf = pw_smem + 2 * XB + 2 * RB + 3 * BP * 16;                 // NEXT: [BP][64] bf16 tile of the fused 2a
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
     // read are fetched into one L2 once
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int ct = jb % ctiles, p0 = (jb / ctiles) * 8 + xcd;
-    const int c0 = ct * 128;
+    const int c0 = ct * BC;
     const int nt = p0 < ptiles ? (ptiles - p0 + pstride - 1) / pstride : 0;
     if (nt == 0) return;
 
@@ -82,19 +92,19 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
         char* xb = xbuf + (t & 1) * XB;
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
-            const int q = i * 256 + tid, row = q / CPX, cp = q % CPX;
+            const int q = i * THREADS + tid, row = q / CPX, cp = q % CPX;
             const int c = cp ^ (row & 7);
             const char* src = reinterpret_cast<const char*>(G.in) + ((size_t)mt[row].x * a.in_cstride + G.in_coff + c * 8) * 2;
-            __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(xb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(xb + (i * THREADS + wave * 64) * 16), 16, 0, 0);
         }
         if (RES) {
             char* rb = rbuf + (t & 1) * RB;
 #pragma unroll
             for (int i = 0; i < NRP; ++i) {
-                const int q = i * 256 + tid, row = q >> 4, cp = q & 15;
+                const int q = i * THREADS + tid, row = q / RCH, cp = q % RCH;
                 const int c = cp ^ (row & 7);
                 const char* src = reinterpret_cast<const char*>(G.res) + ((size_t)mt[row].z * a.res_cstride + c0 + c * 8) * 2;
-                __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(rb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(rb + (i * THREADS + wave * 64) * 16), 16, 0, 0);
             }
         }
     };
@@ -117,6 +127,16 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
 #pragma unroll
     for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(G.bias + c0 + wave * 32 + g * 8 + fhalf * 4);
     const bool relu = a.flags & CONV_RELU;
+    // NEXT: waves 0-3 compute the fused 2a -- cout block (wave & 1) x pixel fragment (wave >> 1) -- with its 16 k-steps of weights in registers
+    pw_bf16x8 wf2[NEXT ? KS2 : 1];
+    float4 bv2[4];
+    if (NEXT) {
+        const char* wrow = reinterpret_cast<const char*>(G.ch_w3) + ((size_t)((wave & 1) * 32 + frow) * BC + fhalf * 8) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) wf2[ks] = *reinterpret_cast<const pw_bf16x8*>(wrow + ks * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv2[g] = *reinterpret_cast<const float4*>(G.ch_b3 + (wave & 1) * 32 + g * 8 + fhalf * 4);
+    }
 
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                          // meta of tile t+1 visible; the buffers of tile t+1 (= of tile t-1) are free
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
         // tile t's pieces have landed once at most the instructions issued BEHIND them are outstanding (vmcnt retires in issue order on
         // gfx9, the model the compiler's own wait insertion uses): this iteration's pieces + row-table load and, from the second tile
         // on, the previous iteration's row-table load and output stores -- which thereby stay in flight under this tile's MFMAs
-        if (more) { if (t > 0) pw_wait_vm<1 + NRP + NXP + (RES ? NRP : 0) + 1>(); else pw_wait_vm<NXP + (RES ? NRP : 0) + 1>(); }
+        if (more) { if (t > 0) pw_wait_vm<1 + NRP + NTP + NXP + (RES ? NRP : 0) + 1>(); else pw_wait_vm<NXP + (RES ? NRP : 0) + 1>(); }
         else pw_wait_vm<1>();
         __syncthreads();
 
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
             const int px = j * 32 + frow;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                char* p = rb + px * 256 + (((wave * 4 + g) ^ (px & 7)) << 4) + fhalf * 8;
+                char* p = rb + px * (BC * 2) + (((wave * 4 + g) ^ (px & 7)) << 4) + fhalf * 8;
                 float v0 = __builtin_fmaf(acc[j][g * 4 + 0], 1.0f, bv[g].x), v1 = __builtin_fmaf(acc[j][g * 4 + 1], 1.0f, bv[g].y);
                 float v2 = __builtin_fmaf(acc[j][g * 4 + 2], 1.0f, bv[g].z), v3 = __builtin_fmaf(acc[j][g * 4 + 3], 1.0f, bv[g].w);
                 if (RES) {
@@ -172,11 +192,42 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
             const int4* mt = meta + (t % 3) * BP;
 #pragma unroll
             for (int i = 0; i < NRP; ++i) {
-                const int q = i * 256 + tid, row = q >> 4, cp = q & 15;
+                const int q = i * THREADS + tid, row = q / RCH, cp = q % RCH;
                 const int c = cp ^ (row & 7);
                 const uint4 v = *reinterpret_cast<const uint4*>(rb + q * 16);
                 const int4 e = mt[row];
                 uint4* dst = e.w ? reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + (size_t)e.y * a.out_cstride + c0 + c * 8) : &pw_sink[lane];
+                *dst = v;
+            }
+        }
+        if (NEXT) {
+            // ---- the next block's 2a on the finished tile (its stored bf16 values): D[64 couts][BP pixels] over k = 0 .. BC-1
+            if (wave < 4) {
+                const int px = (wave >> 1) * 32 + frow;
+                pw_f32x16 acc2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+                    const pw_bf16x8 b = *reinterpret_cast<const pw_bf16x8*>(rb + px * (BC * 2) + (((ks * 2 + fhalf) ^ (px & 7)) << 4));
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[ks], b, acc2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pw_relu(pw_pack(__builtin_fmaf(acc2[g * 4 + 0], 1.0f, bv2[g].x), __builtin_fmaf(acc2[g * 4 + 1], 1.0f, bv2[g].y)));
+                    o.y = pw_relu(pw_pack(__builtin_fmaf(acc2[g * 4 + 2], 1.0f, bv2[g].z), __builtin_fmaf(acc2[g * 4 + 3], 1.0f, bv2[g].w)));
+                    *reinterpret_cast<uint2*>(tbuf + px * 128 + ((((wave & 1) * 4 + g) ^ (px & 7)) << 4) + fhalf * 8) = o;
+                }
+            }
+            __syncthreads();
+            {
+                const int4* mt = meta + (t % 3) * BP;
+                const int q = tid, row = q >> 3, cp = q & 7;           // BP * 8 = THREADS pieces: one per thread
+                const int c = cp ^ (row & 7);
+                const uint4 v = *reinterpret_cast<const uint4*>(tbuf + q * 16);
+                const int4 e = mt[row];
+                uint4* dst = e.w ? reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.ch_out3) + (size_t)e.y * C2 + c * 8) : &pw_sink[lane];
                 *dst = v;
             }
         }
@@ -185,22 +236,22 @@ __global__ __launch_bounds__(256, WGS) void pw_conv_kernel(const ConvArgs a, int
     }
 }
 
-template <int K, int BP, bool RES, int WGS>
+template <int K, int BP, bool RES, int WGS, int BC = 128, bool NEXT = false>
 static hipError_t pw_launch_cfg(const ConvArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * BP * K * 2 + 2 * BP * 256 + 3 * BP * 16;
+    constexpr int LDS = 2 * BP * K * 2 + 2 * BP * BC * 2 + 3 * BP * 16 + (NEXT ? BP * 128 : 0);
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
-    auto kern = pw_conv_kernel<K, BP, RES, WGS>;
+    auto kern = pw_conv_kernel<K, BP, RES, WGS, BC, NEXT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int ptiles = (a.M + BP - 1) / BP, ctiles = a.cout_pad / 128;
+    const int ptiles = (a.M + BP - 1) / BP, ctiles = a.cout_pad / BC;
     const int slots = 256 * WGS;                            // MI355X: 256 CUs
     int pstride = std::min(slots / ctiles, ptiles) / 8 * 8; // pixel-tile lanes: a multiple of the 8 XCDs
     if (pstride < 8) pstride = 8;
-    hipLaunchKernelGGL(kern, dim3(pstride * ctiles), dim3(256), LDS, s, a, ptiles, ctiles, pstride);
+    hipLaunchKernelGGL(kern, dim3(pstride * ctiles), dim3(BC * 2), LDS, s, a, ptiles, ctiles, pstride);
     return hipGetLastError();
 }
 
@@ -212,6 +263,7 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
     if (a.variant != 0 || a.split || a.xreuse || a.ksplit > 1 || a.groups != 1 || a.taps != 1 || a.fan_count > 1) return false;
     if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
     if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind) return false;
+    if (g.ch_w3 && !(a.cin == 64 && a.cout_pad == 256 && g.res && g.ch_b3 && g.ch_out3)) return false;   // fused next 2a: stage 2's shape only
     // (512-channel reductions measured on this kernel -- 128 weight registers, one workgroup per CU: +0.55 ms per 256-frame step
     //  against the generic kernel, which already moves those layers at 4.5 TB/s; not kept)
     if (a.cin != 64 && a.cin != 128 && a.cin != 256) return false;
@@ -226,6 +278,7 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
 
 hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
     const bool res = a.g[0].res != nullptr;
+    if (a.g[0].ch_w3) return pw_launch_cfg<64, 64, true, 1, 256, true>(a, s);      // 2c + the next block's 2a (stage 2)
     // (32-pixel tiles with 5 / 4 workgroups per CU for the 64- / 128-channel reductions measured: +0.3 ms per 256-frame step)
     if (a.cin == 64) return res ? pw_launch_cfg<64, 64, true, 3>(a, s) : pw_launch_cfg<64, 64, false, 3>(a, s);
     if (a.cin == 128) return res ? pw_launch_cfg<128, 64, true, 2>(a, s) : pw_launch_cfg<128, 64, false, 2>(a, s);
@@ -387,4 +440,14 @@ hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s) {
     if (lead == 2) hipLaunchKernelGGL(slide3x3_c64_kernel<2>, dim3(std::min(nstrips, 512)), dim3(256), LDS, s, a, nstrips, xsegs);
     else hipLaunchKernelGGL(slide3x3_c64_kernel<1>, dim3(std::min(nstrips, 512)), dim3(256), 4 * 66 * 128 + 2 * 64 * 128, s, a, nstrips, xsegs);
     return hipGetLastError();
+}
+
+// Plan-time question of engine.hip: may this 1x1 expansion (64 -> 256 with shortcut, ResNet stage 2) carry the next block's 2a?  Only
+// when the launch is certain to run on the pointwise kernel (the generic kernel knows nothing of ConvGroup.ch_w3 on its own).
+bool conv_pointwise_can_fuse_next(const ConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("BOD_PW_FUSE_NEXT"); return !e || atoi(e) != 0; }();
+    static const bool forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e && atoi(e) != 0; }();
+    static const bool nt = [] { const char* e = getenv("BOD_NT_STORES"); return e && (atoi(e) & 1); }();
+    if (!on || forced || nt) return false;
+    return a.cin == 64 && a.cout_pad == 256 && a.g[0].res && conv_pointwise_eligible(a);
 }

@@ -480,6 +480,7 @@ bod_status build_plan(bod_context* h) {
         Plane t1alt;
         if (chain_ok) BODCHK(new_plane(h, &t1alt, B, hh, ww, f1));
         bool t1_ready = false;                  // the previous block's fused launch already produced this block's t1
+        bool pw_t1_ready = false;               // (same, through the pointwise kernel's fused 2a)
         for (const char* bl = blocks[st]; *bl; ++bl) {
             char cb[64], bb[64];
             snprintf(cb, sizeof cb, "res%d%c_branch", st, *bl);
@@ -535,6 +536,26 @@ bod_status build_plan(bod_context* h) {
                 use_a = !use_a;
                 continue;
             }
+            // Stage 2 on the streaming pointwise kernel (conv_pointwise.hip, BC = 256): the 1x1 expansion just added carries the NEXT
+            // block's 1x1 reduction -- computed from the finished tile in LDS, written to the t1 plane this block's 3x3 has already
+            // consumed -- when the launch is certain to run on that kernel (conv_pointwise_can_fuse_next).  BOD_PW_FUSE_NEXT=0: off.
+            auto fuse_next_2a = [&](const char* blk) -> bod_status {
+                if (st != 2 || blk[1] == 0 || train_mode || h->es != 2 || h->split) return BOD_OK;
+                Op& op2c = h->ops.back();
+                if (!conv_pointwise_can_fuse_next(op2c.conv) || op2c.conv.ksplit > 1) return BOD_OK;
+                char nb[64], nbb[64];
+                snprintf(nb, sizeof nb, "res%d%c_branch2a", st, blk[1]);
+                snprintf(nbb, sizeof nbb, "bn%d%c_branch2a", st, blk[1]);
+                PackedConv p2a;
+                BODCHK(pack_conv(h, nb, nbb, 64, &p2a));
+                if (p2a.cin != f3 || p2a.cout != f1 || p2a.taps != 1 || p2a.cout_pad != 64) return BOD_OK;
+                ConvGroup& G = op2c.conv.g[0];
+                G.ch_w3 = p2a.w; G.ch_b3 = p2a.bias; G.ch_out3 = t1.d;
+                op2c.flops += 2.0 * op2c.conv.M * (double)f1 * f3;
+                op2c.name += std::string("+") + nb; op2c.wname[2] = nb; op2c.bnname[2] = nbb;
+                pw_t1_ready = true;
+                return BOD_OK;
+            };
             if (train_mode) {                   // training keeps every activation: fresh planes per block
                 BODCHK(new_plane(h, &t1, B, hh, ww, f1));
                 BODCHK(new_plane(h, &t2, B, hh, ww, f1));
@@ -548,6 +569,7 @@ bod_status build_plan(bod_context* h) {
                 BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
                 BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
                 BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &sc));
+                BODCHK(fuse_next_2a(bl));
                 // the C3 / C4 taps are the block-'a' outputs (:119-120,:126-127): keep them alive
                 if (st == 3 || st == 4) {
                     taps[st] = out;
@@ -559,9 +581,11 @@ bod_status build_plan(bod_context* h) {
                     continue;
                 }
             } else {
-                BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, 1, false, true, nullptr));
+                if (!pw_t1_ready) BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, 1, false, true, nullptr));
+                pw_t1_ready = false;
                 BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
                 BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &x));
+                BODCHK(fuse_next_2a(bl));
             }
             x = out;
             use_a = !use_a;

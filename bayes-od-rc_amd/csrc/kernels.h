@@ -239,6 +239,7 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 // Streaming pointwise (1x1) convolution for reductions of <= 256 channels (conv_pointwise.hip); launch_conv_igemm routes eligible
 // launches there (BOD_POINTWISE=0: off)
 bool conv_pointwise_eligible(const ConvArgs& a);
+bool conv_pointwise_can_fuse_next(const ConvArgs& a);      // plan time: may a 64 -> 256 expansion carry the next block's 2a (ch_w3)?
 hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
 // Sliding-window 3x3 stride-1 SAME convolution, 64 -> 64 channels (ResNet stage 2's `2b`; conv_pointwise.hip, BOD_SLIDE3X3=0: off)
 bool conv_slide3x3_eligible(const ConvArgs& a);

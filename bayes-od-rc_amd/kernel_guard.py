@@ -266,7 +266,13 @@ POINTWISE_PRODUCTION = ["pw_conv_kernelILi64ELi64E", "pw_conv_kernelILi128ELi64E
 def verify_pointwise(host_obj):
     regs = verify_aux(host_obj, POINTWISE_PRODUCTION)
     for n, v in regs.items():
-        cap = 256 if ("ILi128ELi64E" in n or "slide3x3" in n) else 168          # two / three workgroups of four waves per CU
+        # pw_conv_kernel<K, BP, RES, WGS, BC, NEXT>: WGS workgroups of BC/32 waves per CU must stay co-resident
+        m = re.search(r"pw_conv_kernelILi\d+ELi\d+ELb[01]ELi(\d+)ELi(\d+)ELb[01]E", n)
+        if m:
+            waves_per_simd = int(m.group(1)) * (int(m.group(2)) // 32) / 4.0
+            cap = min(512, int(512 / waves_per_simd) // 8 * 8)
+        else:
+            cap = 256                                          # slide3x3: two workgroups of four waves
         if v > cap:
             raise GuardError("%s uses %d registers: more than the %d that keep its workgroups co-resident" % (n, v, cap))
     return regs

@@ -436,3 +436,43 @@ def test_sliding_window_3x3_kernel_is_bit_identical():
     for k in sorted(outs[0]):
         assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
         assert np.isfinite(outs[0][k]).all(), k
+
+
+def test_pointwise_fused_next_reduction_is_bit_identical():
+    """ResNet stage 2 on the pointwise kernel's 256-channel tile: the 1x1 expansion of a block carries the NEXT block's 1x1
+    reduction, computed from the finished tile in LDS (conv_pointwise.hip, NEXT).  BOD_PW_FUSE_NEXT=0 plans the separate
+    launches: pyramid and raw head outputs must not differ by one bit; the fused plan is two launches shorter (ResNet-50)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b, depth in (('a', (128, 128), 3, 50), ('b', (96, 160), 1, 50), ('c', (192, 624), 2, 50), ('d', (128, 128), 2, 101), ('e', (256, 256), 9, 50)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=2, backbone_depth=depth))\n"
+            "    eng.load_weights(synthetic.make_weights(depth=depth))\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=3), seed=11, first_image_id=2)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    for k, v in zip('cbv', eng.get_raw()): out['%%s_%%s' %% (tag, k)] = v\n"
+            "    out[tag + '_ops'] = np.int32(eng.plan_info()['ops'])\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_PW_FUSE_NEXT=on, BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1])
+    for k in sorted(outs[0]):
+        if k.endswith("_ops"):
+            assert int(outs[0][k]) == int(outs[1][k]) - 2, (k, int(outs[0][k]), int(outs[1][k]))
+            continue
+        assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
+        assert np.isfinite(outs[0][k]).all(), k
