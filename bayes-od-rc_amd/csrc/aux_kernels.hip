@@ -361,6 +361,176 @@ __global__ __launch_bounds__(256, 1) void stem_conv_bf16_row_kernel(const float*
     }
 }
 
+// Round 3: stem + ZeroPadding2D((1,2)) + max-pool in ONE kernel (bf16 inference, stem rows of at most 256 pixels).  A workgroup owns
+// an image and walks DOWN it: a stem row needs input rows 2r .. 2r+6, the next one two new rows -- an eight-slot LDS ring of (hi, lo)
+// input rows, every input row loaded once instead of 3.5 times -- and every stem row is max-combined in registers (packed bf16, all
+// values >= 0) into the pooling window it belongs to; every second row the window is finished through an LDS tile (the horizontal
+// 3-window, stride 2) and ONLY the pooled row is stored: the 2.1 GB stem plane (at 256 frames of 512 x 512) is neither written nor
+// re-read.  Same MFMAs in the same order as the row kernel above, the same packs and the same maxima as stem_pool_kernel:
+// bit-identical pooled plane (tests/test_gpu_forward.py::test_fused_stem_pool_is_bit_identical; BOD_STEM_POOL_FUSED=0: separate).
+constexpr int SF_RING = 8;
+constexpr int SF_LDS_BYTES = SF_RING * 2 * SR_ROWE * 2 + 256 * 128;      // ring [8][hi / lo][1560] uint16 + tile [256 px][64 ch]
+
+__device__ __forceinline__ uint32_t sf_max(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, uint16_t* __restrict__ pooled,
+                                                                 int B, int H, int W, int oh, int ow, int ph, int pw, int pool_pitch,
+                                                                 int pool_plane) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sf_smem[];
+    uint16_t* const ring = sf_smem;                                     // slot s, plane h: ring + (s * 2 + h) * SR_ROWE
+    char* const tile = reinterpret_cast<char*>(sf_smem + SF_RING * 2 * SR_ROWE);      // [256 px][128 B], 16-byte chunks swizzled by the pixel
+    uint16_t (*wl)[SB_WROW] = reinterpret_cast<uint16_t (*)[SB_WROW]>(tile);          // the weight table lives in the tile until the loop starts
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < 64 * SB_WROW; i += 256) {
+        const int co = i / SB_WROW, kp = i % SB_WROW;
+        const int c = kp >> 3, t = kp & 7, ky = c / 3, j = (c % 3) * 8 + t;
+        wl[co][kp] = (c < 21 && j < 21) ? (uint16_t)f32_to_bf16_a(w[(ky * 21 + j) * 64 + co]) : (uint16_t)0;
+    }
+    float bv[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[f][r] = bias[f * 16 + lq * 4 + r];
+    constexpr int ROWQ = SR_ROWF / 4;                                   // 389 quads per input row
+    auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
+    const int valid = W * 3;
+    const float* const im = img + (size_t)blockIdx.x * H * W * 3;
+    // quad q of input row ir: fetch / convert-and-store (hi, lo) into ring slot ir & 7
+    auto fetch_quad = [&](int ir, int q) {
+        const int c = q * 4;
+        return (q < ROWQ && c < valid && ir < H) ? *reinterpret_cast<const float4*>(im + (size_t)ir * W * 3 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit_quad = [&](int ir, int q, const float4 v) {
+        if (q >= ROWQ) return;
+        uint16_t* pb = ring + ((ir & (SF_RING - 1)) * 2) * SR_ROWE + q * 4;
+        const uint32_t h0 = pk(v.x, v.y), h1 = pk(v.z, v.w);
+        const uint32_t l0 = pk(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xFFFF0000u));
+        const uint32_t l1 = pk(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xFFFF0000u));
+        *reinterpret_cast<uint2*>(pb) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pb + SR_ROWE) = make_uint2(l0, l1);
+    };
+    // ---- prologue: input rows 0 .. 6, the weights into registers
+    for (int ir = 0; ir < 7; ++ir)
+        for (int q = tid; q < ROWQ; q += 256) commit_quad(ir, q, fetch_quad(ir, q));
+    __syncthreads();
+    const int role = lq >> 1, k1 = lq & 1;                              // this lane's B source: plane, chunk parity
+    stem_bf16x8_t aqr[11][4];
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) aqr[s][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wl[f * 16 + li][(2 * s + k1) * 8]);
+    __syncthreads();                                                    // the table's LDS becomes the pooling tile
+    uint2 vm[4][4];                                                     // running maximum of the open pooling window: [cout frag][pixel frag]
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vm[f][p] = make_uint2(0u, 0u);
+    uint16_t* const obase = pooled + (size_t)blockIdx.x * pool_plane * 64;
+
+    for (int r = 0; r < oh; ++r) {
+        // the two input rows the NEXT stem row adds (2r+7, 2r+8): four quads per thread, in flight during this row's MFMAs
+        float4 st[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int q = i * 256 + tid; st[i] = fetch_quad(2 * r + 7 + (q >= 512), q & 511); }
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[f][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int c = 2 * s + k1;
+            const int cc = c < 21 ? c : 20;                             // chunk 21 has zero weights: any finite data will do
+            const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
+            const uint16_t* pb = ring + ((((2 * r + ky) & (SF_RING - 1)) * 2) + role) * SR_ROWE + (wave * 64 + li) * 6 + j0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                union { uint32_t u[4]; stem_bf16x8_t v; } bq;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(pb + p * 96);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq.u[t] = src[t];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqr[s][f], bq.v, acc[f][p], 0, 0, 0);
+            }
+        }
+        // this stem row joins the open pooling window (rows 2p-1, 2p, 2p+1): bias + ReLU + pack exactly like the stem kernels, then a
+        // packed signed 16-bit maximum (every value is >= +0; a -0 from fmaxf can never win against the window's initial +0)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const uint32_t x = pk(fmaxf(acc[f][p][0] + bv[f][0], 0.f), fmaxf(acc[f][p][1] + bv[f][1], 0.f));
+                const uint32_t y = pk(fmaxf(acc[f][p][2] + bv[f][2], 0.f), fmaxf(acc[f][p][3] + bv[f][3], 0.f));
+                vm[f][p].x = sf_max(vm[f][p].x, x); vm[f][p].y = sf_max(vm[f][p].y, y);
+                acc[f][p][0] = __uint_as_float(x); acc[f][p][1] = __uint_as_float(y);      // (kept: an odd row opens the next window)
+            }
+        const bool closes = (r & 1) || r == oh - 1;                     // row 2p+1 closes window p; so does the last row of an odd-height plane
+        if (closes) {
+            const int prow = r >> 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int px = wave * 64 + p * 16 + li;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    *reinterpret_cast<uint2*>(tile + px * 128 + (((f * 2 + (lq >> 1)) ^ (px & 7)) << 4) + (lq & 1) * 8) = vm[f][p];
+            }
+            __syncthreads();
+            if (prow < ph) {
+                // horizontal window: pooled column q = max over stem columns 2q-2, 2q-1, 2q (those inside the row)
+                for (int i = tid; i < pw * 8; i += 256) {
+                    const int q = i >> 3, ch = i & 7;
+                    uint4 m = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int px = 2 * q + kx - 2;
+                        if (px < 0 || px >= ow) continue;
+                        const uint4 v = *reinterpret_cast<const uint4*>(tile + px * 128 + ((ch ^ (px & 7)) << 4));
+                        m.x = sf_max(m.x, v.x); m.y = sf_max(m.y, v.y); m.z = sf_max(m.z, v.z); m.w = sf_max(m.w, v.w);
+                    }
+                    *reinterpret_cast<uint4*>(obase + ((size_t)(prow + 1) * pool_pitch + (q + 1)) * 64 + ch * 8) = m;
+                }
+            }
+            // the closing row (when it is row 2p+1) opens window p+1
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) vm[f][p] = make_uint2(__float_as_uint(acc[f][p][0]), __float_as_uint(acc[f][p][1]));
+        }
+        __syncthreads();                                                // every wave is done with input rows 2r, 2r+1 (and the tile)
+        if (r + 1 < oh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int q = i * 256 + tid; commit_quad(2 * r + 7 + (q >= 512), q & 511, st[i]); }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int B, int H, int W, int oh, int ow,
+                                  int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s) {
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_pool_fused_kernel, dim3(B), dim3(256), SF_LDS_BYTES, s, img, w, bias, reinterpret_cast<uint16_t*>(pooled), B, H, W, oh, ow,
+                       ph, pw, pool_pitch, pool_plane);
+    return hipGetLastError();
+}
+// the fused kernel's shapes: one 256-pixel segment per stem row, 16-byte aligned rows, enough images to fill the chip's CUs
+bool stem_pool_fused_applies(const float* img, int B, int W, int ow) {
+    static const bool on = [] { const char* e = getenv("BOD_STEM_POOL_FUSED"); return !e || atoi(e) != 0; }();
+    static const int min_b = [] { const char* e = getenv("BOD_STEM_POOL_FUSED_MIN_B"); return e ? atoi(e) : 128; }();
+    return on && ow <= SR_SEG && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && B >= min_b;
+}
+
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,
                             int B, int H, int W, int oh, int ow, hipStream_t s) {
     const int segs = (ow + ST_SEG - 1) / ST_SEG;

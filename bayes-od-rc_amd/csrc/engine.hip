@@ -918,6 +918,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         HIPCHK(h, hipEventRecord(tev[0], h->stream));
     }
     size_t op_i = 0;
+    bool stem_pool_fused = false;
     std::string cur_stage;                                        // open marker range (BOD_ROCTX=1)
     struct StageCloser { std::string& s; ~StageCloser() { if (!s.empty()) markers().pop(); } } stage_closer{cur_stage};
     for (Op& op : h->ops) {
@@ -933,7 +934,16 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
             }
         }
         switch (op.kind) {
-            case Op::STEM:
+            case Op::STEM: {
+                // bf16 inference on rows of <= 256 stem pixels: stem + zero-pad + max-pool in one kernel (the stem plane is never
+                // written; aux_kernels.hip, BOD_STEM_POOL_FUSED=0: the two launches).  Training handles keep the plane (pool backward).
+                const Op* pool = op_i < h->ops.size() && h->ops[op_i].kind == Op::POOL ? &h->ops[op_i] : nullptr;
+                stem_pool_fused = pool && !h->train && h->es == 2 && !h->split && !trace &&
+                                  stem_pool_fused_applies(dev_images, c.batch, c.image_w, h->sw);
+                if (stem_pool_fused)
+                    HIPCHK(h, launch_stem_pool_fused(dev_images, h->stem_w, h->stem_b, pool->conv.g[0].out, c.batch, c.image_h, c.image_w, h->sh,
+                                                     h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
+                else
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, h->stream));
                 // the frames are consumed: the copy stream may refill this buffer.  (Training handles read the frames again in the
@@ -941,7 +951,9 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 // mark_images_consumed, train_impl.inc)
                 if (!h->train) BODCHK(mark_images_consumed(h));
                 break;
+            }
             case Op::POOL:
+                if (stem_pool_fused) break;
                 HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->split ? 2 : (h->es == 4 ? 1 : 0), c.batch,
                                            h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
                 break;

@@ -122,6 +122,10 @@ hipError_t launch_stem_conv(const float* img, const float* w, const float* bias,
                             int B, int H, int W, int oh, int ow, hipStream_t s);
 // ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on [B,ih,iw,64] -> padded-plane output.  mode 0: bf16 -> bf16; 1: fp32 -> fp32;
 // 2: fp32 -> (hi, lo) bf16 pairs (bf16x3 precision)
+// stem + zero-pad + max-pool in one kernel (bf16 inference, stem rows of <= 256 pixels; aux_kernels.hip)
+bool stem_pool_fused_applies(const float* img, int B, int W, int ow);
+hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int B, int H, int W, int oh, int ow,
+                                  int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s);
 hipError_t launch_stem_pool(const void* in, void* out, int mode, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s);
 

@@ -476,3 +476,39 @@ def test_pointwise_fused_next_reduction_is_bit_identical():
             continue
         assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
         assert np.isfinite(outs[0][k]).all(), k
+
+
+def test_fused_stem_pool_is_bit_identical():
+    """bf16 inference on stem rows of at most 256 pixels runs stem + ZeroPadding2D((1,2)) + max-pool as ONE kernel (aux_kernels.hip,
+    stem_pool_fused_kernel: a workgroup walks down an image with an 8-row input ring, stem rows are max-combined in registers,
+    only the pooled rows are stored).  BOD_STEM_POOL_FUSED=0 runs the two launches: the pyramid must not differ by one bit --
+    even / odd stem heights, widths below and at the 256-pixel limit, several images."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b in (('a', (128, 128), 3), ('b', (96, 160), 2), ('c', (512, 512), 2), ('d', (192, 512), 1), ('e', (128, 126), 1)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=1))\n"
+            "    eng.load_weights(synthetic.make_weights())\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=4), seed=1, first_image_id=0)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_STEM_POOL_FUSED=on, BOD_STEM_POOL_FUSED_MIN_B="1")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) == 25
+    for k in sorted(outs[0]):
+        assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
+        assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k

@@ -44,7 +44,7 @@ def test_row_task_stem_kernel_does_not_spill():
         pytest.skip("hipcc not available")
     build_mod.build(verbose=False)
     regs = guard.verify_aux(os.path.join(build_mod.LIB_DIR, "obj", "aux_kernels.o"))
-    assert len(regs) == 1 and 256 < list(regs.values())[0] <= 512, regs
+    assert len(regs) == 2 and all(256 < v <= 512 for v in regs.values()), regs
 
 
 def test_pointwise_kernels_keep_their_residency():
