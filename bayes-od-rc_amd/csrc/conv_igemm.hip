@@ -2166,6 +2166,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_pointwise_eligible(a)) return launch_conv_pointwise(a, s);   // streaming 1x1 kernel (bit-identical)
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_slide3x3_eligible(a)) return launch_conv_slide3x3(a, s);     // sliding-window 3x3, 64 -> 64 (bit-identical)
+    // a fused "next block's 2a" (ch_w3 without the chain's ch_w2) exists only in the pointwise kernel: a plan that carries one must
+    // never fall through to the generic kernel, which would run the expansion and silently skip the reduction
+    if (a.g[0].ch_w3 && !a.g[0].ch_w2) return hipErrorInvalidValue;
     bool big = conv_big_tile_pays(a);
     if (a.fan_count > 1 && fan_out_small_tile()) big = false;
     if (forced == 256) big = a.cout_pad % 256 == 0 && !(a.flags & CONV_OUT_F32);

@@ -448,6 +448,7 @@ bool conv_pointwise_can_fuse_next(const ConvArgs& a) {
     static const bool on = [] { const char* e = getenv("BOD_PW_FUSE_NEXT"); return !e || atoi(e) != 0; }();
     static const bool forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e && atoi(e) != 0; }();
     static const bool nt = [] { const char* e = getenv("BOD_NT_STORES"); return e && (atoi(e) & 1); }();
-    if (!on || forced || nt) return false;
+    static const bool res_reg = [] { const char* e = getenv("BOD_RES_REGISTER"); return e && atoi(e) == 1; }();   // (sends the launch to a variant build)
+    if (!on || forced || nt || res_reg) return false;
     return a.cin == 64 && a.cout_pad == 256 && a.g[0].res && conv_pointwise_eligible(a);
 }
