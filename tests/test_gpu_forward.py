@@ -464,7 +464,7 @@ def test_pointwise_fused_next_reduction_is_bit_identical():
     for on in ("1", "0"):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "o.npz")
-            env = dict(os.environ, BOD_PW_FUSE_NEXT=on, BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
+            env = dict(os.environ, BOD_PW_FUSE_NEXT=on, BOD_POINTWISE="1", BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
             r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr[-3000:]
             z = np.load(path)
