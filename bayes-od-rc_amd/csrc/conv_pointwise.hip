@@ -63,9 +63,10 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
     static_assert(NXP >= 1 && NRP >= 1 && BP % 32 == 0 && (CPX & 7) == 0 && (!NEXT || (BC == 256 && BP == 64 && NTP == 1)), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char pw_smem[];
     char* const xbuf = pw_smem;                   // [2][BP][K] bf16, chunk-swizzled
-    char* const rbuf = pw_smem + 2 * XB;          // [2][BP][BC] bf16, chunk-swizzled
-    int4* const meta = reinterpret_cast<int4*>(pw_smem + 2 * XB + 2 * RB);      // [3][BP] {in_off, out_off, res_off, valid}
-    char* const tbuf = pw_smem + 2 * XB + 2 * RB + 3 * BP * 16;                 // NEXT: [BP][64] bf16 tile of the fused 2a
+    constexpr int NRB = RES ? 2 : 1;              // shortcut / output buffers: double-buffered only when a shortcut is DMA'd into them
+    char* const rbuf = pw_smem + 2 * XB;          // [NRB][BP][BC] bf16, chunk-swizzled
+    int4* const meta = reinterpret_cast<int4*>(pw_smem + 2 * XB + NRB * RB);    // [3][BP] {in_off, out_off, res_off, valid}
+    char* const tbuf = pw_smem + 2 * XB + NRB * RB + 3 * BP * 16;               // NEXT: [BP][64] bf16 tile of the fused 2a
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
         __syncthreads();
 
         const char* xb = xbuf + (t & 1) * XB;
-        char* rb = rbuf + (t & 1) * RB;
+        char* rb = rbuf + (RES ? (t & 1) : 0) * RB;
         pw_f32x16 acc[FP];
 #pragma unroll
         for (int j = 0; j < FP; ++j)
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
 
 template <int K, int BP, bool RES, int WGS, int BC = 128, bool NEXT = false>
 static hipError_t pw_launch_cfg(const ConvArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * BP * K * 2 + 2 * BP * BC * 2 + 3 * BP * 16 + (NEXT ? BP * 128 : 0);
+    constexpr int LDS = 2 * BP * K * 2 + (RES ? 2 : 1) * BP * BC * 2 + 3 * BP * 16 + (NEXT ? BP * 128 : 0);
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
     auto kern = pw_conv_kernel<K, BP, RES, WGS, BC, NEXT>;
@@ -264,9 +265,12 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
     if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
     if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind) return false;
     if (g.ch_w3 && !(a.cin == 64 && a.cout_pad == 256 && g.res && g.ch_b3 && g.ch_out3)) return false;   // fused next 2a: stage 2's shape only
-    // (512-channel reductions measured on this kernel -- 128 weight registers, one workgroup per CU: +0.55 ms per 256-frame step
-    //  against the generic kernel, which already moves those layers at 4.5 TB/s; not kept)
-    if (a.cin != 64 && a.cin != 128 && a.cin != 256) return false;
+    // (512-channel reductions WITH shortcut need two output buffers and fit one workgroup per CU only: +0.55 ms per 256-frame step
+    //  against the generic kernel, not kept)
+    // 512-channel reductions WITHOUT shortcut (stage 3's `2a`, stage 4's first block, the C3 lateral of the FPN): 128 weight registers,
+    // 32-pixel tiles and a single output buffer keep two workgroups on a CU; -0.1 ms per 256-frame step (BOD_PW_K512=0: generic)
+    static const bool k512 = [] { const char* e = getenv("BOD_PW_K512"); return !e || atoi(e) != 0; }();
+    if (a.cin != 64 && a.cin != 128 && a.cin != 256 && !(k512 && a.cin == 512 && !g.res)) return false;
     // (64-channel cout tiles -- stage 2's `2a` reductions -- measured on this kernel: no difference to the generic 64x128 tiles, three
     //  workgroups per CU, that run them now; not kept)
     if (a.cout_pad % 128 != 0 || a.cout_valid != a.cout_pad) return false;
@@ -282,6 +286,7 @@ hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
     // (32-pixel tiles with 5 / 4 workgroups per CU for the 64- / 128-channel reductions measured: +0.3 ms per 256-frame step)
     if (a.cin == 64) return res ? pw_launch_cfg<64, 64, true, 3>(a, s) : pw_launch_cfg<64, 64, false, 3>(a, s);
     if (a.cin == 128) return res ? pw_launch_cfg<128, 64, true, 2>(a, s) : pw_launch_cfg<128, 64, false, 2>(a, s);
+    if (a.cin == 512) return pw_launch_cfg<512, 32, false, 2>(a, s);
     return res ? pw_launch_cfg<256, 32, true, 3>(a, s) : pw_launch_cfg<256, 32, false, 3>(a, s);
 }
 
