@@ -26,7 +26,8 @@ class BodConfig(C.Structure):
         ("mc_ensemble_size", C.c_int32),
         ("training", C.c_int32),
         ("backbone_depth", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("pipeline_overlap", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

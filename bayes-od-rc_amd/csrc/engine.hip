@@ -131,6 +131,23 @@ struct bod_context {
     float* out_scores = nullptr; float* out_means = nullptr; float* out_covs = nullptr; float* out_counts = nullptr;
     int slot = 0;
     hipStream_t side = nullptr;
+    // ---- CU-partitioned pipeline overlap (bod_config.pipeline_overlap; bod_infer_async only).  The memory-bound front of batch i+1
+    // (stem, backbone, FPN) runs on its own stream, masked to the last `ov_front_slots` CU slots of every XCD, while the MFMA-bound
+    // back of batch i (fan-out layer, towers, posterior) runs on the other slots: `back` = the main stream of such a call (h->stream
+    // points at it for the call's duration), `full` = the unmasked main stream every other entry point uses.  The only tensor that
+    // crosses the partition is the pyramid, double-buffered (pyr_d); ev_front_done[p]: front of the batch with parity p finished,
+    // ev_l0_done[p]: the fan-out layer that read pyramid p finished (the front two batches later waits for it).
+    int overlap_mode = 0;                               // 0 off, 1 CU-masked streams, 2 plain streams (A/B)
+    int ov_front_slots = 0, ov_slots = 0;
+    hipStream_t full = nullptr, front = nullptr, back = nullptr;
+    hipEvent_t ev_front_done[2] = {nullptr, nullptr}, ev_l0_done[2] = {nullptr, nullptr}, ev_join = nullptr;
+    bool l0_pending[2] = {false, false};
+    bool ov_dirty = false;                              // front / back hold work no `full`-stream call has been ordered behind yet
+    char* pyr_d[2] = {nullptr, nullptr};                // pyr_d[0] == pyramid.d; [1] only on overlap handles
+    int fwd_parity = 0, pyr_last = 0;
+    int first_head_op = 0;                              // index of the first head launch in ops: everything before it is the front
+    bool in_overlap_call = false;
+    int n_cu = 256;                                     // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     hipEvent_t ev_posterior = nullptr; hipEvent_t ev_done[2] = {nullptr, nullptr};
     bool side_pending[2] = {false, false};
     char* host_stage[2] = {nullptr, nullptr};     // pinned host copy of a slot's records (filled on the side stream)
@@ -185,6 +202,15 @@ namespace {
 
 const char* kHeadPrefix[3] = {"pyramid_classification", "pyramid_regression", "pyramid_cov"};
 const int kHeadConvs[3] = {4, 3, 4};     // RegHeader.call uses 3 towers convs (multitask_headers.py:209-230)
+
+// CU mask of hipExtStreamCreateWithCUMask for CU slots [lo, hi) of every XCD.  On MI355X (8 XCDs x 32 CUs) mask bit i selects slot
+// i / 8 of XCD i % 8 (tests/tools/cu_mask_probe.hip; an XCD without any bit set keeps all its CUs), so a slot range is symmetric
+// over the XCDs and workgroup b still lands on XCD b % 8 -- what the tower kernel's XCD-aware tile order assumes.
+void cu_slot_mask(int lo, int hi, uint32_t mask[8]) {
+    for (int w = 0; w < 8; ++w) mask[w] = 0u;
+    for (int slot = lo; slot < hi; ++slot)
+        for (int xcd = 0; xcd < 8; ++xcd) { const int bit = slot * 8 + xcd; mask[bit >> 5] |= 1u << (bit & 31); }
+}
 
 int same_pad_before(int in, int k, int s) {
     const int out = (in + s - 1) / s;
@@ -800,6 +826,10 @@ bod_status build_plan(bod_context* h) {
         for (Op& o : h->ops) if (o.kind == Op::CONV && o.conv.ksplit > 1) o.conv.partial = h->splitk_partial;
     }
     if (h->split) for (Op& o : h->ops) if (o.kind == Op::CONV) to_split_args(&o.conv);
+    h->first_head_op = (int)h->ops.size();
+    for (size_t i = 0; i < h->ops.size(); ++i) if (h->ops[i].is_head3x3) { h->first_head_op = (int)i; break; }
+    h->pyr_d[0] = h->pyramid.d;
+    if (h->overlap_mode) BODCHK(h->dalloc(&h->pyr_d[1], (size_t)B * h->Ppad * 256 * h->es));      // zero borders like the first
     return BOD_OK;
 }
 
@@ -894,23 +924,45 @@ static std::string op_stage(const std::string& name) {
 
 // Records ev_img_free for the image buffer the current call reads (bod_device_images_buffer(k)): everything enqueued on the main
 // stream so far has finished with the frames once the event fires; bod_upload_frames_u8_async makes the copy stream wait on it.
-bod_status mark_images_consumed(bod_context* h) {
+bod_status mark_images_consumed(bod_context* h, hipStream_t st = nullptr) {
     if (h->cur_img_buf >= 0 && h->copy) {
-        HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_img_free[h->cur_img_buf], st ? st : h->stream));
         h->img_free_pending[h->cur_img_buf] = true;
     }
     return BOD_OK;
 }
 
+// Every entry point but the pipelined ones (bod_infer_async, bod_collect, bod_gather_detections of a ticket, the asynchronous upload)
+// works on the unmasked `full` stream: it first waits for whatever the partition's two streams still hold.
+bod_status join_overlap(bod_context* h) {
+    if (!h->ov_dirty) return BOD_OK;
+    HIPCHK(h, hipStreamSynchronize(h->front));
+    HIPCHK(h, hipStreamSynchronize(h->back));
+    h->ov_dirty = false;
+    return BOD_OK;
+}
+
+// overlapped (bod_infer_async on a pipeline_overlap handle; h->stream == h->back for the call): the ops in front of the first head
+// launch go to h->front, the pyramid they write is buffer `fwd_parity` of two, and two events hand it to the back and take it back.
 bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, uint32_t first_image, int flavour = FLAVOUR_RAW,
-                       bool only_flavoured = false) {
+                       bool only_flavoured = false, bool overlapped = false) {
     const bod_config& c = h->cfg;
     if (flavour == FLAVOUR_RAW && !only_flavoured) BODCHK(ensure_raw(h));
+    const bool ov = overlapped && h->overlap_mode != 0 && !only_flavoured;
+    hipStream_t fs = ov ? h->front : h->stream;
+    int par = 0;
+    if (ov) {
+        par = h->fwd_parity; h->fwd_parity ^= 1;
+        if (h->l0_pending[par]) { HIPCHK(h, hipStreamWaitEvent(fs, h->ev_l0_done[par], 0)); h->l0_pending[par] = false; }
+    }
+    if (!only_flavoured) h->pyr_last = par;
+    const int cus_front = ov && h->overlap_mode == 1 ? h->ov_front_slots * 8 : h->n_cu;
+    const int cus_back = ov && h->overlap_mode == 1 ? (h->ov_slots - h->ov_front_slots) * 8 : h->n_cu;
     // BOD_TRACE_OPS=k: the k-th forward call is traced op by op (HIP events on the engine stream) and a table
     // is printed to stderr -- a development aid (tests/tools), off by default.
     static const int trace_call = getenv("BOD_TRACE_OPS") ? atoi(getenv("BOD_TRACE_OPS")) : 0;
     static int call_no = 0;
-    const bool trace = trace_call > 0 && ++call_no == trace_call;
+    const bool trace = trace_call > 0 && ++call_no == trace_call && !ov;
     std::vector<hipEvent_t> tev;
     if (trace) {
         tev.resize(h->ops.size() + 1);
@@ -923,8 +975,15 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
     struct StageCloser { std::string& s; ~StageCloser() { if (!s.empty()) markers().pop(); } } stage_closer{cur_stage};
     for (Op& op : h->ops) {
         if (trace && op_i > 0) HIPCHK(h, hipEventRecord(tev[op_i], h->stream));
+        const bool is_front = (int)op_i < h->first_head_op;
+        const bool first_back = (int)op_i == h->first_head_op;
+        hipStream_t st = is_front ? fs : h->stream;
         ++op_i;
         if ((op.flavour != FLAVOUR_BOTH && op.flavour != flavour) || (only_flavoured && op.flavour == FLAVOUR_BOTH)) continue;
+        if (ov && first_back) {                          // the pyramid is complete: hand it to the back
+            HIPCHK(h, hipEventRecord(h->ev_front_done[par], fs));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done[par], 0));
+        }
         if (markers().on) {
             std::string st = op_stage(op.name);
             if (st != cur_stage) {
@@ -942,20 +1001,20 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                                   stem_pool_fused_applies(dev_images, c.batch, c.image_w, h->sw);
                 if (stem_pool_fused)
                     HIPCHK(h, launch_stem_pool_fused(dev_images, h->stem_w, h->stem_b, pool->conv.g[0].out, c.batch, c.image_h, c.image_w, h->sh,
-                                                     h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
+                                                     h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
                 else
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
-                                           c.image_w, h->sh, h->sw, h->stream));
+                                           c.image_w, h->sh, h->sw, st));
                 // the frames are consumed: the copy stream may refill this buffer.  (Training handles read the frames again in the
                 // backward pass -- bf16 copy + stem weight gradient -- and record the event at the end of the step instead:
                 // mark_images_consumed, train_impl.inc)
-                if (!h->train) BODCHK(mark_images_consumed(h));
+                if (!h->train) BODCHK(mark_images_consumed(h, st));
                 break;
             }
             case Op::POOL:
                 if (stem_pool_fused) break;
                 HIPCHK(h, launch_stem_pool(h->stem_out, op.conv.g[0].out, h->split ? 2 : (h->es == 4 ? 1 : 0), c.batch,
-                                           h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), h->stream));
+                                           h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
                 break;
             case Op::CONV: {
                 op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
@@ -967,13 +1026,26 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timed) {
                     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-                    HIPCHK(h, hipEventRecord(e0, h->stream));
+                    HIPCHK(h, hipEventRecord(e0, st));
                 }
-                HIPCHK(h, (h->es == 4 && !h->split) ? launch_conv_igemm_f32(op.conv, h->stream) : launch_conv_igemm(op.conv, h->stream));
+                op.conv.n_cu = is_front ? cus_front : cus_back;          // compute units this launch may fill (planner: workgroups vs CUs)
+                if (par != 0) {                                  // the second pyramid buffer of an overlap handle
+                    ConvArgs a = op.conv;
+                    for (int g = 0; g < a.groups; ++g) {
+                        if (a.g[g].in == h->pyr_d[0]) a.g[g].in = h->pyr_d[1];
+                        if (a.g[g].out == h->pyr_d[0]) a.g[g].out = h->pyr_d[1];
+                    }
+                    HIPCHK(h, (h->es == 4 && !h->split) ? launch_conv_igemm_f32(a, st) : launch_conv_igemm(a, st));
+                } else
+                HIPCHK(h, (h->es == 4 && !h->split) ? launch_conv_igemm_f32(op.conv, st) : launch_conv_igemm(op.conv, st));
                 if (timed) {
-                    HIPCHK(h, hipEventRecord(e1, h->stream));
+                    HIPCHK(h, hipEventRecord(e1, st));
                     h->ev_head.emplace_back(e0, e1);
                     h->prof_flops += op.flops;
+                }
+                if (ov && first_back) {                          // the fan-out layer has read pyramid `par`
+                    HIPCHK(h, hipEventRecord(h->ev_l0_done[par], h->stream));
+                    h->l0_pending[par] = true;
                 }
                 break;
             }
@@ -1066,15 +1138,16 @@ bod_status run_cluster(bod_context* h, hipStream_t st) {
     return BOD_OK;
 }
 
-bod_status stage_images(bod_context* h, const float* images, int on_device, const float** dev) {
+bod_status stage_images(bod_context* h, const float* images, int on_device, const float** dev, hipStream_t st = nullptr) {
     if (!images) return h->fail(BOD_ERR_INVALID_ARG, "images is NULL");
+    if (!st) st = h->stream;                            // the stream the stem will run on
     h->cur_img_buf = -1;
     if (on_device) {
         for (int k = 0; k < 2; ++k)
             if (images == h->d_images_b[k] && h->d_images_b[k]) {
                 h->cur_img_buf = k;
                 if (h->img_ready_pending[k]) {           // filled by bod_upload_frames_u8_async on the copy stream
-                    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_img_ready[k], 0));
+                    HIPCHK(h, hipStreamWaitEvent(st, h->ev_img_ready[k], 0));
                     h->img_ready_pending[k] = false;
                 }
             }
@@ -1082,7 +1155,7 @@ bod_status stage_images(bod_context* h, const float* images, int on_device, cons
         return BOD_OK;
     }
     const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
-    HIPCHK(h, hipMemcpyAsync(h->d_images, images, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_images, images, bytes, hipMemcpyHostToDevice, st));
     *dev = h->d_images;
     return BOD_OK;
 }
@@ -1148,8 +1221,50 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     h->es = c.precision == BOD_PRECISION_BF16 ? 2 : 4;
     h->split = c.precision == BOD_PRECISION_BF16X3;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
+    // BOD_MAIN_CUS_PER_XCD=k (development aid, tests/tools): the main stream owns only CU slots [0, k) of each of the 8 XCDs
+    // (mask bit i = slot i / 8 of XCD i % 8: tests/tools/cu_mask_probe.hip)
+    if (const char* e = getenv("BOD_MAIN_CUS_PER_XCD")) {
+        uint32_t mask[8];
+        cu_slot_mask(0, std::max(1, std::min(32, atoi(e))), mask);
+        if (hipExtStreamCreateWithCUMask(&h->stream, 8, mask) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipExtStreamCreateWithCUMask failed"));
+    } else
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+    h->full = h->stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipGetDeviceProperties failed"));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // pipeline overlap: BOD_OVERLAP=0 forces it off, =1 on (CU-masked streams), =2 on with two plain streams (A/B aid);
+        // BOD_OVERLAP_FRONT_SLOTS=k: CU slots per XCD the front owns (default 4; the workgroup dispatcher balances over the four
+        // shader engines of an XCD, so only multiples of 4 change anything: tests/tools/cu_mask_probe.hip)
+        int want = c.pipeline_overlap ? 1 : 0;
+        if (const char* e = getenv("BOD_OVERLAP")) want = atoi(e);
+        if (c.training) want = 0;
+        if (want) {
+            const int slots = h->n_cu / 8;
+            int fs = getenv("BOD_OVERLAP_FRONT_SLOTS") ? atoi(getenv("BOD_OVERLAP_FRONT_SLOTS")) : 4;
+            fs = std::max(1, std::min(fs, slots - 1));
+            const bool masks = want == 1 && h->n_cu % 8 == 0 && slots >= 8 && slots <= 32;
+            if (masks) {
+                uint32_t mf[8], mb[8];
+                cu_slot_mask(slots - fs, slots, mf);
+                cu_slot_mask(0, slots - fs, mb);
+                if (hipExtStreamCreateWithCUMask(&h->front, 8, mf) != hipSuccess || hipExtStreamCreateWithCUMask(&h->back, 8, mb) != hipSuccess)
+                    return bail(h->fail(BOD_ERR_HIP, "hipExtStreamCreateWithCUMask failed"));
+                h->overlap_mode = 1; h->ov_front_slots = fs; h->ov_slots = slots;
+            } else {
+                if (hipStreamCreateWithFlags(&h->front, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->back, hipStreamNonBlocking) != hipSuccess)
+                    return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+                h->overlap_mode = 2; h->ov_front_slots = 0; h->ov_slots = slots;
+            }
+            for (int k = 0; k < 2; ++k)
+                if (hipEventCreateWithFlags(&h->ev_front_done[k], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_l0_done[k], hipEventDisableTiming) != hipSuccess)
+                    return bail(h->fail(BOD_ERR_HIP, "hipEventCreate failed"));
+            if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipEventCreate failed"));
+        }
+    }
     if (hipEventCreateWithFlags(&h->ev_posterior, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_done[1], hipEventDisableTiming) != hipSuccess)
@@ -1167,6 +1282,11 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
 bod_status bod_destroy(bod_handle h) {
     if (!h) return BOD_OK;
     hipSetDevice(h->cfg.device);
+    h->stream = h->full;
+    if (h->front) { hipStreamSynchronize(h->front); hipStreamDestroy(h->front); }
+    if (h->back) { hipStreamSynchronize(h->back); hipStreamDestroy(h->back); }
+    for (int k = 0; k < 2; ++k) { if (h->ev_front_done[k]) hipEventDestroy(h->ev_front_done[k]); if (h->ev_l0_done[k]) hipEventDestroy(h->ev_l0_done[k]); }
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
     if (h->ev_posterior) hipEventDestroy(h->ev_posterior);
@@ -1209,7 +1329,7 @@ bod_status bod_update_config(bod_handle h, const bod_config* cfg) {
         cfg->mc_samples != o.mc_samples || cfg->num_classes != o.num_classes ||
         cfg->anchors_per_location != o.anchors_per_location || cfg->min_level != o.min_level ||
         cfg->max_level != o.max_level || cfg->has_covar_head != o.has_covar_head || cfg->dropout_rate != o.dropout_rate ||
-        cfg->precision != o.precision || cfg->training != o.training || cfg->backbone_depth != o.backbone_depth || (std::max(cfg->mc_ensemble_size, cfg->mc_samples) > 1) != (std::max(o.mc_ensemble_size, o.mc_samples) > 1))
+        cfg->precision != o.precision || cfg->training != o.training || cfg->backbone_depth != o.backbone_depth || cfg->pipeline_overlap != o.pipeline_overlap || (std::max(cfg->mc_ensemble_size, cfg->mc_samples) > 1) != (std::max(o.mc_ensemble_size, o.mc_samples) > 1))
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: geometry / model fields cannot change on a live handle");
     if (cfg->nms_max_output_size != o.nms_max_output_size)
         return h->fail(BOD_ERR_INVALID_ARG, "bod_update_config: nms_max_output_size sizes device buffers and cannot change");
@@ -1237,6 +1357,7 @@ bod_status bod_load_weight(bod_handle h, const char* name, int32_t kind, const i
 
 bod_status bod_finalize_weights(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->weights_ready) return BOD_OK;
     if (!h->ops.empty()) return h->fail(BOD_ERR_INVALID_ARG, "weights were already finalized; create a new handle to reload");
@@ -1249,6 +1370,7 @@ bod_status bod_finalize_weights(bod_handle h) {
 
 bod_status bod_set_anchors(bod_handle h, const float* anchors, int32_t n) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!anchors || n != h->A) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_anchors: expected %d anchors, got %d", h->A, n);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_anchors, anchors, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
@@ -1259,6 +1381,7 @@ bod_status bod_set_anchors(bod_handle h, const float* anchors, int32_t n) {
 
 bod_status bod_upload_images(bod_handle h, const float* host_images) {
     if (!h || !host_images) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->cfg.batch * h->cfg.image_h * h->cfg.image_w * 3 * sizeof(float);
     HIPCHK(h, hipMemcpyAsync(h->d_images, host_images, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1297,6 +1420,7 @@ bod_status bod_upload_frames_u8(bod_handle h, const uint8_t* rgb, int32_t src_h,
                                 int32_t aspect_resize) {
     MarkerRange mr_api("bod:upload");
     if (!h || !rgb || !rgb_means || src_h < 1 || src_w < 1) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     const bod_config& c = h->cfg;
     HIPCHK(h, hipSetDevice(c.device));
     PreprocArgs a{};
@@ -1345,7 +1469,10 @@ bod_status bod_upload_frames_u8_async(bod_handle h, const uint8_t* rgb, int32_t 
     // do not overwrite frames a forward pass still has to read (its stem records ev_img_free), nor frames of an upload
     // nobody consumed yet (same stream: ordered)
     if (h->img_free_pending[buffer]) { HIPCHK(h, hipStreamWaitEvent(h->copy, h->ev_img_free[buffer], 0)); h->img_free_pending[buffer] = false; }
-    else if (buffer == 0) HIPCHK(h, hipStreamSynchronize(h->stream));       // buffer 0 doubles as the synchronous d_images
+    else if (buffer == 0) {                                                   // buffer 0 doubles as the synchronous d_images
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->front) HIPCHK(h, hipStreamSynchronize(h->front));
+    }
     a.src = h->d_u8_b[buffer]; a.dst = h->d_images_b[buffer];
     HIPCHK(h, hipMemcpyAsync(h->d_u8_b[buffer], rgb, bytes, hipMemcpyHostToDevice, h->copy));
     HIPCHK(h, launch_preprocess(a, h->copy));
@@ -1362,6 +1489,7 @@ const float* bod_device_images(bod_handle h) { return h ? h->d_images : nullptr;
 
 bod_status bod_synchronize(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (h->copy) HIPCHK(h, hipStreamSynchronize(h->copy));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->side));
@@ -1371,6 +1499,7 @@ bod_status bod_synchronize(bod_handle h) {
 
 bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const float* dev = nullptr;
@@ -1382,6 +1511,7 @@ bod_status bod_forward(bod_handle h, const float* images, int32_t on_device, uin
 
 bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* cov) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     BODCHK(materialise_raw(h));
@@ -1399,6 +1529,7 @@ bod_status bod_get_raw(bod_handle h, float* cls, float* box, float* cov) {
 
 bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const float* cov) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     HIPCHK(h, hipSetDevice(h->cfg.device));
     BODCHK(ensure_raw(h));
     const bod_config& c = h->cfg;
@@ -1414,11 +1545,12 @@ bod_status bod_set_raw(bod_handle h, const float* cls, const float* box, const f
 
 bod_status bod_get_pyramid(bod_handle h, int32_t l, float* out) {
     if (!h || !out) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->forward_done || !h->pyramid.d) return h->fail(BOD_ERR_NOT_READY, "bod_forward has not run");
     if (l < 0 || l >= h->nlev) return h->fail(BOD_ERR_INVALID_ARG, "level index %d out of range", l);
     const int B = h->cfg.batch;
     std::vector<char> tmp((size_t)B * h->Ppad * 256 * h->es);
-    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pyramid.d, tmp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pyr_d[h->pyr_last] ? h->pyr_d[h->pyr_last] : h->pyramid.d, tmp.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int hh = h->lh[l], ww = h->lw[l], pitch = ww + 2;
     for (int b = 0; b < B; ++b)
@@ -1441,6 +1573,7 @@ bod_status bod_get_pyramid(bod_handle h, int32_t l, float* out) {
 
 bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward / bod_set_raw has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return run_posterior(h, seed, first_image_id);
@@ -1448,6 +1581,7 @@ bod_status bod_posterior(bod_handle h, uint64_t seed, uint32_t first_image_id) {
 
 bod_status bod_validation_post(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->forward_done) return h->fail(BOD_ERR_NOT_READY, "bod_forward / bod_set_raw has not run");
     if (!h->anchors_ready) return h->fail(BOD_ERR_NOT_READY, "bod_set_anchors has not been called");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1464,6 +1598,7 @@ bod_status bod_validation_post(bod_handle h) {
 
 bod_status bod_get_num_kept(bod_handle h, int32_t* out) {
     if (!h || !out) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
     BODCHK(d2h(h, out, h->pb.num_kept, (size_t)h->cfg.batch));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1479,6 +1614,7 @@ static bod_status image_m(bod_handle h, int32_t img, int32_t* m) {
 
 bod_status bod_get_posterior(bod_handle h, int32_t img, float* counts, float* score, float* means, float* covs, float* ranking, int32_t* anchor_index) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
     int32_t m = 0;
     BODCHK(image_m(h, img, &m));
@@ -1495,6 +1631,7 @@ bod_status bod_get_posterior(bod_handle h, int32_t img, float* counts, float* sc
 
 bod_status bod_set_posterior(bod_handle h, int32_t img, int32_t m, const float* counts, const float* means, const float* covs, const float* ranking) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (img < 0 || img >= h->cfg.batch || m < 0 || m > h->A) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_posterior: bad image index / M");
     if (m > 0 && (!counts || !means || !covs || !ranking)) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_posterior: NULL array");
     const size_t o = (size_t)img * h->A, C = h->cfg.num_classes;
@@ -1519,6 +1656,7 @@ bod_status bod_set_posterior(bod_handle h, int32_t img, int32_t m, const float* 
 
 bod_status bod_nms(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return run_nms(h, h->stream);
@@ -1526,6 +1664,7 @@ bod_status bod_nms(bod_handle h) {
 
 bod_status bod_get_nms(bod_handle h, int32_t img, int32_t* indices, int32_t* num) {
     if (!h || !num) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms has not run");
     if (img < 0 || img >= h->cfg.batch) return h->fail(BOD_ERR_INVALID_ARG, "image index out of range");
     HIPCHK(h, hipMemcpyAsync(num, h->nms_nsel + img, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1537,6 +1676,7 @@ bod_status bod_get_nms(bod_handle h, int32_t img, int32_t* indices, int32_t* num
 
 bod_status bod_set_nms(bod_handle h, int32_t img, const int32_t* indices, int32_t n) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior / bod_set_posterior has not run");
     if (img < 0 || img >= h->cfg.batch || n < 0 || n > h->cfg.nms_max_output_size || (n > 0 && !indices))
         return h->fail(BOD_ERR_INVALID_ARG, "bod_set_nms: bad image index or count (max %d)", h->cfg.nms_max_output_size);
@@ -1554,6 +1694,7 @@ bod_status bod_set_nms(bod_handle h, int32_t img, const int32_t* indices, int32_
 
 bod_status bod_get_iou_matrix(bod_handle h, int32_t img, float* iou) {
     if (!h || !iou) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->posterior_done) return h->fail(BOD_ERR_NOT_READY, "bod_posterior has not run");
     int32_t m = 0;
     BODCHK(image_m(h, img, &m));
@@ -1574,6 +1715,7 @@ bod_status bod_get_iou_matrix(bod_handle h, int32_t img, float* iou) {
 
 bod_status bod_set_affinity(bod_handle h, int32_t img, const float* centre_columns, int32_t k, int32_t m) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms / bod_set_nms has not run");
     if (img < 0 || img >= h->cfg.batch || !centre_columns) return h->fail(BOD_ERR_INVALID_ARG, "bod_set_affinity: bad image index / NULL");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1594,6 +1736,7 @@ bod_status bod_set_affinity(bod_handle h, int32_t img, const float* centre_colum
 
 bod_status bod_cluster_fuse(bod_handle h) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->nms_done) return h->fail(BOD_ERR_NOT_READY, "bod_nms has not run");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return run_cluster(h, h->stream);
@@ -1601,6 +1744,7 @@ bod_status bod_cluster_fuse(bod_handle h) {
 
 bod_status bod_get_detections(bod_handle h, int32_t img, int32_t* num, float* scores, float* means, float* covs, float* counts) {
     if (!h || !num) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_cluster_fuse has not run");
     if (img < 0 || img >= h->cfg.batch) return h->fail(BOD_ERR_INVALID_ARG, "image index out of range");
     HIPCHK(h, hipMemcpyAsync(num, h->nms_nsel + img, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1616,6 +1760,7 @@ bod_status bod_get_detections(bod_handle h, int32_t img, int32_t* num, float* sc
 
 bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, float* means, float* covs, float* counts) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_cluster_fuse has not run");
     const size_t BK = (size_t)h->cfg.batch * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
     BODCHK(d2h(h, num, h->nms_nsel, (size_t)h->cfg.batch));
@@ -1629,6 +1774,7 @@ bod_status bod_get_detections_batch(bod_handle h, int32_t* num, float* scores, f
 
 bod_status bod_device_raw(bod_handle h, void** p, int32_t mark_ready) {
     if (!h || !p) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (mark_ready) BODCHK(ensure_raw(h)); else BODCHK(materialise_raw(h));
     p[0] = h->raw[0]; p[1] = h->raw[1]; p[2] = h->cfg.has_covar_head ? h->raw[2] : nullptr;
@@ -1646,6 +1792,7 @@ bod_status bod_device_detections(bod_handle h, int32_t sidx, void** p) {
 bod_status bod_infer(bod_handle h, const float* images, int32_t on_device, uint64_t seed, uint32_t first_image_id) {
     MarkerRange mr_api("bod:infer");
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     if (h->cfg.mc_samples < 2) return h->fail(BOD_ERR_INVALID_ARG, "bayes_od needs mc_samples >= 2 (sample covariance divides by N-1)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1667,10 +1814,20 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
     const int sidx = h->slot ^ 1;
     if (h->side_pending[sidx])
         return h->fail(BOD_ERR_NOT_READY, "slot %d still holds uncollected detections: call bod_collect first", sidx);
+    // pipeline_overlap handles: this call's front goes to h->front, everything else to h->back (h->stream for the call's duration);
+    // both are first ordered behind whatever the full-chip stream still holds (an upload, a synchronous call's tail)
+    const bool ov = h->overlap_mode != 0;
+    struct MainStream { bod_context* h; ~MainStream() { h->stream = h->full; h->in_overlap_call = false; } } restore_main{h};
+    if (ov) {
+        HIPCHK(h, hipEventRecord(h->ev_join, h->full));
+        HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_join, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->back, h->ev_join, 0));
+        h->stream = h->back; h->in_overlap_call = true; h->ov_dirty = true;
+    }
     const float* dev = nullptr;
-    BODCHK(stage_images(h, images, on_device, &dev));
+    BODCHK(stage_images(h, images, on_device, &dev, ov ? h->front : h->stream));
     h->cur_images = dev;
-    BODCHK(run_forward(h, dev, seed, first_image_id, infer_flavour(h)));
+    BODCHK(run_forward(h, dev, seed, first_image_id, infer_flavour(h), false, ov));
     BODCHK(run_posterior(h, seed, first_image_id));           // waits for the side stream's previous readers
     HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
     h->select_slot(sidx);
@@ -2064,6 +2221,7 @@ bod_status bod_loss_backward(int32_t device, int32_t B, int32_t A, int32_t C, co
 
 bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters, double* mean_ms, double* flops) {
     if (!h || !mean_ms || iters < 1 || layer < 0 || layer > 3) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int seen = 0; Op* op = nullptr;
@@ -2152,11 +2310,14 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     // where the records are and which stream finished them
     int sidx = slot;
     hipStream_t st = h->side;
-    if (slot < 0) {                                   // synchronous bod_infer / bod_cluster_fuse: current buffers, main stream
+    if (slot < 0) {
+        // synchronous bod_infer / bod_cluster_fuse: the records are the current buffers, finished on the MAIN stream -- pack and gather
+        // go out on that stream too, so the next bod_infer (which rewrites nms_nsel / out_* of this slot on the main stream) and
+        // bod_synchronize are ordered behind them by stream order.  (On the side stream nothing would hold the main stream back.)
         if (!h->cluster_done) return h->fail(BOD_ERR_NOT_READY, "bod_gather_detections: bod_cluster_fuse has not run");
+        BODCHK(join_overlap(h));
         sidx = h->slot;
-        HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
+        st = h->stream;
     } else if (slot > 1 || !h->side_pending[slot]) {
         return h->fail(BOD_ERR_NOT_READY, "bod_gather_detections: slot %d has no pending batch", slot);
     }
@@ -2212,6 +2373,7 @@ bod_status bod_profile_select(bod_handle h, int32_t which) {
 
 bod_status bod_profile_end(bod_handle h, double* head_ms, int64_t* head_launches, double* head_flops, double* post_ms, int64_t* post_launches) {
     if (!h) return BOD_ERR_INVALID_ARG;
+    BODCHK(join_overlap(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double hm = 0, pm = 0;
     for (auto& e : h->ev_head) { float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e.first, e.second)); hm += ms; }

@@ -100,6 +100,9 @@ struct ConvArgs {
     // Output plane geometry of a plane -> plane convolution whose row table is ordered (image, y, x): rows per image and pixels per
     // row (0 = unknown).  The sliding-window 3x3 kernel (conv_pointwise.hip) walks column strips with it.
     int32_t plane_h, plane_w;
+    // Compute units the launch may fill (0 = unknown: the device's count).  The engine sets it per launch -- the whole chip, or the
+    // CU partition of the stream the launch goes to (bod_config.pipeline_overlap) -- and the planner compares workgroup counts with it.
+    int32_t n_cu;
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute

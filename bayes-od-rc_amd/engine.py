@@ -19,7 +19,7 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
                 dropout_rate=0.3, use_full_covar=True, bayes_od_config=None, nms_config=None,
                 has_covar_head=True, dataset_name='bdd', orig_size=None, nms_variant='A',
                 num_categorical_draws=30, layers=(3, 4, 5, 6, 7), precision='bf16', mc_sample_base=0,
-                mc_ensemble_size=0, training=False, backbone_depth=50):
+                mc_ensemble_size=0, training=False, backbone_depth=50, pipeline_overlap=False):
     """Translates the reference's yaml dictionaries (configs/retinanet_bdd_covar.yaml:61-143)
     into a ``bod_config``."""
     bo = bayes_od_config or {'ranking_method': 'score', 'dirichlet_prior': {'type': 'non_informative'},
@@ -54,6 +54,8 @@ def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_loc
     if int(backbone_depth) not in (50, 101):
         raise ValueError("backbone_depth must be 50 or 101")
     cfg.backbone_depth = int(backbone_depth)
+    # infer_async overlaps the front (stem / backbone / FPN) of batch i+1 with the towers of batch i on CU-partitioned streams
+    cfg.pipeline_overlap = int(bool(pipeline_overlap))
     if dataset_name == 'kitti':
         if orig_size is None:
             raise ValueError("dataset_name='kitti' needs orig_size (sample_dict['im_size'])")
@@ -404,7 +406,9 @@ class Engine(object):
         """The path's one multi-GPU exchange through the C ABI (``bod_gather_detections``): packs this batch's detection
         records on the device and gathers every rank's block on ``root`` with ONE RCCL gather.  ``comm``: an ``ncclComm_t``
         as an integer / ``c_void_p`` (None: single process).  ``slot``: ticket of ``infer_async`` (-1 after ``infer``).
-        Returns [world, B, K, 1+4+16+2C] float32 on the root (None elsewhere); unpack with distributed.unpack_records."""
+        Returns [world, B, K, 1+4+16+2C] float32 on the root (None elsewhere); unpack with distributed.unpack_records.
+        ``want_host=False`` (root only): nothing is copied or waited for; returns ``(device pointer, shape)`` of the gathered
+        block, complete after ``collect(slot)`` (a ticket) or ``synchronize()`` (slot -1) -- see include/bayesod.h."""
         w = int(self.lib.bod_record_width(self.h))
         out = None
         dev = C.c_void_p(0)
@@ -413,6 +417,8 @@ class Engine(object):
         self._chk(self.lib.bod_gather_detections(self.h, int(slot), C.c_void_p(int(comm) if comm else 0), int(world), int(rank), int(root),
                                                  out.ctypes.data if out is not None else None,
                                                  C.byref(dev) if rank == root else None))
+        if rank == root and not want_host:
+            return int(dev.value or 0), (world, self.B, self.K, w)
         return out
 
     def plan_info(self):

@@ -17,7 +17,26 @@ import re
 import subprocess
 import tempfile
 
-LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+import shutil
+
+
+def _llvm_bin_candidates():
+    """Directories that may hold llvm-objcopy / clang-offload-bundler / llvm-readelf / llvm-objdump: next to the hipcc the build
+    uses ($HIPCC, PATH), under $ROCM_PATH, the unversioned /opt/rocm, any /opt/rocm-x.y.z."""
+    import glob
+    roots = []
+    for hipcc in (os.environ.get("HIPCC"), shutil.which("hipcc")):
+        if hipcc:
+            roots.append(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))))      # <root>/bin/hipcc
+    roots += [os.environ.get("ROCM_PATH"), os.environ.get("ROCM_HOME"), "/opt/rocm"] + sorted(glob.glob("/opt/rocm-*"), reverse=True)
+    out = []
+    for r in roots:
+        if r:
+            for sub in ("lib/llvm/bin", "llvm/bin", "bin"):
+                d = os.path.join(r, sub)
+                if d not in out:
+                    out.append(d)
+    return out
 
 PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb0EE",     # head towers (row reuse)
@@ -42,10 +61,15 @@ class GuardError(RuntimeError):
 
 
 def _tool(name):
-    p = os.path.join(LLVM_BIN, name)
-    if not os.path.exists(p):
-        raise GuardError("%s not found (ROCm llvm tools are needed for the kernel guards)" % p)
-    return p
+    for d in _llvm_bin_candidates():
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            return p
+    p = shutil.which(name)
+    if p:
+        return p
+    raise GuardError("%s not found (looked in %s and PATH): the ROCm llvm tools are needed for the kernel guards; "
+                     "BOD_SKIP_KERNEL_GUARD=1 builds without them, unchecked" % (name, ", ".join(_llvm_bin_candidates())))
 
 
 def extract_device_object(host_obj, workdir):
@@ -191,13 +215,18 @@ def check_asm_lds_reads(body, want, min_reads=60):
                 raise GuardError("%s: `%s` touches a fragment register still in flight" % (want, l))
             queue.append(dst)
             checked += 1
-        elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
-            queue.append(set())                      # another LGKM operation: counted, no fragment register
+        elif op.startswith("ds_"):
+            queue.append(set())                      # another LDS operation: returns in order with the fragment reads, no fragment register
+        elif op.startswith("s_load") or op.startswith("s_buffer_load"):
+            # SMEM shares the counter but returns OUT OF ORDER: an s_load still in flight may be what keeps lgkmcnt at n while an older
+            # ds_read has not landed, and one that returned early lowers the count without any ds_read having landed.  It is NOT put
+            # in the queue: `lgkmcnt(n)` passing means (LDS ops + SMEM ops in flight) <= n, hence at most n LDS operations in
+            # flight whatever the SMEM ones do -- retiring all but the n youngest LDS entries is the sound bound.
+            pass
         elif op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", l)
             if m:
                 n = int(m.group(1))
-                # SMEM returns out of order: an entry without registers may retire early, which only makes the count conservative
                 while len(queue) > n:
                     queue.pop(0)
         elif op.startswith("s_cbranch") or op == "s_branch":

@@ -171,10 +171,11 @@ def train(config, args):
     os.makedirs(ckpt_dir, exist_ok=True)
     # ckpt.restore(manager.latest_checkpoint) (run_training.py:75-82): resume weights, Adam moments and the step counter
     opt_state, restored = None, None
+    superseded = []
     if getattr(args, 'no_resume', False):
-        # a fresh run: the previous run's checkpoints must not stay the "latest" of this one
-        for old in sorted_checkpoints(ckpt_dir):
-            os.remove(old)
+        # a fresh run: nothing is restored, and the previous run's checkpoints must not stay the "latest" of this one -- they are
+        # MOVED ASIDE (never deleted), and only once the Trainer below has been built, so a bad config or weight file costs nothing
+        superseded = sorted_checkpoints(ckpt_dir)
     else:
         for cand in reversed(sorted_checkpoints(ckpt_dir)):           # newest first; a damaged file falls back to the one before
             try:
@@ -198,6 +199,12 @@ def train(config, args):
     trainer = Trainer(config, hw, weights, device=int(args.gpu_device), seed=args.seed)
     if opt_state:
         trainer.restore_optimizer_state(opt_state)
+    if superseded:
+        aside = os.path.join(ckpt_dir, 'superseded-%s-%d' % (time.strftime('%Y%m%d-%H%M%S'), os.getpid()))
+        os.makedirs(aside)
+        for old in superseded:
+            os.replace(old, os.path.join(aside, os.path.basename(old)))
+        print('--no_resume: moved {} checkpoint(s) of the previous run to {}'.format(len(superseded), aside))
     total_steps = args.steps or epoch_size * int(training_config['max_epochs'])
     ckpt_every = max(int(epoch_size * training_config['checkpoint_interval']), 1)
     keep = int(training_config.get('max_checkpoints_to_keep', 10000))
@@ -273,7 +280,8 @@ def main(argv=None):
     ap.add_argument('--image_size', type=int, nargs=2, default=[256, 256])
     ap.add_argument('--steps', type=int, default=0)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--no_resume', action='store_true', help='ignore existing checkpoints of this run')
+    ap.add_argument('--no_resume', action='store_true', help='start from scratch: existing checkpoints of this run are not restored; they are moved to '
+                    'checkpoints/superseded-<time>/ (never deleted) once the trainer has been built')
     args = ap.parse_args(argv)
     config = config_utils.setup(config_utils.load_yaml(args.yaml_path), args)
     return train(config, args)

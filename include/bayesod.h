@@ -83,7 +83,14 @@ typedef struct {
     int32_t backbone_depth;      /* 0 / 50: ResNet-50, the reference's only backbone (feature_extractor.py:6-9).  101: stage 4 with
                                     1 ConvBlock + 22 IdentityBlocks (layer names res4a .. res4w) -- BASELINE config 5's
                                     "ResNet-101", which has no counterpart in the reference.             */
-    int32_t reserved[3];
+    int32_t pipeline_overlap;    /* 1: bod_infer_async overlaps the memory-bound front of batch i+1 (stem, backbone, FPN) with the
+                                    MFMA-bound back of batch i (fan-out layer, towers, posterior) on two CU-partitioned streams
+                                    (hipExtStreamCreateWithCUMask: the front owns the last 4 CU slots of every XCD, 32 of 256 CUs,
+                                    the back the other 224; the pyramid is double-buffered).  Results are bit-identical to the
+                                    serial pipeline; every other entry point keeps the whole chip.  Inference handles only.
+                                    Images are independent (run_inference.py:137-149), so the order of two batches' kernels
+                                    is free.  0 (default): one stream.                                           */
+    int32_t reserved[2];
 } bod_config;
 
 /* Sizes the caller needs to allocate host buffers. */
@@ -337,14 +344,20 @@ bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_con
  * row-major, score[C], counts[C]]; a rank's block is [batch][max_detections][W], rows beyond an image's detection count are zero.
  *
  * bod_gather_detections packs the records of `slot` (the ticket of bod_infer_async; pass -1 after a synchronous bod_infer) on the
- * device and issues ONE RCCL gather -- ncclGather(send, recv, batch*K*W, ncclFloat32, root, comm, stream) -- on the handle's side
- * stream, behind the slot's cluster-and-fuse kernels, so it overlaps the next batch's convolutions like bod_collect's copies do.
+ * device and issues ONE RCCL gather -- ncclGather(send, recv, batch*K*W, ncclFloat32, root, comm, stream).  For a ticket
+ * (slot >= 0) both run on the handle's side stream, behind the slot's cluster-and-fuse kernels, so they overlap the next batch's
+ * convolutions like bod_collect's copies do, and the slot's event is re-recorded behind them: bod_collect(slot) and the next
+ * bod_infer_async that reuses the slot wait for the send.  For slot == -1 both run on the handle's MAIN stream, behind the
+ * synchronous bod_infer's own kernels: every later call on the handle (the next bod_infer, bod_synchronize, ...) is ordered behind
+ * the pack and the gather by stream order.
  * `nccl_comm` is the caller's ncclComm_t (created with ncclCommInitRank on this handle's device; librccl.so is opened at run time,
  * the library does not link it); `world` / `rank` are the communicator's size and this process' rank.  nccl_comm == NULL is the
  * single-process form (world must be 1: the block is "gathered" by a device copy).
  * On `root`, `gathered_host` (may be NULL) receives [world][batch][K][W] floats, in rank order, after the stream has been waited
- * for; *gathered_device (may be NULL) is set to the device copy, valid until the next gather.  Other ranks pass NULL for both (their
- * call returns once the send is enqueued and the slot's event recorded).  A pending slot is NOT released: bod_collect still may. */
+ * for; *gathered_device (may be NULL) is set to the device copy, valid until the next gather: its contents are complete once
+ * bod_collect(slot) has returned (slot >= 0) or after bod_synchronize (slot == -1) -- unless gathered_host was given, in which case
+ * the call itself has waited.  Other ranks pass NULL for both (their call returns once the send is enqueued).  A pending slot is
+ * NOT released: bod_collect still may. */
 int32_t bod_record_width(bod_handle h);
 bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, int32_t world, int32_t rank, int32_t root,
                                  float* gathered_host, float** gathered_device);

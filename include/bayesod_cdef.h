@@ -39,7 +39,8 @@ typedef struct {
     int32_t mc_ensemble_size;
     int32_t training;
     int32_t backbone_depth;
-    int32_t reserved[3];
+    int32_t pipeline_overlap;
+    int32_t reserved[2];
 } bod_config;
 typedef struct {
     int32_t num_pixels;

@@ -148,6 +148,86 @@ def test_async_pipeline_equals_synchronous():
                 assert np.array_equal(a[key][img, :k], b[key][img, :k])
 
 
+@pytest.mark.parametrize("mode", ["cu_masks", "plain_streams"])
+def test_overlapped_pipeline_equals_serial(mode, monkeypatch):
+    """bod_config.pipeline_overlap: the front (stem, backbone, FPN) of batch i+1 on its own CU-partitioned stream underneath the
+    fan-out layer / towers / posterior of batch i, the pyramid double-buffered.  Images are independent (run_inference.py:137-149)
+    and no kernel's result depends on where its workgroups run: the detections of every batch are BIT-IDENTICAL to the serial
+    pipeline's, batch after batch, also when synchronous calls, raw-output reads and pipelined calls alternate on one handle and
+    when the frames come through the asynchronous uint8 upload."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, n, batch = (128, 160), 4, 3
+    weights = synthetic.make_weights(cls_fg_bias=-1.0)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    clips = [synthetic.make_frames(batch, hw[0], hw[1], seed=40 + i) for i in range(6)]
+
+    def engine(overlap):
+        e = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True,
+                               pipeline_overlap=overlap))
+        e.load_weights(weights)
+        e.set_anchors(anchors)
+        return e
+
+    def pipelined(e, frames_list):
+        pending, got = [], []
+        for i, f in enumerate(frames_list):
+            pending.append(e.infer_async(f, seed=3, first_image_id=batch * i))
+            if len(pending) > 1:
+                got.append({k: v.copy() for k, v in e.collect(pending.pop(0)).items()})
+        got.append({k: v.copy() for k, v in e.collect(pending.pop(0)).items()})
+        return got
+
+    def same(a, b):
+        assert np.array_equal(a["num"], b["num"]) and a["num"].sum() > 0
+        for img in range(batch):
+            k = a["num"][img]
+            for key in ("scores", "means", "covs", "counts"):
+                assert np.array_equal(a[key][img, :k], b[key][img, :k]), key
+
+    serial = engine(False)
+    want = pipelined(serial, clips)
+    serial.infer(clips[1], seed=3, first_image_id=batch)
+    want_raw = [a.copy() for a in serial.get_raw()]
+    want_pyr = serial.get_pyramid(0).copy()
+    monkeypatch.setenv("BOD_OVERLAP", "1" if mode == "cu_masks" else "2")
+    ov = engine(True)
+    monkeypatch.delenv("BOD_OVERLAP")
+    for rep in range(2):                                 # twice: the second pass starts on the other pyramid buffer's parity
+        got = pipelined(ov, clips if rep == 0 else clips[:5])
+        for a, b in zip(want, got):
+            same(a, b)
+    # a synchronous call between pipelined ones: ordered behind the partition's streams, same results, raw outputs and pyramid readable
+    s0 = ov.infer_async(clips[0], seed=3, first_image_id=0)
+    ov.infer(clips[1], seed=3, first_image_id=batch)
+    same(want[1], {k: v.copy() for k, v in ov.get_detections_batch().items()})
+    for a, b in zip(want_raw, ov.get_raw()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(want_pyr, ov.get_pyramid(0))
+    same(want[0], ov.collect(s0))
+    s1 = ov.infer_async(clips[2], seed=3, first_image_id=2 * batch)
+    same(want[2], ov.collect(s1))
+    # frames through the pipelined uint8 upload (copy stream -> front stream)
+    rng = np.random.default_rng(5)
+    u8 = [rng.integers(0, 256, (batch, hw[0], hw[1], 3), dtype=np.uint8) for _ in range(4)]
+    res = {}
+    for name, e in (("serial", serial), ("overlap", ov)):
+        pending, got = [], []
+        e.upload_frames_u8_async(u8[0], buffer=0)
+        for i in range(len(u8)):
+            pending.append(e.infer_async(None, seed=9, first_image_id=batch * i, image_buffer=i & 1))
+            if i + 1 < len(u8):
+                e.upload_frames_u8_async(u8[i + 1], buffer=(i + 1) & 1)
+            if len(pending) > 1:
+                got.append({k: v.copy() for k, v in e.collect(pending.pop(0)).items()})
+        got.append({k: v.copy() for k, v in e.collect(pending.pop(0)).items()})
+        res[name] = got
+    for a, b in zip(res["serial"], res["overlap"]):
+        same(a, b)
+    serial.close(); ov.close()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_fp32_pipeline_matches_oracle_end_to_end(precision):
     """fp32 / bf16x3 precision modes, whole pipeline against the float64 oracle run from the raw frame.  EVERY image goes through
@@ -752,6 +832,30 @@ def test_gather_detections_through_the_c_abi_single_process():
         eng.gather_detections(slot=slot)              # released by collect: no pending batch
     with pytest.raises(Exception):
         eng.gather_detections(slot=-1, world=2, rank=0)   # two ranks need a communicator
+    eng.close()
+
+
+def test_gather_after_a_synchronous_infer_is_ordered_before_the_next_infer():
+    """slot -1 without a host buffer (what a non-root rank, or a root that only wants the device block, does): the pack and the
+    gather run on the handle's MAIN stream, so a bod_infer issued right behind them cannot rewrite the detection buffers they
+    read; the device block is complete after bod_synchronize (include/bayesod.h)."""
+    import torch
+    from bayes_od_rc_amd import distributed as bd
+    from bayes_od_rc_amd import synthetic
+    eng, frames = _tiny_pipeline_engine()
+    other = synthetic.make_frames(len(frames), frames.shape[1], frames.shape[2], seed=99)
+    eng.infer(frames, seed=5, first_image_id=0)
+    ref = eng.gather_detections(slot=-1)
+    eng.infer(other, seed=6, first_image_id=50)
+    ref_other = eng.gather_detections(slot=-1)
+    assert not np.array_equal(ref, ref_other)
+    for _ in range(5):
+        eng.infer(frames, seed=5, first_image_id=0)
+        ptr, shape = eng.gather_detections(slot=-1, want_host=False)     # nothing waited for ...
+        eng.infer(other, seed=6, first_image_id=50)                      # ... and the next batch enqueued right behind it
+        eng.synchronize()
+        block = torch.as_tensor(bd.DeviceArray(ptr, shape, "<f4"), device=torch.device("cuda", eng.cfg.device)).cpu().numpy()
+        assert np.array_equal(block, ref)
     eng.close()
 
 

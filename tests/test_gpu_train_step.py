@@ -236,8 +236,19 @@ def test_run_training_resumes_from_the_latest_checkpoint(tmp_path, monkeypatch):
     assert np.allclose(second, whole[4:], rtol=8e-2), (second, whole[4:])
     # a restart from scratch would begin with the initial loss again
     assert second[0] < 0.9 * whole[0]
+    before = {f: os.path.getsize(os.path.join(ckpt_dir, f)) for f in os.listdir(ckpt_dir) if f.startswith("ckpt-")}
     fresh, _ = run_training.main(common + ["--steps", "2", "--no_resume"])
     assert abs(fresh[0] - whole[0]) < 2e-2 * abs(whole[0])
+    # --no_resume never deletes: the previous run's checkpoints were moved aside, whole, and the fresh run's own is the latest
+    aside = [d for d in os.listdir(ckpt_dir) if d.startswith("superseded-")]
+    assert len(aside) == 1
+    kept = {f: os.path.getsize(os.path.join(ckpt_dir, aside[0], f)) for f in os.listdir(os.path.join(ckpt_dir, aside[0]))}
+    assert kept == before and len(before) >= 2
+    assert run_training.latest_checkpoint(ckpt_dir).endswith("ckpt-2.npz")
+    # ... and not before the trainer exists: a run that fails on its weight file leaves the directory as it was
+    with pytest.raises(Exception):
+        run_training.main(common + ["--steps", "2", "--no_resume", "--weights", str(tmp_path / "missing.npz")])
+    assert run_training.latest_checkpoint(ckpt_dir).endswith("ckpt-2.npz") and len([d for d in os.listdir(ckpt_dir) if d.startswith("superseded-")]) == 1
 
 
 def test_learning_rate_schedule():
