@@ -7,6 +7,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbayesod_hip.so")
+# development aid (tests/tools/ab_lib.sh): same-box A/B of two BUILDS of the library -- the override must name an existing file
+if os.environ.get("BOD_LIB_OVERRIDE"):
+    LIB_PATH = os.path.abspath(os.environ["BOD_LIB_OVERRIDE"])
 
 BOD_OK, BOD_ERR_INVALID_ARG, BOD_ERR_HIP, BOD_ERR_OOM, BOD_ERR_NOT_READY, BOD_ERR_NO_DEVICE = range(6)
 
