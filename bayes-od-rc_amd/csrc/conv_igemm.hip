@@ -1594,11 +1594,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         __syncthreads();
         constexpr int GPR = BC / 16;                                   // 16-channel groups per pixel row
         auto keep2 = [thr_m1_x2](uint32_t w) { return keep_mask_u16x2(w, thr_m1_x2); };
+        // A lane owns one (pixel, 16-channel group) item: its two Philox calls decide exactly those 32 bytes.  Stored as they are,
+        // every 64-lane store instruction would write 16-byte pieces 32 bytes apart (two half-covered instructions per row, 64
+        // separate write requests each); ten samples make this launch the chip's largest store stream (21.5 GB per 256 frames).
+        // Lanes 2k / 2k+1 therefore own items k and k + 32 of the wave's 64 and trade halves through DPP (lane ^ 1): the first
+        // store instruction of a sample then writes items 0..31 -- lane 2k the first 16 bytes of item k, lane 2k+1 the second --
+        // i.e. 1 KiB of CONTIGUOUS pixel rows, the second one items 32..63.  Same values to the same addresses.
+        static_assert((BP * GPR) % THREADS == 0 && GPR <= 32 && 64 % GPR == 0, "fan-out item mapping");
+        const int odd = lane & 1;
 #pragma unroll 1
-        for (int q = tid; q < BP * GPR; q += THREADS) {
+        for (int it = 0; it < BP * GPR / THREADS; ++it) {
+            const int base = it * THREADS + wave * 64;
+            const int it_e = base + (lane >> 1), it_o = it_e + 32;      // the pair's two items; this lane owns it_e (even lane) or it_o
+            const int q = odd ? it_o : it_e;
             const int pixl = q / GPR, gq = q % GPR;
-            const int off = s_off[pixl];
-            if (off < 0) continue;
+            const int off_e = s_off[it_e / GPR], off_o = s_off[it_o / GPR];
             const char* prow = smem + pixl * (BC * 2);
             const uint4 va = *reinterpret_cast<const uint4*>(prow + ((((2 * gq) ^ pixl) & (CPR - 1)) << 4));
             const uint4 vb = *reinterpret_cast<const uint4*>(prow + ((((2 * gq + 1) ^ pixl) & (CPR - 1)) << 4));
@@ -1606,7 +1616,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             const uint32_t img = rng_image_base + ((uint32_t)r.y >> 16);
             const int c0 = bc0 + gq * 16;
             const uint32_t ga = dropout_group8(c0), gb = dropout_group8(c0 + 4);
-            uint16_t* o = reinterpret_cast<uint16_t*>(G.out) + (size_t)off * a.out_cstride + c0;
+            uint16_t* const obase = reinterpret_cast<uint16_t*>(G.out) + bc0 + odd * 8;
+            uint16_t* oe = obase + (size_t)(off_e < 0 ? 0 : off_e) * a.out_cstride + (it_e % GPR) * 16;
+            uint16_t* oo = obase + (size_t)(off_o < 0 ? 0 : off_o) * a.out_cstride + (it_o % GPR) * 16;
             const size_t sample_stride = (size_t)a.fan_stride * a.out_cstride;
 #pragma unroll 1
             for (int n = 0; n < fan; ++n) {
@@ -1615,12 +1627,26 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const Philox4 p1 = philox4x32_10((uint32_t)r.x, gb, key, img, rng_seed_lo, rng_seed_hi);
                 const uint4 oa = make_uint4(va.x & keep2(p0.x), va.y & keep2(p0.y), va.z & keep2(p1.x), va.w & keep2(p1.y));
                 const uint4 ob = make_uint4(vb.x & keep2(p0.z), vb.y & keep2(p0.w), vb.z & keep2(p1.z), vb.w & keep2(p1.w));
+                // d1: even lane keeps its first half, odd lane takes the even lane's second half (item it_e, bytes 0..15 | 16..31);
+                // d2: odd lane keeps its second half, even lane takes the odd lane's first half (item it_o).  DPP quad_perm [1,0,3,2]
+                // = the value of lane ^ 1.
+                uint4 d1, d2;
+#if defined(__HIP_DEVICE_COMPILE__)
+                // (the exchange is executed by ALL lanes, outside any branch: a DPP read of an inactive lane returns 0)
+                auto other = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };
+                const uint4 sa = make_uint4(other(oa.x), other(oa.y), other(oa.z), other(oa.w));
+                const uint4 sb = make_uint4(other(ob.x), other(ob.y), other(ob.z), other(ob.w));
+                d1.x = odd ? sb.x : oa.x; d1.y = odd ? sb.y : oa.y; d1.z = odd ? sb.z : oa.z; d1.w = odd ? sb.w : oa.w;
+                d2.x = odd ? ob.x : sa.x; d2.y = odd ? ob.y : sa.y; d2.z = odd ? ob.z : sa.z; d2.w = odd ? ob.w : sa.w;
+#else
+                d1 = oa; d2 = ob;
+#endif
                 if (nt_out) {
-                    __builtin_nontemporal_store(u32x4{oa.x, oa.y, oa.z, oa.w}, reinterpret_cast<u32x4*>(o + (size_t)n * sample_stride));
-                    __builtin_nontemporal_store(u32x4{ob.x, ob.y, ob.z, ob.w}, reinterpret_cast<u32x4*>(o + (size_t)n * sample_stride + 8));
+                    if (off_e >= 0) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, reinterpret_cast<u32x4*>(oe + (size_t)n * sample_stride));
+                    if (off_o >= 0) __builtin_nontemporal_store(u32x4{d2.x, d2.y, d2.z, d2.w}, reinterpret_cast<u32x4*>(oo + (size_t)n * sample_stride));
                 } else {
-                    *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride) = oa;
-                    *reinterpret_cast<uint4*>(o + (size_t)n * sample_stride + 8) = ob;
+                    if (off_e >= 0) *reinterpret_cast<uint4*>(oe + (size_t)n * sample_stride) = d1;
+                    if (off_o >= 0) *reinterpret_cast<uint4*>(oo + (size_t)n * sample_stride) = d2;
                 }
             }
         }
@@ -1958,6 +1984,18 @@ __global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1))
     // back on one XCD and the second and third find the pyramid rows in that XCD's L2 (grid.z-major order re-read the
     // 0.78 GB pyramid from HBM once per head: 3.2 GB fetched for 0.72 GB algorithmic, profiles/round2_head_conv_pmc.json)
     if (gridDim.z == 1 && a.groups > 1 && a.ksplit <= 1) { gz = bx % a.groups; bx = bx / a.groups; }
+    if constexpr (ABL == 5) {
+        // De-phase the CUs of the fan-out launch.  Every CU holds one workgroup, all tiles take the same time, and a launch starts
+        // all CUs together: the epilogues -- ten masked copies of the tile, 1.3 MB per CU -- would all store at the same moment
+        // (8 TB/s demanded for 40 us, then nothing for 70 us) and back up into the CUs' store queues, behind which the Philox
+        // draws of the next samples wait.  The FIRST workgroup of a CU (blockIdx < n_cu: workgroup b starts on CU slot b / 8 of
+        // XCD b % 8) sleeps (slot & 3) quarter-tiles, after which the four phases keep their distance for the whole launch.
+        if (a.stagger_ticks > 0 && (int)blockIdx.x < (a.n_cu > 0 ? a.n_cu : 256) && blockIdx.y == 0 && blockIdx.z == 0) {
+            const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)a.stagger_ticks;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, gz, bx, blockIdx.y, smem);
 }
 

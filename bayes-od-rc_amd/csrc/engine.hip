@@ -1029,6 +1029,10 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                     HIPCHK(h, hipEventRecord(e0, st));
                 }
                 op.conv.n_cu = is_front ? cus_front : cus_back;          // compute units this launch may fill (planner: workgroups vs CUs)
+                {   // fan-out launch: CU de-phasing (conv_igemm.hip); BOD_FAN_STAGGER_US=t: quarter-tile delay in microseconds (0 = off)
+                    static const int stagger_us = getenv("BOD_FAN_STAGGER_US") ? atoi(getenv("BOD_FAN_STAGGER_US")) : 0;
+                    op.conv.stagger_ticks = (op.conv.fan_count > 1 && op.conv.xreuse) ? stagger_us * 100 : 0;
+                }
                 if (par != 0) {                                  // the second pyramid buffer of an overlap handle
                     ConvArgs a = op.conv;
                     for (int g = 0; g < a.groups; ++g) {

@@ -103,6 +103,10 @@ struct ConvArgs {
     // Compute units the launch may fill (0 = unknown: the device's count).  The engine sets it per launch -- the whole chip, or the
     // CU partition of the stream the launch goes to (bod_config.pipeline_overlap) -- and the planner compares workgroup counts with it.
     int32_t n_cu;
+    // Fan-out launch (first tower layer): the first workgroup of CU slot k of every XCD starts (k & 3) * stagger_ticks 100-MHz ticks
+    // late, so that the ten-fold store bursts of the CUs' epilogues interleave with other CUs' main loops instead of all hitting HBM
+    // at once (conv_igemm.hip).  0 = off.
+    int32_t stagger_ticks;
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
