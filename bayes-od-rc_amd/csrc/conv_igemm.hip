@@ -438,6 +438,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const int co = bc0 + i * RPI + ldrow;
         wsrc[i] = reinterpret_cast<const char*>(G.w) + ((size_t)co * wrow + c_begin * BK + ldchunk * 8) * 2;
     }
+    // Row-reuse loop: K-tile 0's weights depend on nothing but the tile's cout range -- their LDS-DMA goes out FIRST, in front of
+    // the row-table loads below, whose L2 / HBM round trip it then shares instead of following it (a fresh workgroup's LDS is free;
+    // the persistent form ends every tile with a workgroup barrier).
+    constexpr bool EARLY_W = XR && ABL != 81;
+    if constexpr (EARLY_W) {
+        const int wrs0 = RPI * wrow * 2;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            int off = i * wrs0;
+            asm volatile("" : "+s"(off));
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wsrc[0] + off), LDS_PTR(smem + (i * THREADS + lwave * 64) * 16), 16, 0, 0);
+        }
+    }
     for (int i = tid; i < BP; i += THREADS) {
         const int m = bp0 + i;
         const int mm = m < a.M ? m : a.M - 1;
@@ -578,7 +591,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue_wx(0, 0, 0, 0);
+        (void)issue_wx;                                                      // (K-tile 0's weights went out at the top of the tile: EARLY_W)
 #pragma unroll
         for (int i = 0; i < NXE; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]), LDS_PTR(smem + 2 * WST + (i * THREADS + wave * 64) * 16), 16, 0, 0);
@@ -1660,6 +1673,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             for (int k = 0; k < 4; ++k) ph_oth[k] = (uint32_t)__shfl_xor((int)ph_bits[k], 32, 64);
         }
     }
+    // M16, decisions drawn in the loop: per 32-bit word of keep bits the lane needs its own or its partner's byte of every call --
+    // even cout fragments of a pair (fc & 1 == 0) take the byte drawn by the lower lane half, odd ones the upper half's -- and of
+    // that byte the nibble (q4 >> 1).  Both selections are made ONCE per word here (En / On: nibble of call byte k at bit 8k), so
+    // that the per-fragment expansion below is four constant-position bit extracts.
+    uint32_t ph_En[4] = {0u, 0u, 0u, 0u}, ph_On[4] = {0u, 0u, 0u, 0u};
+    if constexpr (M16) {
+        if (drop && ph_inloop) {
+            const bool up = (q4 >> 1) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = up ? ph_oth[k] : ph_bits[k], o_ = up ? ph_bits[k] : ph_oth[k];
+                ph_En[k] = up ? e >> 4 : e;
+                ph_On[k] = up ? o_ >> 4 : o_;
+            }
+        }
+    }
     for (int n = 0; n < fan; ++n) {
         if constexpr (M16) {
 #pragma unroll
@@ -1674,14 +1703,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     const int col = wc * WTC + fc * 16 + q4 * 4;
                     uint2 o = pk16[fc][fp];
                     if (drop && ph_inloop) {
-                        // call idx = fp*4 + (fc>>1) left its byte at a fixed position; the lane's nibble is decisions (q4>>1)*4 .. +3
+                        // call idx = fp*4 + (fc>>1) left its byte at a fixed position; the lane's nibble (decisions (q4>>1)*4 .. +3) sits
+                        // at that byte's bit 0 in ph_En / ph_On.  Decision d -> 16-bit lane d of the 4 packed channels.
                         const int idx = fp * 4 + (fc >> 1);
                         const int bitpos = (7 - (idx >> 1)) * 16 + ((idx & 1) ? 0 : 8);
-                        const uint32_t src = ((fc & 1) == (q4 >> 1)) ? ph_bits[bitpos >> 5] : ph_oth[bitpos >> 5];
-                        const uint32_t nib = src >> ((bitpos & 31) + (q4 >> 1) * 4);
-                        auto bit_mask = [](uint32_t v, int pos) { return (uint32_t)((int32_t)(v << (31 - pos)) >> 31); };    // 0 or ~0
-                        o.x &= __builtin_amdgcn_perm(bit_mask(nib, 1), bit_mask(nib, 0), 0x07060100u);
-                        o.y &= __builtin_amdgcn_perm(bit_mask(nib, 3), bit_mask(nib, 2), 0x07060100u);
+                        const int P = bitpos & 31;
+                        const uint32_t srcw = (fc & 1) ? ph_On[bitpos >> 5] : ph_En[bitpos >> 5];
+#if defined(__HIP_DEVICE_COMPILE__)
+                        // (v_bfe_i32 of one bit = 0 / ~0; v_perm_b32 takes the low half of one and the high half of the other)
+                        o.x &= __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)srcw, P + 1, 1), (uint32_t)__builtin_amdgcn_sbfe((int)srcw, P, 1), 0x07060100u);
+                        o.y &= __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)srcw, P + 3, 1), (uint32_t)__builtin_amdgcn_sbfe((int)srcw, P + 2, 1), 0x07060100u);
+#else
+                        (void)P; (void)srcw;
+#endif
                     } else if (drop) {
                         // decisions drawn here: the call of this lane's own fragment (its partner lane draws the same one)
                         Philox4 rr;
@@ -1943,6 +1977,39 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 }
             }
             return;                                   // the tile itself has no other consumer (fused groups never fan out)
+        }
+        if constexpr (M16) {
+            // Tower launches (row reuse, one pass, plain stores): all sixteen 16-byte pieces of a thread are read from the LDS tile
+            // up front -- the accumulators are dead, there are registers for them -- and leave as buffer stores against the tile's
+            // first extended input row (planes of equal geometry: no output pixel of the tile lies below it), so a piece costs one
+            // 32-bit offset instead of a 64-bit address, and an invalid slot is an out-of-range offset the hardware drops instead of
+            // a branch.  (The rolled loop read the tile four pieces at a time, each batch behind its own LDS round trip.)
+            if (fan == 1 && !nt_out && ABL != 30 && a.fan_count <= 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const int prow0 = tid >> 5, cp = tid & 31;
+                const int first = __builtin_amdgcn_readfirstlane(a.ext[(size_t)bx * XR_EXT_ROWS].x);
+                char* obase = reinterpret_cast<char*>(G.out) + ((size_t)first * a.out_cstride + bc0) * 2;
+                obase = reinterpret_cast<char*>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)obase >> 32)) << 32) |
+                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)obase)));
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7FFFFFFF, 0x00020000);      // raw, 2 GiB window
+                int offs[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) offs[k] = s_off[prow0 + 16 * k];
+                u32x4 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const u32x4*>(smem + (prow0 + 16 * k) * (BC * 2) + cp * 16);
+                const int rowb = a.out_cstride * 2;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int c16 = (cp ^ (prow0 + 16 * k)) & (CPR - 1);
+                    const uint32_t vo = offs[k] < 0 ? 0xFFFFFFF0u : (uint32_t)(offs[k] - first) * (uint32_t)rowb + (uint32_t)(c16 * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v[k], orsrc, (int)vo, 0, 0);
+                }
+#endif
+                phase_stamp<ABL>(tstamp, 5);
+                if constexpr (ABL == 90) { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[14], __builtin_amdgcn_s_memrealtime() - treal); }
+                return;
+            }
         }
 #pragma unroll 4
         for (int q = tid; q < BP * CPR; q += THREADS) {

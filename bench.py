@@ -217,6 +217,79 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
     return base, parity
 
 
+class Telemetry(object):
+    """Board power / shader clock / temperature of THIS rank's GPU sampled from the amdgpu hwmon files while the timed region runs
+    (a thread reading three sysfs files every 25 ms: no HIP call, no effect on the streams).  The tower kernel runs at the board's
+    power management limit -- boxes of the pool differ by a few per cent in the clock they sustain -- so the
+    line records what this run's box did: a slow box and a regression are then distinguishable."""
+
+    def __init__(self, device_index):
+        self.dir, self.samples, self._stop, self._thread = None, [], False, None
+        try:
+            import glob
+            import torch
+            props = torch.cuda.get_device_properties(device_index)
+            want = None
+            if hasattr(props, "pci_bus_id"):
+                want = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+            cands = []
+            for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                if os.path.exists(os.path.join(d, "power1_input")) or os.path.exists(os.path.join(d, "power1_average")):
+                    cands.append(d)
+            for d in cands:
+                if want and want in os.path.realpath(os.path.join(d, "..", "..")).lower():
+                    self.dir = d
+            if self.dir is None and len(cands) == 1:
+                self.dir = cands[0]
+            self.candidates = cands
+        except Exception:                        # telemetry is optional: never fail the bench over it
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fp:
+                return float(fp.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        pw = "power1_input" if os.path.exists(os.path.join(self.dir, "power1_input")) else "power1_average"
+        while not self._stop:
+            self.samples.append((self._read(pw), self._read("freq1_input"), self._read("temp2_input")))
+            time.sleep(0.025)
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self.samples, self._stop = [], False
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop = True
+        self._thread.join()
+        self._thread = None
+        col = lambda k: [s[k] for s in self.samples if s[k] is not None]
+        pw, fq, tp = col(0), col(1), col(2)
+        if not pw and not fq:
+            return None
+        cap = self._read("power1_cap")
+        out = {"source": self.dir, "samples": len(self.samples), "interval_ms": 25}
+        if pw:
+            out.update({"board_power_w_mean": round(sum(pw) / len(pw) / 1e6, 1), "board_power_w_max": round(max(pw) / 1e6, 1)})
+        if cap:
+            out["board_power_cap_w"] = round(cap / 1e6, 1)
+        if fq:
+            out.update({"shader_clock_mhz_mean": round(sum(fq) / len(fq) / 1e6, 1), "shader_clock_mhz_min": round(min(fq) / 1e6, 1),
+                        "shader_clock_mhz_max": round(max(fq) / 1e6, 1)})
+        if tp:
+            out["hotspot_temp_c_max"] = round(max(tp) / 1e3, 1)
+        return out
+
+
 def make_engine(hw, B, n, device, precision="bf16", weights=None, anchors=None, **kw):
     from bayes_od_rc_amd.engine import Engine, make_config
     eng = Engine(make_config(hw, batch=B, mc_samples=n, device=device, bayes_od_config=BAYES_CFG,
@@ -499,6 +572,9 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     # HIP events around every head-tower launch (and every posterior) of the timed steps, recorded on the streams the
     # kernels run on; read back after the closing fence
     eng.profile_begin(which=1)         # 1: the launches of the dominant kernel (row-reuse tower kernel, tower layers 1..3)
+    telemetry = Telemetry(local_rank) if rank == 0 else None
+    if telemetry:
+        telemetry.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -506,6 +582,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     t_local = time.perf_counter() - t0          # this rank's own clock, before the closing barrier
     fence()
     elapsed = time.perf_counter() - t0
+    out["telemetry"] = telemetry.stop() if telemetry else None
     per_rank = [B * args.steps / t_local]
     if USE_DIST:
         dev = "cuda" if backend == "nccl" else "cpu"
