@@ -525,10 +525,13 @@ hipError_t launch_stem_pool_fused(const float* img, const float* w, const float*
     return hipGetLastError();
 }
 // the fused kernel's shapes: one 256-pixel segment per stem row, 16-byte aligned rows, enough images to fill the chip's CUs
-bool stem_pool_fused_applies(const float* img, int B, int W, int ow) {
+// (one workgroup per image walks down its frame: with fewer images than CUs part of the chip idles for the whole launch -- measured
+//  per N=1 forward at 512x512, tests/tools/planner_sweep.py: 128 frames on 256 CUs 19.02 ms fused vs 18.74 as two launches, 256 frames
+//  35.9 vs 36.6 -- so the floor is one image per compute unit of the stream's share; BOD_STEM_POOL_FUSED_MIN_B overrides it)
+bool stem_pool_fused_applies(const float* img, int B, int W, int ow, int n_cu) {
     static const bool on = [] { const char* e = getenv("BOD_STEM_POOL_FUSED"); return !e || atoi(e) != 0; }();
-    static const int min_b = [] { const char* e = getenv("BOD_STEM_POOL_FUSED_MIN_B"); return e ? atoi(e) : 128; }();
-    return on && ow <= SR_SEG && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && B >= min_b;
+    static const int min_b = [] { const char* e = getenv("BOD_STEM_POOL_FUSED_MIN_B"); return e ? atoi(e) : 0; }();
+    return on && ow <= SR_SEG && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && B >= (min_b > 0 ? min_b : (n_cu > 0 ? n_cu : 256));
 }
 
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, void* out, int out_f32,

@@ -129,6 +129,17 @@ __device__ __forceinline__ void phase_stamp(unsigned long long& t, int slot) {
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+int device_cu_count() {
+    static int cus[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (cus[d] == 0) {
+        hipDeviceProp_t prop;
+        cus[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[d];
+}
+
 void conv_igemm_phase_cycles(unsigned long long* out16, bool reset) {
     (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }

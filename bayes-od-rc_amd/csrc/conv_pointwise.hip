@@ -249,7 +249,7 @@ static hipError_t pw_launch_cfg(const ConvArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int ptiles = (a.M + BP - 1) / BP, ctiles = a.cout_pad / BC;
-    const int slots = 256 * WGS;                            // MI355X: 256 CUs
+    const int slots = launch_cus(a) * WGS;                  // persistent workgroups: WGS per compute unit of the launch's share
     int pstride = std::min(slots / ctiles, ptiles) / 8 * 8; // pixel-tile lanes: a multiple of the 8 XCDs
     if (pstride < 8) pstride = 8;
     hipLaunchKernelGGL(kern, dim3(pstride * ctiles), dim3(BC * 2), LDS, s, a, ptiles, ctiles, pstride);
@@ -275,8 +275,11 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
     //  workgroups per CU, that run them now; not kept)
     if (a.cout_pad % 128 != 0 || a.cout_valid != a.cout_pad) return false;
     if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7) || (g.res && (a.res_cstride & 7))) return false;
-    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : 32768; }();   // (tests lower it)
-    if (a.M < min_m) return false;                          // persistent workgroups need a few tiles each
+    // persistent workgroups need a few tiles each: at least 128 output pixels per compute unit of the launch's share (32 768 on the
+    // whole chip; tests/tools/planner_sweep.py: no batch from 3 frames on where the generic kernel is faster).  BOD_POINTWISE_MIN_M
+    // overrides the floor (tests lower it).
+    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : -1; }();
+    if (a.M < (min_m >= 0 ? min_m : 128 * launch_cus(a))) return false;
     return true;
 }
 
@@ -422,8 +425,16 @@ bool conv_slide3x3_eligible(const ConvArgs& a) {
     if (a.cin != 64 || a.cout_pad != 64 || a.cout_valid != 64 || a.plane_h < 1 || a.plane_w < 1) return false;
     if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7)) return false;
     if (a.M % (a.plane_h * a.plane_w) != 0) return false;
-    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : 32768; }();
-    return a.M >= min_m;
+    // A workgroup owns one 64-pixel column strip of one image for the whole launch and walks down it: the grid is images x strips,
+    // two workgroups per compute unit.  The rule is therefore in WORKGROUPS against compute units, not in pixels: round 3's pixel floor
+    // sent 3 frames of 512x512 here -- 6 workgroups on 256 CUs, 172 us per launch against ~18 for the generic kernel -- and every batch
+    // up to ~100 frames paid for it.  Measured per N=1 forward (tests/tools/planner_sweep.py, sliding window vs generic): 512x512
+    // (2 strips) 3 / 8 / 32 / 128 / 256 frames +33 / +20 / +7.5 / -0.3 / -1.8 %, 384x1248 (5 strips) +18 / +9 / +2 / -1 / -1.8 %:
+    // it pays from 1.5 workgroups per compute unit on.  BOD_POINTWISE_MIN_M >= 0 (tests) replaces the rule by that pixel floor.
+    static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : -1; }();
+    if (min_m >= 0) return a.M >= min_m;
+    const long nstrips = (long)(a.M / (a.plane_h * a.plane_w)) * ((a.plane_w + 63) / 64);
+    return 2 * nstrips >= 3 * (long)launch_cus(a);
 }
 
 hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s) {
@@ -442,8 +453,9 @@ hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s) {
     // ahead, 23.11-23.17 with two (a sixth ring slot and longer wait chains for nothing: the row in flight is not what a row waits for),
     // 23.69 on the generic kernel
     static const int lead = [] { const char* e = getenv("BOD_SLIDE_LEAD"); return e ? atoi(e) : 1; }();
-    if (lead == 2) hipLaunchKernelGGL(slide3x3_c64_kernel<2>, dim3(std::min(nstrips, 512)), dim3(256), LDS, s, a, nstrips, xsegs);
-    else hipLaunchKernelGGL(slide3x3_c64_kernel<1>, dim3(std::min(nstrips, 512)), dim3(256), 4 * 66 * 128 + 2 * 64 * 128, s, a, nstrips, xsegs);
+    const int wgs = std::min(nstrips, 2 * launch_cus(a));             // two workgroups per compute unit; the rest of the strips in further rounds
+    if (lead == 2) hipLaunchKernelGGL(slide3x3_c64_kernel<2>, dim3(wgs), dim3(256), LDS, s, a, nstrips, xsegs);
+    else hipLaunchKernelGGL(slide3x3_c64_kernel<1>, dim3(wgs), dim3(256), 4 * 66 * 128 + 2 * 64 * 128, s, a, nstrips, xsegs);
     return hipGetLastError();
 }
 

@@ -998,7 +998,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 // written; aux_kernels.hip, BOD_STEM_POOL_FUSED=0: the two launches).  Training handles keep the plane (pool backward).
                 const Op* pool = op_i < h->ops.size() && h->ops[op_i].kind == Op::POOL ? &h->ops[op_i] : nullptr;
                 stem_pool_fused = pool && !h->train && h->es == 2 && !h->split && !trace &&
-                                  stem_pool_fused_applies(dev_images, c.batch, c.image_w, h->sw);
+                                  stem_pool_fused_applies(dev_images, c.batch, c.image_w, h->sw, is_front ? cus_front : cus_back);
                 if (stem_pool_fused)
                     HIPCHK(h, launch_stem_pool_fused(dev_images, h->stem_w, h->stem_b, pool->conv.g[0].out, c.batch, c.image_h, c.image_w, h->sh,
                                                      h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));

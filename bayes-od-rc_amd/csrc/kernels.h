@@ -115,6 +115,10 @@ struct PerDeviceOnce {
     bool* slot() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return &done[d]; }
 };
 
+// Compute units a launch may fill: ConvArgs.n_cu when the engine set it (the whole chip, or a CU-partitioned stream's share), else the
+// current device's count (hipDeviceProp_t::multiProcessorCount, cached per device).  The planner's rules compare workgroup counts with it.
+int device_cu_count();
+inline int launch_cus(const ConvArgs& a) { return a.n_cu > 0 ? a.n_cu : device_cu_count(); }
 hipError_t launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide cout tile => 1x1 fusion possible
 bool conv_igemm_uses_big_tile(const ConvArgs& a);         // true => the 256x256 tile (any cout); false => 128-pixel tiles
@@ -130,7 +134,7 @@ hipError_t launch_stem_conv(const float* img, const float* w, const float* bias,
 // ZeroPadding2D((1,2)) + MaxPool 3x3 s2 VALID on [B,ih,iw,64] -> padded-plane output.  mode 0: bf16 -> bf16; 1: fp32 -> fp32;
 // 2: fp32 -> (hi, lo) bf16 pairs (bf16x3 precision)
 // stem + zero-pad + max-pool in one kernel (bf16 inference, stem rows of <= 256 pixels; aux_kernels.hip)
-bool stem_pool_fused_applies(const float* img, int B, int W, int ow);
+bool stem_pool_fused_applies(const float* img, int B, int W, int ow, int n_cu);
 hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int B, int H, int W, int oh, int ow,
                                   int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s);
 hipError_t launch_stem_pool(const void* in, void* out, int mode, int B, int ih, int iw, int oh, int ow,
