@@ -372,6 +372,17 @@ def secondary_configs(device, weights, lo):
     entry("BASELINE config 4 geometry on one GPU: ResNet-50 RetinaNet + covar head, N=30 MC-dropout, KITTI 384x1248, full BayesOD "
           "pipeline, %d frames/step" % B, dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, 30), B)
     eng.close()
+    # ---- the frame sizes the reference really runs (it never sees 512x512 or 384x1248): native BDD 720x1280
+    # (bdd_dataset_handler.py:128-139) and KITTI resized / padded to 512x1696 (kitti_dataset_handler.py:125-132), N=10, full pipeline
+    for hw, name in (((720, 1280), "BDD frames at their native 720x1280"), ((512, 1696), "KITTI frames resized to 512x1696")):
+        B, n = 64, 10
+        eng = make_engine(hw, B, n, device, weights=weights, anchors=gen.generate_all((hw[0], hw[1], 3)))
+        eng.upload_images(synthetic.make_frames(B, hw[0], hw[1], seed=lo))
+        steps = 5
+        dt = timed_pipeline(eng, steps, 2, False, B)
+        entry("the reference's real geometry: %s (SURVEY F7), ResNet-50 RetinaNet + covar head, N=10 MC-dropout, full BayesOD pipeline, "
+              "%d frames/step" % (name, B), dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, n), B)
+        eng.close()
     # ---- config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (the yaml's minibatch of 3)
     hw, B = (512, 512), 3
     samples = synthetic_samples(B, hw, ANCHOR_CFG, 7)

@@ -70,6 +70,55 @@ def test_forward_at_bf16_noise_floor(hw, batch, n):
             assert np.corrcoef(dg, de)[0, 1] > 0.99
 
 
+REAL_GEOMETRIES = [((720, 1280), "bdd"), ((512, 1696), "kitti")]
+
+
+@pytest.mark.parametrize("hw,dataset", REAL_GEOMETRIES)
+def test_the_reference_s_real_frame_sizes_against_the_cpu_forward(hw, dataset):
+    """The sizes the reference actually feeds the network: BDD frames at their native 720 x 1280
+    (bdd_dataset_handler.py:128-139: no resize) and KITTI frames resized / padded to 512 x 1696
+    (kitti_dataset_handler.py:125-132) -- P = 19 220 / 18 080 pyramid pixels, the 23 -> 45 nearest up-sampling whose ratio is not
+    an integer, odd SAME strides, stage-2 rows of 320 / 424 pixels (5 / 7 column strips of the sliding-window kernel, not multiples
+    of 64), a P7 level of 6 x 10 / 4 x 14.  One full-size frame, N = 2 MC samples, against oracle/torch_ref.py's fp32 forward with
+    the same Philox masks: bf16x3 (the parity mode) element-wise within north_star's 1e-3 on pyramid and head outputs, bf16 (the
+    throughput mode) at its storage-noise floor (relative RMS < 2 %, the bound of test_forward_at_bf16_noise_floor, whose
+    emulation oracle is too slow at this size) with the MC sample differences correlated > 0.99 with the reference's."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    from oracle import philox, torch_ref
+    seed, first, n = 20241003, 11, 2
+    w = synthetic.make_weights()
+    frame = synthetic.make_frames(1, hw[0], hw[1], seed=5)
+    got = {}
+    for precision in ("bf16x3", "bf16"):
+        eng = Engine(make_config(hw, batch=1, mc_samples=n, precision=precision))
+        eng.load_weights(w)
+        eng.forward(frame, seed=seed, first_image_id=first)
+        cls, box, cov = eng.get_raw()
+        got[precision] = {"cls": cls[0].copy(), "box": box[0].copy(), "cov": cov[0].copy(), "pyr": [eng.get_pyramid(l)[0].copy() for l in range(5)]}
+        P = eng.P
+        levels = eng.levels
+        eng.close()
+    want_levels = {"bdd": [(90, 160), (45, 80), (23, 40), (12, 20), (6, 10)], "kitti": [(64, 212), (32, 106), (16, 53), (8, 27), (4, 14)]}[dataset]
+    assert [tuple(l) for l in levels] == want_levels and P == sum(h * ww for h, ww in want_levels)       # SURVEY App. B
+    ref = torch_ref.retinanet_forward(w, frame, n, 8, keep_masks=lambda s_, lid: philox.dropout_keep_mask(seed, first, s_, lid, P, 256, 0.3))
+    items = lambda g: [("P%d" % (l + 3), g["pyr"][l], ref["_pyramid"][l][0]) for l in range(5)] + [
+        ("cls", g["cls"], ref["anchors_class_predictions"]), ("box", g["box"], ref["anchors_box_predictions"]), ("cov", g["cov"], ref["_covar_params"])]
+    worst = 0.0
+    for name, a, t in items(got["bf16x3"]):
+        assert a.shape == t.shape, name
+        rms = _rms(t)
+        err = float(np.max(np.abs(a - t) / (np.abs(t) + rms)))
+        worst = max(worst, err)
+        assert err < 1e-3, (name, err)
+    for name, a, t in items(got["bf16"]):
+        assert _rms(a - t) / _rms(t) < 2e-2, (name, _rms(a - t) / _rms(t))
+    dg = (got["bf16"]["cls"][0] - got["bf16"]["cls"][1]).ravel()
+    dr = (ref["anchors_class_predictions"][0] - ref["anchors_class_predictions"][1]).ravel()
+    assert np.corrcoef(dg, dr)[0, 1] > 0.99
+    print("%dx%d: bf16x3 max rel err %.2e vs the fp32 CPU forward" % (hw[0], hw[1], worst))
+
+
 def test_n1_disables_dropout_and_is_seed_independent():
     """mc_dropout_samples == 1 => dropout off (retinanet_model.py:74-77); BASELINE config 2."""
     w, frames, eng = _setup((128, 128), 1, 1)
@@ -514,21 +563,25 @@ def test_fused_stem_pool_is_bit_identical():
         assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k
 
 
-def test_streaming_backbone_kernels_are_bit_identical_at_full_size():
+@pytest.mark.parametrize("hw,batch", [((512, 512), 128), ((720, 1280), 12), ((512, 1696), 12)])
+def test_streaming_backbone_kernels_are_bit_identical_at_full_size(hw, batch):
     """The round-3 backbone kernels (fused stem + pool, streaming pointwise with stage 2's fused reduction, sliding-window 3x3)
     against the generic launches at the bench's frame size and a batch that fills the chip (128 frames of 512 x 512: two
     workgroups per CU in every persistent kernel, the shapes the explicit vmcnt waits and the LDS rings are exercised hardest
-    by), three forwards each: checksums of every pyramid level and of the raw head outputs must agree exactly."""
+    by), three forwards each: checksums of every pyramid level and of the raw head outputs must agree exactly.  Round 4: also at
+    the reference's real frame sizes -- 720 x 1280 (stage-2 rows of 320 pixels: 5 column strips) and 512 x 1696 (424
+    pixels: 7 strips, the last one 40 pixels wide; ragged pointwise tiles).  The planner's batch floors are lowered so that every
+    streaming kernel really runs at these batches (BOD_POINTWISE_MIN_M / BOD_STEM_POOL_FUSED_MIN_B)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import numpy as np, sys, json; sys.path.insert(0, %r)\n"
+    code = ("import numpy as np, sys, json; sys.path.insert(0, %%r)\n"
             "from bayes_od_rc_amd import synthetic\n"
             "from bayes_od_rc_amd.engine import Engine, make_config\n"
-            "eng = Engine(make_config((512, 512), batch=128, mc_samples=1))\n"
+            "eng = Engine(make_config((%d, %d), batch=%d, mc_samples=1))\n"
             "eng.load_weights(synthetic.make_weights())\n"
-            "frames = synthetic.make_frames(128, 512, 512, seed=9)\n"
+            "frames = synthetic.make_frames(%d, %d, %d, seed=9)\n" % (hw[0], hw[1], batch, batch, hw[0], hw[1])) + (
             "out = []\n"
             "for rep in range(3):\n"
             "    eng.forward(frames, seed=1, first_image_id=rep)\n"
@@ -540,11 +593,12 @@ def test_streaming_backbone_kernels_are_bit_identical_at_full_size():
             "        v = np.ascontiguousarray(t).view(np.uint32).ravel()\n"
             "        row.append([int(v.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(v))])\n"
             "    out.append(row)\n"
-            "print('CHECKSUMS ' + json.dumps(out))\n" % root)
+            "print('CHECKSUMS ' + json.dumps(out))\n")
+    code = code % root
     sums = []
     for streaming in ("1", "0"):
         env = dict(os.environ, BOD_POINTWISE=streaming, BOD_SLIDE3X3=streaming, BOD_STEM_POOL_FUSED=streaming, BOD_PW_FUSE_NEXT=streaming,
-                   BOD_CHAIN_FUSION="0")
+                   BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_STEM_POOL_FUSED_MIN_B="1")
         if streaming == "0":
             env["BOD_STEM_SEG64"] = "1"
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)

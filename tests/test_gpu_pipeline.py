@@ -708,14 +708,16 @@ def test_model_without_covariance_head():
     assert dets[0][0].shape[0] > 0 and np.isfinite(dets[0][2]).all()
 
 
-@pytest.mark.parametrize("hw,n,batch", [((512, 512), 10, 16), ((384, 1248), 30, 4)])
+@pytest.mark.parametrize("hw,n,batch", [((512, 512), 10, 16), ((384, 1248), 30, 4), ((720, 1280), 10, 4), ((512, 1696), 10, 4)])
 def test_full_size_properties(hw, n, batch):
     """BASELINE.json's metric configuration (512x512, N=10; 16 frames per step here: the row-reuse tower kernel, fused
     1x1 outputs and the 256x256 fan-out tile are all in play) and its KITTI configuration (384x1248, N=30), where the
     oracle is too slow: size-independent
     properties instead -- two runs are bit-identical, the pipelined path equals the synchronous one, every fused
     covariance is symmetric positive definite, class scores are distributions, counts are positive, boxes finite,
-    and the MC samples differ (dropout is on) while the first tower layer is shared."""
+    and the MC samples differ (dropout is on) while the first tower layer is shared.  The last two cases are the frame sizes the
+    reference really runs: native BDD 720x1280 (bdd_dataset_handler.py:128-139) and KITTI resized to 512x1696
+    (kitti_dataset_handler.py:125-132), N = 10."""
     from bayes_od_rc_amd import synthetic
     from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
     from bayes_od_rc_amd.engine import Engine, make_config
@@ -732,7 +734,7 @@ def test_full_size_properties(hw, n, batch):
     slot = eng.infer_async(frames, seed=9, first_image_id=100)
     piped = eng.collect(slot)
     kept = eng.num_kept()
-    assert (np.asarray(kept) > 100).all() and (np.asarray(kept) < 5000).all()             # the calibrated filter keeps ~1 000 anchors
+    assert (np.asarray(kept) > 100).all() and (np.asarray(kept) < 0.1 * eng.A).all()      # the calibrated filter keeps ~2 % of the anchors (~1 000 at 512x512)
     for other in (second, piped):
         assert np.array_equal(first["num"], other["num"])
     for b in range(batch):
