@@ -21,7 +21,7 @@ def _bayes_testing_kwargs(bayes_od_config, nms_config, use_full_covar, dataset_n
 
 def bayes_od_inference(model, sample_dict, bayes_od_config, nms_config, use_full_covar=False,
                        dataset_name='bdd', seed=None, image_id=None, nms_variant='A',
-                       return_iou=True):
+                       return_iou=True, return_engine=False):
     """Same 5 return values as the reference (:217) for a batch-of-1 ``sample_dict``:
 
         dirichlet_posterior_count [M,C], gaussian_posterior_means [M,4,1],
@@ -30,6 +30,9 @@ def bayes_od_inference(model, sample_dict, bayes_od_config, nms_config, use_full
     ``seed`` / ``image_id`` key the Philox streams that replace TF's unseeded RNG.
     ``return_iou=False`` skips materialising the M x M matrix (the device clustering does not
     need it); an empty [0,0] array is returned in its place.
+    ``return_engine=True`` appends the handle that produced the results as a sixth value: passing it to
+    ``bayes_od_clustering(..., engine=)`` re-uses its device buffers.  Without it the two calls are as independent as
+    the reference's (run_inference.py:138-149): nothing is remembered between them.
     """
     image = np.asarray(sample_dict[constants.IMAGE_NORMALIZED_KEY], dtype=np.float32)
     if image.ndim == 3:
@@ -56,8 +59,8 @@ def bayes_od_inference(model, sample_dict, bayes_od_config, nms_config, use_full
     post = eng.get_posterior(0)
     nms_indices = eng.get_nms(0)
     iou = eng.get_iou_matrix(0) if return_iou else np.zeros((0, 0), np.float32)
-    model._last_engine = eng
-    return post["counts"], post["means"][:, :, None], post["covs"], nms_indices, iou
+    out = (post["counts"], post["means"][:, :, None], post["covs"], nms_indices, iou)
+    return out + (eng,) if return_engine else out
 
 
 def bayes_od_clustering(predicted_boxes_class_counts, predicted_boxes_means, predicted_boxes_covs,
@@ -70,6 +73,8 @@ def bayes_od_clustering(predicted_boxes_class_counts, predicted_boxes_means, pre
     ``affinity_matrix=None`` selects the reference pipeline's own affinity, ``bbox_iou_vuvu`` of the
     posterior means (:204-215, run_inference.py:145-149), evaluated on the fly against each centre
     on the device without ever building the M x M matrix.
+    ``engine``: optional handle to run on (``bayes_od_inference(..., return_engine=True)``); by default the call runs on a
+    small post-processing handle of its own, sized for M boxes -- it depends on nothing but its arguments, like the reference's.
     """
     from .engine import Engine, make_config
     counts = np.ascontiguousarray(predicted_boxes_class_counts, dtype=np.float32)

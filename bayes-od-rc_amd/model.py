@@ -129,8 +129,6 @@ class RetinaNetModel(object):
         if self.compute_covar:
             self.prediction_dict[constants.ANCHORS_COVAR_PREDICTIONS_KEY] = \
                 fill_triangular_4(cov.reshape(b * nn, a, 10))
-        self._last_engine = eng
-        self._last_seed, self._last_image_id = seed, image_id
         return self.prediction_dict
 
     call = __call__

@@ -98,9 +98,16 @@ def test_reference_surface_bayes_od_inference():
     m = counts.shape[0]
     assert counts.shape == (m, 8) and means.shape == (m, 4, 1) and covs.shape == (m, 4, 4)
     assert iou.shape == (m, m) and nms_idx.ndim == 1 and len(nms_idx) <= 100 and m > 0
+    # the two calls are independent, as in the reference (run_inference.py:138-149): no handle, no hidden state between them
     out_cls, out_means, out_covs, out_counts = inference_utils.bayes_od_clustering(
-        counts, means, covs, nms_idx, iou, affinity_threshold=NMS_CFG["iou_threshold"],
-        engine=model._last_engine)
+        counts, means, covs, nms_idx, iou, affinity_threshold=NMS_CFG["iou_threshold"])
+    # ... and an explicitly returned handle gives the same results on the model's own device buffers
+    *same5, eng = inference_utils.bayes_od_inference(
+        model, sample, BAYES_CFG, NMS_CFG, use_full_covar=True, dataset_name="bdd", seed=3, image_id=0, return_engine=True)
+    assert all(np.array_equal(a, b) for a, b in zip(same5, (counts, means, covs, nms_idx, iou)))
+    again = inference_utils.bayes_od_clustering(counts, means, covs, nms_idx, iou, affinity_threshold=NMS_CFG["iou_threshold"], engine=eng)
+    assert all(np.array_equal(a, b) for a, b in zip(again, (out_cls, out_means, out_covs, out_counts)))
+    assert not hasattr(model, "_last_engine")
     k = len(nms_idx)
     assert out_cls.shape == (k, 8) and out_means.shape == (k, 4, 1) and out_covs.shape == (k, 4, 4)
     assert np.allclose(out_cls.sum(1), 1.0, atol=1e-5)
