@@ -48,7 +48,12 @@ template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_
 // ConvGroup.ch_w3 / ch_b3 / ch_out3) is computed from the finished tile while it is still in LDS -- the 2.1 GB block output is
 // written once and read once (by the next shortcut) instead of twice, and the next block's `2a` launch disappears.  The `2a` MFMAs
 // read the stored bf16 values of the tile in ascending k order like the generic kernel would from memory: bit-identical.
-template <int K, int BP, bool RES, int WGS, int BC = 128, bool NEXT = false>
+// NEXT = 2 ("dual", round 4): the second 64-cout convolution reads the INPUT tile instead of the finished one -- a ConvBlock's first
+// two launches, `branch1` (64 -> 256, the projection shortcut) and `2a` (64 -> 64 + ReLU), both 1x1 over the same pooled plane
+// (feature_extractor.py:283-309), become one: the plane is read once, and the 2a launch -- a one-K-tile layer that ran 4.16 M
+// pixels through the generic kernel's per-tile latency chain at 1.1 TB/s, 0.97 ms per 256 frames -- disappears.  Same MFMA, same k
+// order (four k-steps of 16 ascending), same epilogue arithmetic as the generic 64x128 tile: bit-identical.
+template <int K, int BP, bool RES, int WGS, int BC = 128, int NEXT = 0>
 __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, int ptiles, int ctiles, int pstride) {
     constexpr int THREADS = BC * 2;               // one wave per 32 couts
     constexpr int CPX = K * 2 / 16;               // 16-byte chunks per input pixel row
@@ -58,7 +63,8 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
     constexpr int NXP = BP * CPX / THREADS;       // input DMA pieces per thread
     constexpr int NRP = BP * RCH / THREADS;       // shortcut pieces (and output stores) per thread
     constexpr int FP = BP / 32, KS = K / 16;
-    constexpr int C2 = 64, KS2 = BC / 16;         // NEXT: couts and k-steps of the fused 2a
+    constexpr int C2 = 64, KS2 = NEXT == 2 ? K / 16 : BC / 16;       // NEXT: couts and k-steps of the fused 2a (dual: over the input's channels)
+    constexpr int K2 = NEXT == 2 ? K : BC;        // channels the fused 2a reduces
     constexpr int NTP = NEXT ? BP * (C2 / 8) / THREADS : 0;     // NEXT: stores of the 2a tile per thread
     static_assert(NXP >= 1 && NRP >= 1 && BP % 32 == 0 && (CPX & 7) == 0 && (!NEXT || (BC == 256 && BP == 64 && NTP == 1)), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char pw_smem[];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
     pw_bf16x8 wf2[NEXT ? KS2 : 1];
     float4 bv2[4];
     if (NEXT) {
-        const char* wrow = reinterpret_cast<const char*>(G.ch_w3) + ((size_t)((wave & 1) * 32 + frow) * BC + fhalf * 8) * 2;
+        const char* wrow = reinterpret_cast<const char*>(G.ch_w3) + ((size_t)((wave & 1) * 32 + frow) * K2 + fhalf * 8) * 2;
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) wf2[ks] = *reinterpret_cast<const pw_bf16x8*>(wrow + ks * 32);
 #pragma unroll
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
                 for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks) {
-                    const pw_bf16x8 b = *reinterpret_cast<const pw_bf16x8*>(rb + px * (BC * 2) + (((ks * 2 + fhalf) ^ (px & 7)) << 4));
+                    const pw_bf16x8 b = NEXT == 2 ? *reinterpret_cast<const pw_bf16x8*>(xb + px * (K * 2) + (((ks * 2 + fhalf) ^ (px & 7)) << 4))
+                                                  : *reinterpret_cast<const pw_bf16x8*>(rb + px * (BC * 2) + (((ks * 2 + fhalf) ^ (px & 7)) << 4));
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[ks], b, acc2, 0, 0, 0);
                 }
 #pragma unroll
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(BC * 2, WGS) void pw_conv_kernel(const ConvArgs a, 
     }
 }
 
-template <int K, int BP, bool RES, int WGS, int BC = 128, bool NEXT = false>
+template <int K, int BP, bool RES, int WGS, int BC = 128, int NEXT = 0>
 static hipError_t pw_launch_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * BP * K * 2 + (RES ? 2 : 1) * BP * BC * 2 + 3 * BP * 16 + (NEXT ? BP * 128 : 0);
     static PerDeviceOnce once;
@@ -264,7 +271,7 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
     if (a.variant != 0 || a.split || a.xreuse || a.ksplit > 1 || a.groups != 1 || a.taps != 1 || a.fan_count > 1) return false;
     if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
     if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind) return false;
-    if (g.ch_w3 && !(a.cin == 64 && a.cout_pad == 256 && g.res && g.ch_b3 && g.ch_out3)) return false;   // fused next 2a: stage 2's shape only
+    if (g.ch_w3 && !(a.cin == 64 && a.cout_pad == 256 && (g.res != nullptr) != (g.ch_dual != 0) && g.ch_b3 && g.ch_out3)) return false;   // fused 2a: stage 2's shapes only
     // (512-channel reductions WITH shortcut need two output buffers and fit one workgroup per CU only: +0.55 ms per 256-frame step
     //  against the generic kernel, not kept)
     // 512-channel reductions WITHOUT shortcut (stage 3's `2a`, stage 4's first block, the C3 lateral of the FPN): 128 weight registers,
@@ -285,7 +292,8 @@ bool conv_pointwise_eligible(const ConvArgs& a) {
 
 hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
     const bool res = a.g[0].res != nullptr;
-    if (a.g[0].ch_w3) return pw_launch_cfg<64, 64, true, 1, 256, true>(a, s);      // 2c + the next block's 2a (stage 2)
+    if (a.g[0].ch_w3 && a.g[0].ch_dual) return pw_launch_cfg<64, 64, false, 1, 256, 2>(a, s);   // branch1 + the same block's 2a on one input tile (stage 2's ConvBlock)
+    if (a.g[0].ch_w3) return pw_launch_cfg<64, 64, true, 1, 256, 1>(a, s);         // 2c + the next block's 2a (stage 2)
     // (32-pixel tiles with 5 / 4 workgroups per CU for the 64- / 128-channel reductions measured: +0.3 ms per 256-frame step)
     if (a.cin == 64) return res ? pw_launch_cfg<64, 64, true, 3>(a, s) : pw_launch_cfg<64, 64, false, 3>(a, s);
     if (a.cin == 128) return res ? pw_launch_cfg<128, 64, true, 2>(a, s) : pw_launch_cfg<128, 64, false, 2>(a, s);
@@ -468,4 +476,14 @@ bool conv_pointwise_can_fuse_next(const ConvArgs& a) {
     static const bool res_reg = [] { const char* e = getenv("BOD_RES_REGISTER"); return e && atoi(e) == 1; }();   // (sends the launch to a variant build)
     if (!on || forced || nt || res_reg) return false;
     return a.cin == 64 && a.cout_pad == 256 && a.g[0].res && conv_pointwise_eligible(a);
+}
+
+// ... and may a 64 -> 256 projection shortcut (no residual of its own) carry its block's 2a on the same input tile (dual form)?
+bool conv_pointwise_can_fuse_dual(const ConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("BOD_PW_FUSE_DUAL"); return !e || atoi(e) != 0; }();
+    static const bool forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e && atoi(e) != 0; }();
+    static const bool nt = [] { const char* e = getenv("BOD_NT_STORES"); return e && (atoi(e) & 1); }();
+    static const bool res_reg = [] { const char* e = getenv("BOD_RES_REGISTER"); return e && atoi(e) == 1; }();
+    if (!on || forced || nt || res_reg) return false;
+    return a.cin == 64 && a.cout_pad == 256 && !a.g[0].res && !(a.flags & CONV_RELU) && conv_pointwise_eligible(a);
 }

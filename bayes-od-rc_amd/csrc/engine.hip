@@ -591,9 +591,29 @@ bod_status build_plan(bod_context* h) {
             }
             Plane& out = use_a ? oa : ob;
             if (*bl == 'a') {
-                BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, first_stride, false, true, nullptr));
+                // Stage 2's ConvBlock: `branch1` (64 -> 256) and `2a` (64 -> 64 + ReLU) are both 1x1 over the pooled plane
+                // (feature_extractor.py:283-309).  On the pointwise kernel's 256-channel tile the 2a rides on branch1's input tile
+                // (conv_pointwise.hip, dual form): one launch, the plane read once.  BOD_PW_FUSE_DUAL=0: the two launches.
+                bool dual = false;
+                if (st == 2 && !train_mode && h->es == 2 && !h->split) {
+                    BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
+                    Op& op1 = h->ops.back();
+                    PackedConv p2a;
+                    BODCHK(pack_conv(h, c_ + "2a", b_ + "2a", 64, &p2a));
+                    if (conv_pointwise_can_fuse_dual(op1.conv) && op1.conv.ksplit <= 1 && p2a.cin == 64 && p2a.cout == f1 && f1 == 64 &&
+                        p2a.taps == 1 && p2a.cout_pad == 64) {
+                        ConvGroup& G = op1.conv.g[0];
+                        G.ch_w3 = p2a.w; G.ch_b3 = p2a.bias; G.ch_out3 = t1.d; G.ch_dual = 1;
+                        op1.flops += 2.0 * op1.conv.M * (double)f1 * 64.0;
+                        op1.name += std::string("+") + c_ + "2a"; op1.wname[2] = c_ + "2a"; op1.bnname[2] = b_ + "2a";
+                        dual = true;
+                    } else {
+                        h->ops.pop_back();            // planned below in the reference's order
+                    }
+                }
+                if (!dual) BODCHK(add_conv(h, c_ + "2a", b_ + "2a", x, t1, first_stride, false, true, nullptr));
                 BODCHK(add_conv(h, c_ + "2b", b_ + "2b", t1, t2, 1, true, true, nullptr));
-                BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
+                if (!dual) BODCHK(add_conv(h, c_ + "1", b_ + "1", x, sc, first_stride, false, false, nullptr));
                 BODCHK(add_conv(h, c_ + "2c", b_ + "2c", t2, out, 1, false, true, &sc));
                 BODCHK(fuse_next_2a(bl));
                 // the C3 / C4 taps are the block-'a' outputs (:119-120,:126-127): keep them alive

@@ -48,6 +48,10 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     // geometry (pixel index = RowEnt.out_off); the 2b output itself is not stored.  feature_extractor.py:195-213,283-309.
     const void* ch_w2; const float* ch_b2; const void* ch_res; void* ch_out; int32_t ch_c2;
     const void* ch_w3; const float* ch_b3; void* ch_out3;
+    // Pointwise kernel, dual form (conv_pointwise.hip, NEXT = 2): ch_w3 / ch_b3 / ch_out3 describe a second 1x1 convolution (64 couts,
+    // + bias + ReLU) of the SAME input tile -- a ConvBlock's `2a` riding on its projection shortcut `branch1` -- instead of one of
+    // the finished output tile.
+    int32_t ch_dual;
 };
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
 
@@ -255,6 +259,7 @@ hipError_t launch_loss_backward(const LossArgs& a, const float* sums4, float w_c
 // launches there (BOD_POINTWISE=0: off)
 bool conv_pointwise_eligible(const ConvArgs& a);
 bool conv_pointwise_can_fuse_next(const ConvArgs& a);      // plan time: may a 64 -> 256 expansion carry the next block's 2a (ch_w3)?
+bool conv_pointwise_can_fuse_dual(const ConvArgs& a);      // plan time: may a 64 -> 256 projection shortcut carry its own block's 2a (ch_w3 + ch_dual)?
 hipError_t launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
 // Sliding-window 3x3 stride-1 SAME convolution, 64 -> 64 channels (ResNet stage 2's `2b`; conv_pointwise.hip, BOD_SLIDE3X3=0: off)
 bool conv_slide3x3_eligible(const ConvArgs& a);

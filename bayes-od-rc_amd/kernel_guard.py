@@ -297,7 +297,7 @@ def verify_pointwise(host_obj):
     regs = verify_aux(host_obj, POINTWISE_PRODUCTION)
     for n, v in regs.items():
         # pw_conv_kernel<K, BP, RES, WGS, BC, NEXT>: WGS workgroups of BC/32 waves per CU must stay co-resident
-        m = re.search(r"pw_conv_kernelILi\d+ELi\d+ELb[01]ELi(\d+)ELi(\d+)ELb[01]E", n)
+        m = re.search(r"pw_conv_kernelILi\d+ELi\d+ELb[01]ELi(\d+)ELi(\d+)ELi[012]E", n)
         if m:
             waves_per_simd = int(m.group(1)) * (int(m.group(2)) // 32) / 4.0
             cap = min(512, int(512 / waves_per_simd) // 8 * 8)

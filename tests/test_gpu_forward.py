@@ -527,6 +527,47 @@ def test_pointwise_fused_next_reduction_is_bit_identical():
         assert np.isfinite(outs[0][k]).all(), k
 
 
+def test_pointwise_dual_convblock_launch_is_bit_identical():
+    """Stage 2's ConvBlock on the pointwise kernel's dual form (round 4): the projection shortcut `branch1` (64 -> 256) carries the
+    block's own 1x1 reduction `2a` (64 -> 64 + ReLU) on the SAME input tile (conv_pointwise.hip, NEXT = 2; feature_extractor.py:
+    283-309).  BOD_PW_FUSE_DUAL=0 plans the two launches in the reference's order: pyramid and raw head outputs must not differ by
+    one bit; the fused plan is one launch shorter.  Square / non-square frames, ragged last tiles, ResNet-50 and -101."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b, depth in (('a', (128, 128), 3, 50), ('b', (96, 160), 1, 50), ('c', (192, 624), 2, 50), ('d', (128, 128), 2, 101), ('e', (256, 256), 9, 50), ('f', (360, 640), 2, 50)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=2, backbone_depth=depth))\n"
+            "    eng.load_weights(synthetic.make_weights(depth=depth))\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=3), seed=11, first_image_id=2)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    for k, v in zip('cbv', eng.get_raw()): out['%%s_%%s' %% (tag, k)] = v\n"
+            "    out[tag + '_ops'] = np.int32(eng.plan_info()['ops'])\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_PW_FUSE_DUAL=on, BOD_POINTWISE="1", BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1])
+    for k in sorted(outs[0]):
+        if k.endswith("_ops"):
+            assert int(outs[0][k]) == int(outs[1][k]) - 1, (k, int(outs[0][k]), int(outs[1][k]))
+            continue
+        assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
+        assert np.isfinite(outs[0][k]).all(), k
+
+
 def test_fused_stem_pool_is_bit_identical():
     """bf16 inference on stem rows of at most 256 pixels runs stem + ZeroPadding2D((1,2)) + max-pool as ONE kernel (aux_kernels.hip,
     stem_pool_fused_kernel: a workgroup walks down an image with an 8-row input ring, stem rows are max-combined in registers,
@@ -598,7 +639,7 @@ def test_streaming_backbone_kernels_are_bit_identical_at_full_size(hw, batch):
     sums = []
     for streaming in ("1", "0"):
         env = dict(os.environ, BOD_POINTWISE=streaming, BOD_SLIDE3X3=streaming, BOD_STEM_POOL_FUSED=streaming, BOD_PW_FUSE_NEXT=streaming,
-                   BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_STEM_POOL_FUSED_MIN_B="1")
+                   BOD_PW_FUSE_DUAL=streaming, BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_STEM_POOL_FUSED_MIN_B="1")
         if streaming == "0":
             env["BOD_STEM_SEG64"] = "1"
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sums the PMC counters of the row-reuse tower kernel over the dispatches of tests/tools/pmc_head_conv.sh's three
 passes (rocprofv3 --pmc ... --output-format csv) and prints the derived ratios quoted in DESIGN.md section 5.1.
-usage: pmc_head_summary.py <dir with pmc_sq1/ pmc_sq2/ pmc_tcc/>  > profiles/roundN_head_conv_counters.json"""
+usage: pmc_head_summary.py <dir with pmc_sq1/ pmc_sq2/ pmc_tcc/> ["label of the run"]  > profiles/roundN_head_conv_counters.json"""
 import csv, glob, json, os, sys
 
 root = sys.argv[1]
@@ -13,7 +13,8 @@ for sub in ("pmc_sq1", "pmc_sq2", "pmc_tcc"):
                 if "4, 0, true" not in row.get("Kernel_Name", ""):          # conv_igemm_kernel<256, 256, 2, 4, 0, true, false>: the tower kernel
                     continue
                 tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-out = {"kernel": "conv_igemm_kernel<256,256,2,4,0,true> (tests/tools/bench_head_conv.py, layer 1, B=8)", "counters": tot}
+label = sys.argv[2] if len(sys.argv) > 2 else "tests/tools/bench_head_conv.py, layer 1, B=8"
+out = {"kernel": "conv_igemm_kernel<256,256,2,4,0,true> (%s)" % label, "counters": tot}
 g = tot.get("GRBM_GUI_ACTIVE")
 if g:
     # GRBM_* are reported summed over the 8 XCDs (GUI_ACTIVE / 8 / dispatches = the launch duration in shader clocks:
