@@ -415,8 +415,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (256: ~60 GB of the 288 GB; the tower "
-                    "launches then hold 218 tiles per CU and the step's fixed costs are amortised: +4 %% over 64)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (512: ~140 GB of the 288 GB; the tower "
+                    "launches then hold 436 tiles per CU and the step's fixed costs -- launch ramps and tails -- are amortised: "
+                    "+5 %% over 64, +1.1 %% over 256 frames/s on one box, tower roofline 0.495 -> 0.501)")
     ap.add_argument("--mc", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
@@ -666,7 +667,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes) when they were taken on this exact configuration, else null
     traffic, traffic_source = None, None
-    for pmc_file in ("round3_head_conv_pmc.json", "round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
+    for pmc_file in ("round4_head_conv_pmc.json", "round3_head_conv_pmc.json", "round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as fp:
                 pmc = json.load(fp)
@@ -828,7 +829,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     if extras:
         # ---- parity_mode: the bf16x3 precision mode ((hi, lo) bf16 pairs, three MFMA products per MAC) -- the mode in which the
         # pipeline meets north_star's 1e-3 end to end -- timed in the same run on the same frames
-        Bp = B                            # the production data path: fused 1x1 + MC aggregation, no [B,N,A,.] tensors (92 GB of pair planes at 256 frames)
+        Bp = min(B, 256)                  # the production data path: fused 1x1 + MC aggregation, no [B,N,A,.] tensors (92 GB of pair planes at 256 frames)
         engp = make_engine(hw, Bp, n, local_rank, precision="bf16x3", weights=weights, anchors=anchors)
         engp.upload_images(frames[:Bp])
         engp.infer(None, seed=0, first_image_id=lo)

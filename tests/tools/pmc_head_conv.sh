@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for the head-tower conv micro-benchmark (run on the GPU box through gpurun).
 # usage: pmc_head_conv.sh <variant list> ; writes gpurun_out/pmc_<set>/
-#        PMC_PRODUCTION=1 pmc_head_conv.sh : the same three passes over two steps of the headline bench (256 frames per step: the
+#        PMC_PRODUCTION=1 pmc_head_conv.sh : the same three passes over two steps of the headline bench (512 frames per step: the
 #        production launches of the tower kernel) instead of the micro-benchmark
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 V="${@:-0}"

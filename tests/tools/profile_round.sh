@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every profile of a round in one call (run on the GPU box through gpurun): writes gpurun_out/<prefix>_* -- copy them under profiles/.
 #   kernel trace + stats of the bench command, HBM traffic (FETCH / WRITE PMC passes), SQ / TCC counters and the phase clock of the
-#   tower kernel on its PRODUCTION launches (256 frames per step), the training step's kernel trace.
+#   tower kernel on its PRODUCTION launches (512 frames per step), the training step's kernel trace.
 # usage: profile_round.sh <prefix, e.g. round4> "<label>"
 P=${1:-round}; LABEL="${2:-}"
 cd $GRAFT_REPO_ROOT
@@ -10,10 +10,10 @@ cp gpurun_out/bench_kernel_trace.txt gpurun_out/${P}_bench_kernel_trace.txt; cp 
 tests/tools/pmc_traffic.sh > gpurun_out/${P}_pmc_traffic.log 2>&1
 cp gpurun_out/head_conv_pmc.json gpurun_out/${P}_head_conv_pmc.json
 PMC_PRODUCTION=1 tests/tools/pmc_head_conv.sh > gpurun_out/${P}_pmc_counters.log 2>&1
-python3 tests/tools/pmc_head_summary.py gpurun_out "bench.py --steps 2: the production launches, 256 frames per step, tower layers 1-3" > gpurun_out/${P}_head_conv_counters.json
+python3 tests/tools/pmc_head_summary.py gpurun_out "bench.py --steps 2: the production launches, 512 frames per step, tower layers 1-3" > gpurun_out/${P}_head_conv_counters.json
 rm -rf gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_tcc
-( echo "# phase clock of the tower kernel (variant 90: s_memtime stamps, wave 0) on the PRODUCTION shapes: 256 frames, N = 10, 512x512 -- $LABEL";
-  B=256 python3 tests/tools/bench_head_conv.py 0:1 90:1 0:2 90:2 0:3 90:3 0:0 2>&1 | grep "phase clock\|round 1" ) > gpurun_out/${P}_phase_clock.txt
+( echo "# phase clock of the tower kernel (variant 90: s_memtime stamps, wave 0) on the PRODUCTION shapes: 512 frames, N = 10, 512x512 -- $LABEL";
+  B=512 python3 tests/tools/bench_head_conv.py 0:1 90:1 0:2 90:2 0:3 90:3 0:0 2>&1 | grep "phase clock\|round 1" ) > gpurun_out/${P}_phase_clock.txt
 tests/tools/profile_train.sh "$LABEL" 512 512 3 101 > gpurun_out/${P}_profile_train.log 2>&1
 cp gpurun_out/train_kernel_trace.txt gpurun_out/${P}_train_step_kernel_trace.txt
 ls -la gpurun_out/${P}_*
