@@ -772,13 +772,24 @@ bod_status build_plan(bod_context* h) {
         BODCHK(ensure_raw(h));                 // the ops below reference the raw tensors directly
     }
     h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0;
+    // A layer's launch takes the sample-complete ("aggregated") tiling only for the heads that END there (fused 1x1 + MC aggregation): such
+    // a tile holds 25 pixels x 10 samples = 250 of its 256 rows (240 at N = 30), so every other head's conv of that layer -- the
+    // classification and covariance towers at layer 2 -- would pay 2.8 % (6 %) more MFMA work for nothing.  Round 4: those heads run the
+    // layer as their own launch on the plain tiling (part 0); the ending heads' launch (part 1) exists in the two flavours.
     for (int layer = 0; layer < 4; ++layer)
+    for (int part = 0; part < 2; ++part)
     for (int flav = (agg && layer >= 2) ? FLAVOUR_RAW : FLAVOUR_BOTH; flav <= ((agg && layer >= 2) ? FLAVOUR_AGG : FLAVOUR_BOTH); ++flav) {
-        Op op; op.kind = Op::CONV; op.is_head3x3 = true; op.flavour = flav;
+        static const bool split_on = [] { const char* e = getenv("BOD_SPLIT_AGG_LAUNCH"); return !e || atoi(e) != 0; }();     // (=0: one launch per layer on the aggregated tiling, A/B aid)
+        const bool split_launch = agg && layer >= 2 && split_on;       // part 0: heads that continue, part 1: heads that end at this layer
+        if (!split_launch && part == 1) continue;
+        if (split_launch && part == 0 && flav == FLAVOUR_AGG) continue;      // the continuing heads' launch is the same in both flavours: planned once
+        const bool both = split_launch && part == 0;
+        Op op; op.kind = Op::CONV; op.is_head3x3 = true; op.flavour = both ? FLAVOUR_BOTH : flav;
         int g = 0; PackedConv pc0{};
         double fused_flops = 0;
         for (int hd = 0; hd < nheads; ++hd) {
             if (layer >= kHeadConvs[hd]) continue;
+            if (split_launch && (part == 1) != (layer == kHeadConvs[hd] - 1)) continue;
             PackedConv pc;
             BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc));
             if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
@@ -807,6 +818,7 @@ bod_status build_plan(bod_context* h) {
             if (g == 0) pc0 = pc;
             ++g;
         }
+        if (g == 0) continue;                                // (no head of this part at this layer)
         const int M = layer == 0 ? B * h->P : B * N * h->P;
         ConvArgs a = base_args(pc0, layer == 0 ? d1 : d2, M, 256, 256);
         for (int q = 0; q < g; ++q) a.g[q] = op.conv.g[q];
@@ -818,12 +830,12 @@ bod_status build_plan(bod_context* h) {
         if (xreuse0 && layer == 0) { a.rows = d1x; a.M = m1x; a.ext = dext1; a.xreuse = 2; }
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;
-            if (agg && layer >= 2) { a.rows = d2a; a.M = m2a; a.ext = dexta; }       // sample-complete tiles (both flavours)
+            if (agg && layer >= 2 && !(split_launch && part == 0)) { a.rows = d2a; a.M = m2a; a.ext = dexta; }       // sample-complete tiles (both flavours)
             a.xreuse = 2;       // 32-bit activation offsets against the tile's first extended row: any buffer size
         }
         op.conv = a;
         op.flops = 2.0 * M * 256.0 * 2304.0 * g + fused_flops;
-        op.name = "head_tower_layer_" + std::to_string(layer) + (flav == FLAVOUR_AGG ? "(aggregating)" : flav == FLAVOUR_RAW ? "(raw)" : "");
+        op.name = "head_tower_layer_" + std::to_string(layer) + (both ? "" : flav == FLAVOUR_AGG ? "(aggregating)" : flav == FLAVOUR_RAW ? "(raw)" : "");
         op.same_geom = N == 1;            // pyramid [B][Ppad] and head planes [B*N][Ppad] coincide at N = 1
         h->ops.push_back(op);
     }
@@ -2244,13 +2256,13 @@ bod_status bod_loss_backward(int32_t device, int32_t B, int32_t A, int32_t C, co
 }
 
 bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters, double* mean_ms, double* flops) {
-    if (!h || !mean_ms || iters < 1 || layer < 0 || layer > 3) return BOD_ERR_INVALID_ARG;
+    if (!h || !mean_ms || iters < 1 || layer < 0 || layer > 7) return BOD_ERR_INVALID_ARG;
     BODCHK(join_overlap(h));
     if (!h->weights_ready) return h->fail(BOD_ERR_NOT_READY, "weights not finalized");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int seen = 0; Op* op = nullptr;
     for (Op& o : h->ops) if (o.is_head3x3 && o.flavour != FLAVOUR_RAW && seen++ == layer) { op = &o; break; }    // (layers 2, 3: the flavour bod_infer runs)
-    if (!op) return h->fail(BOD_ERR_INVALID_ARG, "no head layer %d", layer);
+    if (!op) return h->fail(BOD_ERR_INVALID_ARG, "no head launch %d", layer);
     ConvArgs a = op->conv;
     a.variant = variant;
     // BOD_BENCH_ZERO=1: time the identical launch on zero-filled activations (DVFS / power-limit probe: the matrix

@@ -693,6 +693,12 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         roofline["mfma_issue_tflops"] = round(3 * achieved, 2)
     if fan_out:
         roofline["other_head_launch"] = fan_out
+        # "the conv heads" as a whole: the de-duplicated 3 + 8 N head convs and the N 1x1 sets of a step = the three tower launches of
+        # the timed region + the fan-out launch (timed in the three extra steps above)
+        heads_ms = prof["head_conv_ms"] / prof_steps + fan_out["avg_launch_ms"]
+        heads_flops = (algo_flops / prof_steps + 3 * conv_flops * B) / 1e12
+        roofline["heads_total"] = {"achieved": round(heads_flops / (heads_ms * 1e-3), 2), "frac": round(heads_flops / (heads_ms * 1e-3) / peak, 4),
+                                   "ms_per_step": round(heads_ms, 3), "tflop_per_step": round(heads_flops, 2)}
     # BASELINE.md section 3, "reported beside it": the whole pipeline's de-duplicated conv FLOPs per image x images/sec
     # (backbone + FPN 49.05 GFLOP at 512x512, linear in the pixel count; heads 3 + 8 N convs + N 1x1 sets)
     img_gflop = image_gflop(hw, eng.P, n)

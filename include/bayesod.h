@@ -321,10 +321,11 @@ bod_status bod_loss_backward(int32_t device, int32_t B, int32_t A, int32_t C, co
                              const uint8_t* negative_mask, int32_t do_cls, int32_t reg_kind, float label_smoothing,
                              float w_cls, float w_reg, double* out4, float* dcls, float* dbox, float* dcov);
 
-/* Kernel micro-benchmark (tests/tools): re-launches the handle's layer-`layer` head-tower conv
- * (0 = de-duplicated fan-out layer, 1..3 = per-sample layers) `iters` times on the handle's own
- * buffers and returns the mean duration; `variant` selects an ablation build of the kernel
- * (0 = production). */
+/* Kernel micro-benchmark (tests/tools): re-launches the `layer`-th head-tower launch of a bod_infer step
+ * (0 = de-duplicated fan-out layer, 1 = tower layer 1; on plans with the fused MC aggregation 2 = layer 2 of the
+ * heads that continue, 3 = layer 2 of the head that ends there (aggregating), 4 = layer 3; otherwise 2, 3 = layers
+ * 2, 3) `iters` times on the handle's own buffers and returns the mean duration; `variant` selects an ablation
+ * build of the kernel (0 = production). */
 bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int32_t iters,
                                double* mean_ms, double* flops_per_launch);
 

@@ -20,11 +20,15 @@ def dispatches(path, counter):
             e["value"] += float(r["Counter_Value"])
     return [rows[k] for k in sorted(rows)]
 
+fused_agg = not (len(sys.argv) > 7 and sys.argv[7] == "raw")
+NHEAD = 5 if fused_agg else 4          # plans with the fused aggregation run tower layer 2 as two launches (round 4)
+
+
 def head_launches(ds):
     out = []
     for i, d in enumerate(ds):
         if d["name"].startswith("void post_sample_kernel"):
-            convs = [x for x in ds[:i] if "conv_igemm_kernel" in x["name"]][-4:]
+            convs = [x for x in ds[:i] if "conv_igemm_kernel" in x["name"]][-NHEAD:]
             out.append(convs)
     return out
 
@@ -39,17 +43,20 @@ act = lambda rows, heads: rows * 256 * 2 * heads
 wts = lambda heads: 9 * 256 * 256 * 2 * heads
 raw = {"cls": B * N * A * 8 * 4, "box": B * N * A * 4 * 4, "cov": B * N * A * 10 * 4}
 agg = {"cls": B * A * 8 * 4, "box": B * A * 16 * 4, "cov": B * A * 10 * 4}       # per-anchor MC statistics (fused aggregation)
-fused_agg = not (len(sys.argv) > 7 and sys.argv[7] == "raw")
 out = agg if fused_agg else raw
 tail = "fused 1x1 + MC aggregation -> per-anchor statistics" if fused_agg else "fused 1x1 -> fp32 [B,N,A,.] outputs"
 algo = [  # (label, read bytes, write bytes)
     ("head layer 0 (de-duplicated, %d-way dropout fan-out)" % N, act(B * P, 1) + wts(3), act(B * N * P, 3)),
     ("head layer 1", act(B * N * P, 3) + wts(3), act(B * N * P, 3)),
-    ("head layer 2 (regression tower ends: %s)" % tail, act(B * N * P, 3) + wts(3), act(B * N * P, 2) + out["box"]),
-    ("head layer 3 (cls + cov: %s)" % tail, act(B * N * P, 2) + wts(2), out["cls"] + out["cov"]),
 ]
+if fused_agg:
+    algo += [("head layer 2, classification + covariance towers (plain tiles)", act(B * N * P, 2) + wts(2), act(B * N * P, 2)),
+             ("head layer 2, regression tower ends: %s" % tail, act(B * N * P, 1) + wts(1), out["box"])]
+else:
+    algo += [("head layer 2 (regression tower ends: %s)" % tail, act(B * N * P, 3) + wts(3), act(B * N * P, 2) + out["box"])]
+algo += [("head layer 3 (cls + cov: %s)" % tail, act(B * N * P, 2) + wts(2), out["cls"] + out["cov"])]
 launches = []
-for k in range(4):
+for k in range(NHEAD):
     f = sum(hf[s][k]["value"] for s in range(steps)) / steps
     w = sum(hw[s][k]["value"] for s in range(steps)) / steps
     launches.append({"launch": algo[k][0], "kernel": hf[0][k]["name"][:80], "grid_threads": hf[0][k]["grid"],
@@ -63,5 +70,5 @@ print(json.dumps({
     "config": {"height": H, "width": W, "mc_samples": N, "batch": B},
     "correction": "FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide coalesced reads), WRITE_SIZE x 1024",
     "steps_averaged": steps, "launches": launches,
-    "hbm_bytes_per_step_head_convs": tot, "avg_hbm_bytes_per_launch": round(tot / 4),
+    "hbm_bytes_per_step_head_convs": tot, "avg_hbm_bytes_per_launch": round(tot / NHEAD),
     "algorithmic_bytes_per_step_head_convs": sum(a[1] + a[2] for a in algo)}, indent=1))

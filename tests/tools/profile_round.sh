@@ -13,7 +13,7 @@ PMC_PRODUCTION=1 tests/tools/pmc_head_conv.sh > gpurun_out/${P}_pmc_counters.log
 python3 tests/tools/pmc_head_summary.py gpurun_out "bench.py --steps 2: the production launches, 512 frames per step, tower layers 1-3" > gpurun_out/${P}_head_conv_counters.json
 rm -rf gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_tcc
 ( echo "# phase clock of the tower kernel (variant 90: s_memtime stamps, wave 0) on the PRODUCTION shapes: 512 frames, N = 10, 512x512 -- $LABEL";
-  B=512 python3 tests/tools/bench_head_conv.py 0:1 90:1 0:2 90:2 0:3 90:3 0:0 2>&1 | grep "phase clock\|round 1" ) > gpurun_out/${P}_phase_clock.txt
+  B=512 python3 tests/tools/bench_head_conv.py 0:1 90:1 0:2 90:2 0:3 90:3 0:4 90:4 0:0 2>&1 | grep "phase clock\|round 1" ) > gpurun_out/${P}_phase_clock.txt
 tests/tools/profile_train.sh "$LABEL" 512 512 3 101 > gpurun_out/${P}_profile_train.log 2>&1
 cp gpurun_out/train_kernel_trace.txt gpurun_out/${P}_train_step_kernel_trace.txt
 ls -la gpurun_out/${P}_*
