@@ -613,7 +613,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
 
     # ---- roofline of the dominant kernel (head 3x3 implicit-GEMM): the launches of the timed region itself
     # The dominant kernel is ONE kernel symbol -- conv_igemm_kernel<256,256,2,4,0,true>, the row-reuse loop that runs tower
-    # layers 1..3 (3 launches per step, 8 of the 11 de-duplicated head convs) -- so that its average launch duration here
+    # layers 1..3 (4 launches per step -- layer 2 is two, DESIGN.md 5.2 --, 8 of the 11 de-duplicated head convs) -- so that its average launch duration here
     # and in the rocprofv3 --kernel-trace summary under profiles/ are the same quantity.  The first tower layer (N-way
     # dropout fan-out, a different instantiation) is timed in three extra steps below and reported beside it.
     def more_steps(k):
@@ -693,7 +693,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         roofline["mfma_issue_tflops"] = round(3 * achieved, 2)
     if fan_out:
         roofline["other_head_launch"] = fan_out
-        # "the conv heads" as a whole: the de-duplicated 3 + 8 N head convs and the N 1x1 sets of a step = the three tower launches of
+        # "the conv heads" as a whole: the de-duplicated 3 + 8 N head convs and the N 1x1 sets of a step = the tower launches of
         # the timed region + the fan-out launch (timed in the three extra steps above)
         heads_ms = prof["head_conv_ms"] / prof_steps + fan_out["avg_launch_ms"]
         heads_flops = (algo_flops / prof_steps + 3 * conv_flops * B) / 1e12
