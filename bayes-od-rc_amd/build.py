@@ -101,12 +101,17 @@ def build(force=False, verbose=True):
     if force or _stale(LIB_PATH, objs):
         # guards on the object about to be linked: no spills in the production kernels, no hazard around the inline-asm MFMAs of
         # the tower loop (kernel_guard.py) -- a compiler bump that breaks either fails the build instead of shipping
-        kernel_guard = _load_guard()
-        regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
-        regs.update(kernel_guard.verify_aux(os.path.join(obj_dir, "aux_kernels.o")))
-        regs.update(kernel_guard.verify_pointwise(os.path.join(obj_dir, "conv_pointwise.o")))
-        if verbose:
-            print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
+        if os.environ.get("BOD_SKIP_KERNEL_GUARD") == "1":
+            # explicit opt-out (a toolchain without the llvm binary tools, an experiment): never silent
+            print("WARNING: BOD_SKIP_KERNEL_GUARD=1 -- linking libbayesod_hip.so WITHOUT the disassembly guards (spills, inline-asm MFMA "
+                  "hazard windows and hand-counted LDS waits are UNCHECKED)", file=sys.stderr, flush=True)
+        else:
+            kernel_guard = _load_guard()
+            regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
+            regs.update(kernel_guard.verify_aux(os.path.join(obj_dir, "aux_kernels.o")))
+            regs.update(kernel_guard.verify_pointwise(os.path.join(obj_dir, "conv_pointwise.o")))
+            if verbose:
+                print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd), flush=True)
