@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep (GPU): the forward plan's kernel choices against their alternatives, by batch and geometry.
-For B in {1, 3, 8, 32, 128, 256} x {512x512, 384x1248}: median-of-5 HIP-event time of the N=1 forward (backbone + FPN + one-sample heads:
+For B in {1, 3, 8, 32, 128, 256} x {512x512, 384x1248}: median-of-5 wall time (engine synchronised on both sides, several forwards per sample) of the N=1 forward (backbone + FPN + one-sample heads:
 the launches the streaming kernels -- sliding-window 3x3, pointwise 1x1, fused stem + pool -- compete for) under the default plan and
 with each of those kernels switched off (BOD_SLIDE3X3=0 / BOD_POINTWISE=0 / BOD_STEM_POOL_FUSED=0).  Every configuration runs in a child
 process (the switches are read once per process).  usage: planner_sweep.py [--json]   (tests/test_gpu_planner.py asserts on it)"""
@@ -12,7 +12,7 @@ SWITCHES = {"default": {}, "no_slide3x3": {"BOD_SLIDE3X3": "0"}, "no_pointwise":
 CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r)
-import numpy as np, torch
+import numpy as np
 from bayes_od_rc_amd import synthetic
 from bayes_od_rc_amd.engine import Engine, make_config
 hw, B, reps = (%d, %d), %d, %d
@@ -23,10 +23,9 @@ for _ in range(3): eng.forward(None)
 eng.synchronize()
 ts = []
 inner = max(1, min(20, 2048 // max(B, 1) // 8))
+import time
 for r in range(reps):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    eng.synchronize(); torch.cuda.synchronize()
-    import time
+    eng.synchronize()
     t0 = time.perf_counter()
     for _ in range(inner): eng.forward(None)
     eng.synchronize()
