@@ -1243,7 +1243,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         rng_seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng_seed_hi);
         // (row-reuse launches never fan out in this mode -- launch_conv_igemm refuses it: no sample loop there, so that nothing
         // loop-invariant is hoisted in front of the passes, where all 128 accumulators are live)
-        const int fan = XR ? 1 : ((drop && a.fan_count > 1) ? a.fan_count : 1);
+        const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
         const uint32_t thr_m1 = a.drop_threshold > 0 ? a.drop_threshold - 1u : 0u;
         const uint32_t thr_m1_x2 = thr_m1 | (thr_m1 << 16);
         uint16_t* out16 = reinterpret_cast<uint16_t*>(G.out);
@@ -2292,7 +2292,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     for (int g = 0; g < a.groups; ++g)
         if (a.g[g].w2 && !(big && a.cout_pad == 256)) return hipErrorInvalidValue;   // fusion needs the full-cout tile
     if (a.split) {                                   // bf16x3: fused 1x1 (+ aggregation) on the row-reuse loop only, no ablation builds, no fan-out on the row-reuse loop
-        if (a.variant != 0 || a.cin % 128 != 0 || (a.xreuse && (a.xreuse != 2 || a.fan_count > 1))) return hipErrorInvalidValue;
+        if (a.variant != 0 || a.cin % 128 != 0 || (a.xreuse && a.xreuse != 2)) return hipErrorInvalidValue;
+        for (int g = 0; g < a.groups; ++g) if (a.g[g].w2 && a.fan_count > 1) return hipErrorInvalidValue;    // fused groups never fan out
         for (int g = 0; g < a.groups; ++g) if (a.g[g].w2 && !a.xreuse) return hipErrorInvalidValue;   // the fused 1x1 lives in the row-reuse kernel's epilogue
     }
     // bottleneck chain (ConvGroup.ch_w2): one cout tile holding all couts, 128-pixel tiles, bf16, no split-K
