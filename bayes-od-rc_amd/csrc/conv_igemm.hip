@@ -2346,6 +2346,9 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         // it runs the loop and the register-resident fan-out epilogue), so that a kernel trace lists the per-sample tower
         // launches -- the roofline kernel of bench.py -- and the fan-out launch separately
         if (a.fan_count > 1) return launch_cfg<256, 256, 2, 4, 5, true>(a, s);
+        // ... and so are the plane -> plane 3x3 layers of the backbone / FPN that the engine plans on this loop (ABL = 6: the production
+        // code without dropout -- no in-loop Philox build)
+        if (a.plane_h > 0 && !(a.flags & CONV_DROPOUT) && a.variant == 0) return launch_cfg<256, 256, 2, 4, 6, true>(a, s);
         // BOD_TOWER_MIDBAR=0: the per-sample tower launches on the round-2 loop (barrier at the top of the K-tile, compiler-placed
         // LDS waits; ABL = 9) -- A/B aid, bit-identical results
         static const bool old_loop = getenv("BOD_TOWER_MIDBAR") && atoi(getenv("BOD_TOWER_MIDBAR")) == 0;

@@ -115,6 +115,8 @@ struct bod_context {
     bool raw_valid = false, agg_valid = false;           // which of the two the last forward produced
     uint64_t last_seed = 0; uint32_t last_first_image = 0;
     std::map<std::string, RowEnt*> tables;
+    struct XrTable { RowEnt* rows = nullptr; int2* ext = nullptr; int m = 0; };
+    std::map<std::string, XrTable> xr_tables;          // row-reuse tilings of plane -> plane 3x3 layers (add_conv)
     std::vector<Op> ops;
     const float* cur_images = nullptr;
 
@@ -375,6 +377,34 @@ bod_status add_conv(bod_context* h, const std::string& name, const std::string& 
         if (S > 1) {
             op.conv.ksplit = S;
             h->splitk_elems = std::max(h->splitk_elems, (size_t)S * op.conv.M * pc.cout_pad);
+        }
+    }
+    // Activation row reuse for the plane -> plane 3x3 stride-1 SAME convolutions of 256 -> 256 channels (stage 4's `2b` layers, P3-P5
+    // of the FPN): the tower kernel's loop -- every (chunk, ky) staged once, the three kx taps read the same rows -- on this layer's own
+    // tiles of x-adjacent runs (plan_tables.h).  Round 4, tests/tools/op_table.py: these launches ran the generic loop at 1 100-1 130
+    // TFLOP/s against the towers' 1 270.  BOD_PLANE_XREUSE=0: the generic launches (different fp32 summation order: not bit-identical).
+    static const bool plane_xr_on = [] { const char* e = getenv("BOD_PLANE_XREUSE"); return !e || atoi(e) != 0; }();
+    static const bool xr_on = [] { const char* e = getenv("BOD_CONV_XREUSE"); return !e || atoi(e) != 0; }();
+    if (plane_xr_on && xr_on && (h->es == 2 || h->split) && !h->cfg.training && op.conv.ksplit <= 1 && stride == 1 && same && pc.taps == 9 && pc.kw == 3 &&
+        pc.cin == 256 && pc.cout == 256 && pc.cout_pad == 256 && !res && !out_relu && in.h == out.h && in.w == out.w) {
+        ConvArgs probe = op.conv;
+        if (conv_igemm_uses_full_cout_tile(probe)) {
+            const std::string xkey = std::string(key) + ":xr";
+            auto it = h->xr_tables.find(xkey);
+            if (it == h->xr_tables.end()) {
+                std::vector<RowEnt> rows((size_t)op.conv.M), tiled;
+                std::vector<ExtRow> ext;
+                HIPCHK(h, hipMemcpy(rows.data(), tbl, rows.size() * sizeof(RowEnt), hipMemcpyDeviceToHost));
+                if (!xr_tile_rows(rows, tiled, ext)) return h->fail(BOD_ERR_INVALID_ARG, "row-reuse tiling of '%s': extended rows out of order", name.c_str());
+                bod_context::XrTable t;
+                t.m = (int)tiled.size();
+                BODCHK(h->dalloc(&t.rows, tiled.size(), false));
+                BODCHK(h->dalloc(&t.ext, ext.size(), false));
+                HIPCHK(h, hipMemcpy(t.rows, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice));
+                HIPCHK(h, hipMemcpy(t.ext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice));
+                it = h->xr_tables.emplace(xkey, t).first;
+            }
+            op.conv.rows = it->second.rows; op.conv.ext = it->second.ext; op.conv.M = it->second.m; op.conv.xreuse = 2;
         }
     }
     h->ops.push_back(op);
@@ -861,6 +891,30 @@ bod_status build_plan(bod_context* h) {
     h->first_head_op = (int)h->ops.size();
     for (size_t i = 0; i < h->ops.size(); ++i) if (h->ops[i].is_head3x3) { h->first_head_op = (int)i; break; }
     h->pyr_d[0] = h->pyramid.d;
+    // BOD_DUMP_OPS=1: the plan, one line per op on stderr, with the ALGORITHMIC bytes of the launch (input pixels read once, output and
+    // shortcut once, weights once) -- tests/tools/op_table.py joins it with a rocprofv3 kernel trace into a per-op roofline table
+    if (const char* e = getenv("BOD_DUMP_OPS")) if (atoi(e) != 0) {
+        fprintf(stderr, "# ops: index name kind flavour M taps cin cout groups fan has_res fused_next flops bytes\n");
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            const Op& o = h->ops[i];
+            const ConvArgs& a = o.conv;
+            double bytes = 0;
+            if (o.kind == Op::STEM)                    // fp32 frames in, pooled 64-channel plane out (the fused stem + pool kernel)
+                bytes = (double)B * c.image_h * c.image_w * 3 * 4 + (double)B * h->ph * h->pw * 64 * h->es;
+            if (o.kind == Op::CONV) {
+                const double es = (a.flags & CONV_OUT_F32) ? 4.0 : (double)h->es;
+                for (int g = 0; g < a.groups; ++g) {
+                    bytes += (double)a.M * a.cin * h->es;                                                    // input pixels (stride-2 3x3: ~4x that)
+                    bytes += (double)a.M * std::max(1, a.fan_count) * a.cout_valid * es;                     // output(s)
+                    if (a.g[g].res) bytes += (double)a.M * a.cout_valid * h->es;
+                    if (a.g[g].ch_w3) bytes += (double)a.M * 64 * h->es;
+                    bytes += (double)a.taps * a.cin * a.cout_pad * h->es;
+                }
+            }
+            fprintf(stderr, "# op %zu %s %d %d %d %d %d %d %d %d %d %d %.6g %.6g\n", i, o.name.c_str(), (int)o.kind, o.flavour, a.M, a.taps, a.cin,
+                    a.cout_valid, a.groups, a.fan_count, o.kind == Op::CONV && a.g[0].res ? 1 : 0, o.kind == Op::CONV && a.g[0].ch_w3 ? 1 : 0, o.flops, bytes);
+        }
+    }
     if (h->overlap_mode) BODCHK(h->dalloc(&h->pyr_d[1], (size_t)B * h->Ppad * 256 * h->es));      // zero borders like the first
     return BOD_OK;
 }
@@ -2397,6 +2451,7 @@ bod_status bod_plan_info(bod_handle h, int32_t* info8) {
     for (int i = 0; i < 8; ++i) info8[i] = 0;
     info8[0] = h->agg_plan; info8[1] = h->plan_fused_out; info8[2] = h->plan_xreuse; info8[3] = h->plan_xreuse0;
     info8[4] = (int32_t)h->ops.size();
+    for (const Op& o : h->ops) if (o.kind == Op::CONV && !o.is_head3x3 && o.conv.xreuse) ++info8[5];
     return BOD_OK;
 }
 

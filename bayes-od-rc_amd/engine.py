@@ -422,11 +422,12 @@ class Engine(object):
         return out
 
     def plan_info(self):
-        """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops'} of the forward plan (bod_plan_info)."""
+        """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops', 'plane_row_reuse_layers'} of the forward plan
+        (bod_plan_info)."""
         info = (C.c_int32 * 8)()
         self._chk(self.lib.bod_plan_info(self.h, info))
         return {"aggregating": bool(info[0]), "fused_head_outputs": bool(info[1]), "row_reuse": bool(info[2]),
-                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4])}
+                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4]), "plane_row_reuse_layers": int(info[5])}
 
     @property
     def aggregating(self):

@@ -41,6 +41,7 @@ def _llvm_bin_candidates():
 PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb0EE",     # head towers (row reuse)
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi5ELb1ELb0EE",     # first tower layer, N-way fan-out, on the row-reuse loop
+    "conv_igemm_kernelILi256ELi256ELi2ELi4ELi6ELb1ELb0EE",     # backbone / FPN 3x3 256 -> 256 layers on the row-reuse loop (no dropout build)
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb0ELb0EE",     # backbone / FPN, big tile
     "conv_igemm_kernelILi128ELi128ELi2ELi2ELi0ELb0ELb0EE",     # fan-out layer, small layers, split-K
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb0EE",
@@ -52,8 +53,8 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb1EE",     # bf16x3 on the row-reuse loop (fused 1x1 + MC aggregation)
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi9ELb1ELb0EE",     # head towers on the round-2 loop (top-of-K-tile barrier): A/B twin, BOD_TOWER_MIDBAR=0
 ]
-INLINE_ASM_MFMA = PRODUCTION[:2] + PRODUCTION[-1:]             # the kernels on the 16x16x32 inline-asm loop
-INLINE_ASM_LDS = PRODUCTION[:2]                                # ... whose fragment reads and lgkmcnt waits are hand-written too (mid-tile barrier)
+INLINE_ASM_MFMA = PRODUCTION[:3] + PRODUCTION[-1:]             # the kernels on the 16x16x32 inline-asm loop
+INLINE_ASM_LDS = PRODUCTION[:3]                                # ... whose fragment reads and lgkmcnt waits are hand-written too (mid-tile barrier)
 
 
 class GuardError(RuntimeError):

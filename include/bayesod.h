@@ -366,7 +366,8 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
 /* What the handle's plan looks like (tests / bench report it; nothing on the hot path reads it).  info8[0] = 1 when the MC
  * statistics are reduced inside the last tower layers' tiles (no [B,N,A,.] tensors on the bod_infer path), [1] = 1 when the 1x1
  * head output convs are fused into the last tower layers' epilogues, [2] = 1 when the per-sample tower layers run on the
- * activation-row-reuse kernel, [3] = 1 when the fan-out layer does, [4] = number of ops of the forward plan, [5..7] = 0. */
+ * activation-row-reuse kernel, [3] = 1 when the fan-out layer does, [4] = number of ops of the forward plan, [5] = number of
+ * backbone / FPN 3x3 layers planned on the row-reuse kernel, [6..7] = 0. */
 bod_status bod_plan_info(bod_handle h, int32_t* info8);
 
 #ifdef __cplusplus

@@ -452,6 +452,56 @@ def test_pointwise_kernel_is_bit_identical():
         assert np.isfinite(outs[0][k]).all(), k
 
 
+def test_plane_row_reuse_layers_are_bit_identical():
+    """Round 4: the plane -> plane 3x3 stride-1 layers of 256 -> 256 channels (stage 4's `2b`, P3-P5) run on the tower kernel's
+    row-reuse loop once their launch fills the chip with 256x256 tiles (engine.hip add_conv; BOD_PLANE_XREUSE=0: the generic loop).
+    Row reuse changes how activations reach LDS, not the order of the products per accumulator: every pyramid level must not differ
+    by one bit -- widths that do and do not fill a tile's runs, ragged last tiles, ResNet-101's 23 stage-4 blocks; one shape at its
+    natural tile size (P3 of 24 frames of 512x512 = 384 tiles) without BOD_FORCE_CONV_TILE.  The plan must really differ
+    (plan_info()['plane_row_reuse_layers'])."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys, os; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "shapes = (('n', (512, 512), 24, 50),) if os.environ.get('BOD_FORCE_CONV_TILE') is None else "
+            "(('a', (128, 128), 3, 50), ('b', (96, 160), 1, 50), ('c', (192, 624), 2, 50), ('d', (128, 128), 2, 101), ('e', (256, 256), 9, 50))\n"
+            "for tag, hw, b, depth in shapes:\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=2, backbone_depth=depth))\n"
+            "    eng.load_weights(synthetic.make_weights(depth=depth))\n"
+            "    out['%%s_layers' %% tag] = np.array([eng.plan_info()['plane_row_reuse_layers']])\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=3), seed=11, first_image_id=2)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    for forced in ("256", None):
+        outs = []
+        for on in ("1", "0"):
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "o.npz")
+                env = dict(os.environ, BOD_PLANE_XREUSE=on, BOD_CONV_SPLITK="0")
+                env.pop("BOD_FORCE_CONV_TILE", None)
+                if forced:
+                    env["BOD_FORCE_CONV_TILE"] = forced
+                r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+                assert r.returncode == 0, r.stderr[-3000:]
+                z = np.load(path)
+                outs.append({k: z[k] for k in z.files})
+        assert set(outs[0]) == set(outs[1]) and len(outs[0]) == (30 if forced else 6)
+        for k in sorted(outs[0]):
+            if k.endswith("_layers"):
+                # forced tiles: 6 (23 for ResNet-101) stage-4 `2b` layers + P3, P4, P5; natural size at 24 frames: P3 only
+                want = (26 if k.startswith("d") else 9) if forced else 1
+                assert int(outs[0][k][0]) == want and int(outs[1][k][0]) == 0, (k, outs[0][k], outs[1][k])
+                continue
+            assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k
+            assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k]).max()))
+
+
 def test_sliding_window_3x3_kernel_is_bit_identical():
     """ResNet stage 2's 3x3 layers (64 -> 64 channels) run on the sliding-window kernel (conv_pointwise.hip: a workgroup walks
     down a 64-pixel column strip, three input rows in an LDS ring, every input pixel staged once; same MFMA shape, k order and
