@@ -377,7 +377,11 @@ __device__ __forceinline__ uint32_t sf_max(uint32_t a, uint32_t b) {
     return r;
 }
 
-__global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __restrict__ img, const float* __restrict__ w,
+// NCH = 1: four waves, each a 64-pixel quarter of the row x all 64 couts (176 weight registers, one wave per SIMD).  NCH = 2 (round 4):
+// eight waves = pixel quarter x cout half -- 88 weight registers, TWO waves per SIMD, so one wave's LDS round trips, conversions and
+// barriers hide behind the other's MFMAs; every B fragment is read by two waves.  Same MFMAs in the same order per accumulator.
+template <int NCH>
+__global__ __launch_bounds__(256 * NCH, 1) void stem_pool_fused_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, uint16_t* __restrict__ pooled,
                                                                  int B, int H, int W, int oh, int ow, int ph, int pw, int pool_pitch,
                                                                  int pool_plane) {
@@ -385,18 +389,20 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
     uint16_t* const ring = sf_smem;                                     // slot s, plane h: ring + (s * 2 + h) * SR_ROWE
     char* const tile = reinterpret_cast<char*>(sf_smem + SF_RING * 2 * SR_ROWE);      // [256 px][128 B], 16-byte chunks swizzled by the pixel
     uint16_t (*wl)[SB_WROW] = reinterpret_cast<uint16_t (*)[SB_WROW]>(tile);          // the weight table lives in the tile until the loop starts
+    constexpr int THREADS = 256 * NCH, FW = 4 / NCH;                    // cout fragments of 16 per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxq = wave & 3, chh = wave >> 2;                          // pixel quarter, cout half
     const int li = lane & 15, lq = lane >> 4;
-    for (int i = tid; i < 64 * SB_WROW; i += 256) {
+    for (int i = tid; i < 64 * SB_WROW; i += THREADS) {
         const int co = i / SB_WROW, kp = i % SB_WROW;
         const int c = kp >> 3, t = kp & 7, ky = c / 3, j = (c % 3) * 8 + t;
         wl[co][kp] = (c < 21 && j < 21) ? (uint16_t)f32_to_bf16_a(w[(ky * 21 + j) * 64 + co]) : (uint16_t)0;
     }
-    float bv[4][4];
+    float bv[FW][4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < FW; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[f][r] = bias[f * 16 + lq * 4 + r];
+        for (int r = 0; r < 4; ++r) bv[f][r] = bias[(chh * FW + f) * 16 + lq * 4 + r];
     constexpr int ROWQ = SR_ROWF / 4;                                   // 389 quads per input row
     auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
     const int valid = W * 3;
@@ -417,30 +423,31 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
     };
     // ---- prologue: input rows 0 .. 6, the weights into registers
     for (int ir = 0; ir < 7; ++ir)
-        for (int q = tid; q < ROWQ; q += 256) commit_quad(ir, q, fetch_quad(ir, q));
+        for (int q = tid; q < ROWQ; q += THREADS) commit_quad(ir, q, fetch_quad(ir, q));
     __syncthreads();
     const int role = lq >> 1, k1 = lq & 1;                              // this lane's B source: plane, chunk parity
-    stem_bf16x8_t aqr[11][4];
+    stem_bf16x8_t aqr[11][FW];
 #pragma unroll
     for (int s = 0; s < 11; ++s)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) aqr[s][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wl[f * 16 + li][(2 * s + k1) * 8]);
+        for (int f = 0; f < FW; ++f) aqr[s][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wl[(chh * FW + f) * 16 + li][(2 * s + k1) * 8]);
     __syncthreads();                                                    // the table's LDS becomes the pooling tile
-    uint2 vm[4][4];                                                     // running maximum of the open pooling window: [cout frag][pixel frag]
+    uint2 vm[FW][4];                                                    // running maximum of the open pooling window: [cout frag][pixel frag]
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < FW; ++f)
 #pragma unroll
         for (int p = 0; p < 4; ++p) vm[f][p] = make_uint2(0u, 0u);
     uint16_t* const obase = pooled + (size_t)blockIdx.x * pool_plane * 64;
 
     for (int r = 0; r < oh; ++r) {
         // the two input rows the NEXT stem row adds (2r+7, 2r+8): four quads per thread, in flight during this row's MFMAs
-        float4 st[4];
+        constexpr int NQ = 1024 / THREADS;
+        float4 st[NQ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int q = i * 256 + tid; st[i] = fetch_quad(2 * r + 7 + (q >= 512), q & 511); }
-        f32x4_t acc[4][4];
+        for (int i = 0; i < NQ; ++i) { const int q = i * THREADS + tid; st[i] = fetch_quad(2 * r + 7 + (q >= 512), q & 511); }
+        f32x4_t acc[FW][4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < FW; ++f)
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[f][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
             const int c = 2 * s + k1;
             const int cc = c < 21 ? c : 20;                             // chunk 21 has zero weights: any finite data will do
             const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
-            const uint16_t* pb = ring + ((((2 * r + ky) & (SF_RING - 1)) * 2) + role) * SR_ROWE + (wave * 64 + li) * 6 + j0;
+            const uint16_t* pb = ring + ((((2 * r + ky) & (SF_RING - 1)) * 2) + role) * SR_ROWE + (pxq * 64 + li) * 6 + j0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 union { uint32_t u[4]; stem_bf16x8_t v; } bq;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
 #pragma unroll
                 for (int t = 0; t < 4; ++t) bq.u[t] = src[t];
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqr[s][f], bq.v, acc[f][p], 0, 0, 0);
+                for (int f = 0; f < FW; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqr[s][f], bq.v, acc[f][p], 0, 0, 0);
             }
         }
         // this stem row joins the open pooling window (rows 2p-1, 2p, 2p+1): bias + ReLU + pack exactly like the stem kernels, then a
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < FW; ++f) {
                 const uint32_t x = pk(fmaxf(acc[f][p][0] + bv[f][0], 0.f), fmaxf(acc[f][p][1] + bv[f][1], 0.f));
                 const uint32_t y = pk(fmaxf(acc[f][p][2] + bv[f][2], 0.f), fmaxf(acc[f][p][3] + bv[f][3], 0.f));
                 vm[f][p].x = sf_max(vm[f][p].x, x); vm[f][p].y = sf_max(vm[f][p].y, y);
@@ -475,15 +482,15 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
             const int prow = r >> 1;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int px = wave * 64 + p * 16 + li;
+                const int px = pxq * 64 + p * 16 + li;
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    *reinterpret_cast<uint2*>(tile + px * 128 + (((f * 2 + (lq >> 1)) ^ (px & 7)) << 4) + (lq & 1) * 8) = vm[f][p];
+                for (int f = 0; f < FW; ++f)
+                    *reinterpret_cast<uint2*>(tile + px * 128 + ((((chh * FW + f) * 2 + (lq >> 1)) ^ (px & 7)) << 4) + (lq & 1) * 8) = vm[f][p];
             }
             __syncthreads();
             if (prow < ph) {
                 // horizontal window: pooled column q = max over stem columns 2q-2, 2q-1, 2q (those inside the row)
-                for (int i = tid; i < pw * 8; i += 256) {
+                for (int i = tid; i < pw * 8; i += THREADS) {
                     const int q = i >> 3, ch = i & 7;
                     uint4 m = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -500,12 +507,12 @@ __global__ __launch_bounds__(256, 1) void stem_pool_fused_kernel(const float* __
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) vm[f][p] = make_uint2(__float_as_uint(acc[f][p][0]), __float_as_uint(acc[f][p][1]));
+                for (int f = 0; f < FW; ++f) vm[f][p] = make_uint2(__float_as_uint(acc[f][p][0]), __float_as_uint(acc[f][p][1]));
         }
         __syncthreads();                                                // every wave is done with input rows 2r, 2r+1 (and the tile)
         if (r + 1 < oh) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int q = i * 256 + tid; commit_quad(2 * r + 7 + (q >= 512), q & 511, st[i]); }
+            for (int i = 0; i < NQ; ++i) { const int q = i * THREADS + tid; commit_quad(2 * r + 7 + (q >= 512), q & 511, st[i]); }
         }
         __syncthreads();
     }
@@ -516,12 +523,19 @@ hipError_t launch_stem_pool_fused(const float* img, const float* w, const float*
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(stem_pool_fused_kernel, dim3(B), dim3(256), SF_LDS_BYTES, s, img, w, bias, reinterpret_cast<uint16_t*>(pooled), B, H, W, oh, ow,
-                       ph, pw, pool_pitch, pool_plane);
+    // BOD_STEM_WAVES=4: the four-wave form (round 3), A/B aid -- bit-identical pooled plane
+    static const bool eight = [] { const char* e = getenv("BOD_STEM_WAVES"); return !e || atoi(e) != 4; }();
+    if (eight)
+        hipLaunchKernelGGL(stem_pool_fused_kernel<2>, dim3(B), dim3(512), SF_LDS_BYTES, s, img, w, bias, reinterpret_cast<uint16_t*>(pooled), B, H, W, oh, ow,
+                           ph, pw, pool_pitch, pool_plane);
+    else
+        hipLaunchKernelGGL(stem_pool_fused_kernel<1>, dim3(B), dim3(256), SF_LDS_BYTES, s, img, w, bias, reinterpret_cast<uint16_t*>(pooled), B, H, W, oh, ow,
+                           ph, pw, pool_pitch, pool_plane);
     return hipGetLastError();
 }
 // the fused kernel's shapes: one 256-pixel segment per stem row, 16-byte aligned rows, enough images to fill the chip's CUs

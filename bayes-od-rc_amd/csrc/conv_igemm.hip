@@ -2052,8 +2052,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1)) void conv_igemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int bx = blockIdx.x, gz = blockIdx.z;
-    {
+    int bx = blockIdx.x, by = blockIdx.y, gz = blockIdx.z;
+    const int ny_tiles = a.cout_pad / BC;
+    if (!XR && gridDim.y == 1 && ny_tiles > 1) {
+        // Several cout tiles per pixel tile, launched as ONE grid row with the cout tile as the fast index INSIDE an XCD (round 4): the
+        // ny workgroups of a pixel tile run side by side on one XCD and read its activation rows from HBM once, through that L2.  The
+        // (nx, ny) grid ran a whole plane of pixel tiles per cout tile: stage 5's 512 -> 2048 expansions re-read their input eight
+        // times (tests/tools/op_table.py: 2.2 TB/s algorithmic at 540 us for 263 us of bytes).  Workgroup b: XCD b % 8, slot b / 8 ->
+        // cout tile slot % ny, the XCD's (slot / ny)-th pixel tile; XCDs with one pixel tile less retire their last ny slots at once.
+        const int nx = (a.M + BP - 1) / BP, q = nx >> 3, r = nx & 7, xcd = bx & 7, slot = bx >> 3;
+        const int pj = slot / ny_tiles;
+        by = slot - pj * ny_tiles;
+        if (pj >= q + (xcd < r ? 1 : 0)) return;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pj;
+    } else {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -2074,7 +2086,7 @@ __global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1))
             while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
         }
     }
-    conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, gz, bx, blockIdx.y, smem);
+    conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, gz, bx, by, smem);
 }
 
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
@@ -2133,6 +2145,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     }
     dim3 grid(nx, ny, a.groups * (a.ksplit > 1 ? a.ksplit : 1));
     if (ABL == 5 && a.groups > 1 && a.ksplit <= 1) grid = dim3(nx * a.groups, ny, 1);      // shared-input groups, interleaved (see the kernel)
+    // cout tile as the fast index inside an XCD (see the kernel).  BOD_COUT_INNER=0: the (nx, ny) grid, A/B aid -- same tiles, same results
+    static const bool cout_inner = [] { const char* e = getenv("BOD_COUT_INNER"); return !e || atoi(e) != 0; }();
+    if (cout_inner && !XR && ny > 1) grid = dim3(8 * ((nx >> 3) + ((nx & 7) ? 1 : 0)) * ny, 1, grid.z);
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::LDS, s, a);
     return hipGetLastError();
 }
