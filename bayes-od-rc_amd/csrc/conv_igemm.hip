@@ -6,7 +6,7 @@
 //
 // Orientation: D[cout][pixel] = W[cout][k] * X[pixel][k].  Weights are the MFMA "A" operand and
 // pixels the "B" operand, so a lane's accumulator registers hold 4 CONSECUTIVE output channels of
-// one pixel; one Philox4x32 call yields the 8 dropout decisions of two such groups (contract v2).
+// one pixel; one Philox4x32 call yields the 16 dropout decisions of four such groups (contract v3, philox.h).
 //
 // Both operands are K-contiguous (OHWI weights, NHWC activations), staged global->LDS with
 // 16-byte LDS-DMA (global_load_lds_dwordx4) into 128-byte rows, double-buffered, one barrier per
@@ -552,6 +552,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // k-steps, every ds_read_b128 is issued >= 4 MFMAs before its first use, and the only exposed LDS
         // wait is the first fragment set after each block barrier (covered by issuing the LDS-DMA there).
         static_assert(BC == 256 && BP == 256 && WC == 2 && WP == 4, "written for the 256x256 8-wave tile");
+        static_assert(M16 || !(!SPLIT && FP == 2 && ABL != 81), "decisions are drawn in the loop by the 16x16x32 builds only");
         constexpr int WST = BC * ROWB, XBUF = XR_EXT_ROWS * ROWB, NXE = XR_EXT_ROWS * 8 / THREADS;   // 5 pieces / thread
         // 32-bit offsets are taken against the tile's FIRST extended row (the smallest pixel index of the tile: the
         // host builds the list in increasing order and pads it with that row), so the activation buffer may be of any size
@@ -613,23 +614,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         const bool ph_on = PH_BUILD && (a.flags & CONV_DROPOUT) && !(a.flags & CONV_OUT_F32) && a.fan_count <= 1 && NG >= 8 && bc0 == 0 &&
                            a.drop_threshold >= 1 && a.variant != 83;            // (variant 83: decisions drawn in the epilogue, A/B)
         ph_inloop = ph_on;
-        int2 prg[2] = {make_int2(0, 0), make_int2(0, 0)};
-        uint32_t ph_k0 = a.seed_lo, ph_k1 = a.seed_hi, ph_img = a.image_base, ph_byte_a = 0u;
+        uint32_t ph_k0 = a.seed_lo, ph_k1 = a.seed_hi, ph_img = a.image_base;
         PhiloxState ph{0u, 0u, 0u, 0u, 0u, 0u};
         if (ph_on) {
             if (a.dyn_rng) { ph_k0 = a.dyn_rng[0]; ph_k1 = a.dyn_rng[1]; ph_img = a.dyn_rng[2]; }
-            if (!M16) {
-                prg[0] = s_rng[wp * WTP + frow];                             // (written before the barrier above)
-                prg[1] = s_rng[wp * WTP + 32 + frow];
-            }
         }
         const uint32_t ph_thr = a.drop_threshold;
-        auto ph_compress = [&]() -> uint32_t {                               // 8 keep bits: (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi, w.lo, w.hi)
-            const uint32_t w[4] = {ph.c0, ph.c1, ph.c2, ph.c3};
+        auto ph_compress = [&]() -> uint32_t {                               // 16 keep bits: bit 4u + r = channel r of run u (contract v3)
+            const Philox4 rr{ph.c0, ph.c1, ph.c2, ph.c3};
             uint32_t b = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                b |= (((w[k] & 0xFFFFu) >= ph_thr) ? 1u : 0u) << (2 * k) | (((w[k] >> 16) >= ph_thr) ? 1u : 0u) << (2 * k + 1);
+            for (int u = 0; u < 4; ++u) {
+                const DropPair w = dropout_run_windows(rr, u);
+                b |= (((w.x & 0xFFFFu) >= ph_thr) ? 1u : 0u) << (4 * u) | (((w.x >> 16) >= ph_thr) ? 1u : 0u) << (4 * u + 1) |
+                     (((w.y & 0xFFFFu) >= ph_thr) ? 1u : 0u) << (4 * u + 2) | (((w.y >> 16) >= ph_thr) ? 1u : 0u) << (4 * u + 3);
+            }
             return b;
         };
         // ------------------------------------------------------------------------------------------------------------------
@@ -719,25 +718,27 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const bool next_row = ky + 1 < 3;
                 const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
                 const bool ph_act = ph_on && g < 8;
+                // group g < 8 draws ONE call in slots 0..9 (contract v3: 16 decisions per call): pixel fragment fp = g >> 1, cout fragment
+                // pair tt = (g & 1) * 2 + (q4 >> 1) -- the lane pair (l, l ^ 32) shares the calls of a fragment pair's two halves: the lower
+                // lane half draws the even pairs, the upper half the odd ones, and they swap their 128 keep bits after the loop
                 auto ph_slot = [&](int sidx) {
-                    if (!PH_BUILD || !ph_act || sidx > 19) return;
-                    if (sidx == 0 || sidx == 9) {
-                        if (sidx == 9) { philox_rounds(ph, 1); ph_byte_a = ph_compress(); }
+                    if (!PH_BUILD || !ph_act || sidx > 9) return;
+                    if (sidx == 0) {
                         long long rr;
                         const uint32_t ra = (uint32_t)(uintptr_t)LDS_PTR(&s_rng[wp * WTP + (g >> 1) * 16 + l15]);
                         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(ra) : "memory");
-                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);
+                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (q4 >> 1)) * 2 + (q4 & 1));     // dropout_group16(wc*128 + tt*32 + (q4&1)*4)
                         ph.c0 = (uint32_t)rr;
                         const uint32_t ry = (uint32_t)((unsigned long long)rr >> 32);
                         ph.c2 = (ph_sbase + (ry & 0xFFFFu)) | ph_lid16;
                         ph.c3 = ph_img + (ry >> 16);
                         ph.k0 = ph_k0; ph.k1 = ph_k1;
-                        if (sidx == 0) philox_rounds(ph, 1);
+                        philox_rounds(ph, 1);
                         return;
                     }
                     philox_rounds(ph, 1);
-                    if (sidx == 19) {
-                        const uint32_t n16 = (ph_byte_a << 8) | ph_compress();
+                    if (sidx == 9) {
+                        const uint32_t n16 = ph_compress();
                         ph_bits[3] = (ph_bits[3] << 16) | (ph_bits[2] >> 16);
                         ph_bits[2] = (ph_bits[2] << 16) | (ph_bits[1] >> 16);
                         ph_bits[1] = (ph_bits[1] << 16) | (ph_bits[0] >> 16);
@@ -825,38 +826,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             const bool xnext = g + 1 < NG;
             const bool next_row = ky + 1 < 3;
             const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
-            // group g < 8 draws calls q = 2g (slots 0..9) and 2g + 1 (slots 9..19): (j, i, p) = (g >> 2, g & 3, c)
+            // group g < 8 draws one call in slots 0..9 (see the mid-tile-barrier loop above)
             const bool ph_act = ph_on && g < 8;
             auto ph_slot = [&](int sidx) {
-                if (!PH_BUILD || !ph_act || sidx > 19) return;
-                if (sidx == 0 || sidx == 9) {
-                    if (sidx == 9) { philox_rounds(ph, 1); ph_byte_a = ph_compress(); }
-                    int2 r;
+                if (!PH_BUILD || !ph_act || sidx > 9) return;
+                if (sidx == 0) {
+                    int2 r = make_int2(0, 0);
                     if constexpr (M16) {
-                        // 16x16 accumulator layout: call index 2g + c = fp*4 + t decides the 8 channels {16(2t)+4(q4&1).., +8..} of pixel
-                        // fragment fp; the lane pair (l, l^32) needs both calls of t's two cout fragments: the lower half draws the one
-                        // of fragment 2t, the upper half that of 2t+1, and they swap bytes after the loop (same counters as ever)
                         // read by hand: the compiler puts an s_waitcnt vmcnt(0) in front of a plain LDS load that follows an LDS-DMA issue
-                        // (it cannot tell the table from the staging buffers) -- a full L2 round trip with the matrix pipe idle, twice per group
+                        // (it cannot tell the table from the staging buffers) -- a full L2 round trip with the matrix pipe idle
                         long long rr;
                         const uint32_t ra = (uint32_t)(uintptr_t)LDS_PTR(&s_rng[wp * WTP + (g >> 1) * 16 + l15]);
                         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(ra) : "memory");
                         r.x = (int)(uint32_t)rr; r.y = (int)(uint32_t)((unsigned long long)rr >> 32);
-                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (sidx == 9 ? 1 : 0)) * 4 + q4);    // dropout_group8(wc*128 + (2t + (q4>>1))*16 + (q4&1)*4)
-                    } else {
-                        r = (g >> 2) ? prg[1] : prg[0];
-                        ph.c1 = (uint32_t)((wc * 4 + (g & 3)) * 4 + (sidx == 9 ? 2 : 0) + fhalf);   // dropout_group8(col), bc0 = 0
+                        ph.c1 = (uint32_t)((wc * 4 + (g & 1) * 2 + (q4 >> 1)) * 2 + (q4 & 1));     // dropout_group16(wc*128 + tt*32 + (q4&1)*4)
                     }
                     ph.c0 = (uint32_t)r.x;
                     ph.c2 = (a.sample_base + ((uint32_t)r.y & 0xFFFFu)) | ((uint32_t)G.layer_id << 16);
                     ph.c3 = ph_img + ((uint32_t)r.y >> 16);
                     ph.k0 = ph_k0; ph.k1 = ph_k1;
-                    if (sidx == 0) philox_rounds(ph, 1);
+                    philox_rounds(ph, 1);
                     return;
                 }
                 philox_rounds(ph, 1);
-                if (sidx == 19) {
-                    const uint32_t n16 = (ph_byte_a << 8) | ph_compress();
+                if (sidx == 9) {
+                    const uint32_t n16 = ph_compress();
                     ph_bits[3] = (ph_bits[3] << 16) | (ph_bits[2] >> 16);
                     ph_bits[2] = (ph_bits[2] << 16) | (ph_bits[1] >> 16);
                     ph_bits[1] = (ph_bits[1] << 16) | (ph_bits[0] >> 16);
@@ -1292,12 +1286,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]);
                         lo.x = pack_bf16x2(v[0] - bf16_to_f32(hi.x & 0xFFFFu), v[1] - bf16_to_f32(hi.x >> 16));
                         lo.y = pack_bf16x2(v[2] - bf16_to_f32(hi.y & 0xFFFFu), v[3] - bf16_to_f32(hi.y >> 16));
-                        if (drop) {                       // dropout contract v2, as in the bf16 epilogue below
-                            if ((g4 & 1) == 0)
-                                rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img,
+                        if (drop) {                       // dropout contract v3, as in the bf16 epilogue below: the fragment's four runs share one call
+                            if (g4 == 0)
+                                rr = philox4x32_10((uint32_t)rg.x, dropout_group16(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img,
                                                    rng_seed_lo, rng_seed_hi);
-                            const uint32_t m0 = keep_mask_u16x2((g4 & 1) ? rr.z : rr.x, thr_m1_x2);
-                            const uint32_t m1 = keep_mask_u16x2((g4 & 1) ? rr.w : rr.y, thr_m1_x2);
+                            const DropPair dw = dropout_run_windows(rr, g4);
+                            const uint32_t m0 = keep_mask_u16x2(dw.x, thr_m1_x2);
+                            const uint32_t m1 = keep_mask_u16x2(dw.y, thr_m1_x2);
                             hi.x &= m0; lo.x &= m0; hi.y &= m1; lo.y &= m1;
                         }
                         const int ch = slot >> 3;
@@ -1589,8 +1584,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     if (fan > 1 && !fuse && !(CAN_RES && G.out_relu) && (ABL == 0 || ABL == 5)) {
         // ---- N-way dropout fan-out (first tower layer: one convolution, N masked copies).  The unmasked tile goes
         // through LDS ONCE; each thread then keeps (pixel, 16-channel group) items in registers and, per sample, draws
-        // the group's two Philox calls (contract v2: a call decides channels {x..x+3, x+8..x+11}), masks and stores
-        // 2 x 16 bytes -- no LDS traffic and no barrier inside the sample loop.
+        // ONE Philox call (contract v3: a call decides the runs {x..x+3, x+8.., x+16.., x+24..} of a 32-channel block, i.e. half of
+        // this item and half of its neighbour's -- the neighbour draws the other call and they trade mask halves through DPP),
+        // masks and stores 2 x 16 bytes -- no LDS traffic and no barrier inside the sample loop.
         if constexpr (M16) {
 #pragma unroll
             for (int fp = 0; fp < FP16; ++fp) {
@@ -1639,7 +1635,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             const int2 r = s_rng[pixl];
             const uint32_t img = rng_image_base + ((uint32_t)r.y >> 16);
             const int c0 = bc0 + gq * 16;
-            const uint32_t ga = dropout_group8(c0), gb = dropout_group8(c0 + 4);
+            // the 32-channel block of items gq & ~1, gq | 1 has two calls: bit 2 of the channel = 0 (runs at +0, +8, +16, +24) and = 1 (+4,
+            // +12, +20, +28).  The even item's lane draws the first, the odd item's lane (lane ^ 2: same pixel) the second; an item needs
+            // runs u0 = (gq & 1) * 2, u0 + 1 of BOTH calls.
+            const bool gq_odd = (gq & 1) != 0;
+            const uint32_t gmine = dropout_group16(c0 & ~31) + (gq_odd ? 1u : 0u);
             uint16_t* const obase = reinterpret_cast<uint16_t*>(G.out) + bc0 + odd * 8;
             uint16_t* oe = obase + (size_t)(off_e < 0 ? 0 : off_e) * a.out_cstride + (it_e % GPR) * 16;
             uint16_t* oo = obase + (size_t)(off_o < 0 ? 0 : off_o) * a.out_cstride + (it_o % GPR) * 16;
@@ -1647,10 +1647,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll 1
             for (int n = 0; n < fan; ++n) {
                 const uint32_t key = (a.sample_base + (uint32_t)n) | ((uint32_t)G.layer_id << 16);
-                const Philox4 p0 = philox4x32_10((uint32_t)r.x, ga, key, img, rng_seed_lo, rng_seed_hi);
-                const Philox4 p1 = philox4x32_10((uint32_t)r.x, gb, key, img, rng_seed_lo, rng_seed_hi);
-                const uint4 oa = make_uint4(va.x & keep2(p0.x), va.y & keep2(p0.y), va.z & keep2(p1.x), va.w & keep2(p1.y));
-                const uint4 ob = make_uint4(vb.x & keep2(p0.z), vb.y & keep2(p0.w), vb.z & keep2(p1.z), vb.w & keep2(p1.w));
+                const Philox4 pm = philox4x32_10((uint32_t)r.x, gmine, key, img, rng_seed_lo, rng_seed_hi);
+                // masks of my call's four runs; runs u0, u0+1 are mine, the other two the neighbour item's
+                const DropPair w0 = dropout_run_windows(pm, 0), w1 = dropout_run_windows(pm, 1), w2 = dropout_run_windows(pm, 2), w3 = dropout_run_windows(pm, 3);
+                const uint32_t k0x = keep2(w0.x), k0y = keep2(w0.y), k1x = keep2(w1.x), k1y = keep2(w1.y);
+                const uint32_t k2x = keep2(w2.x), k2y = keep2(w2.y), k3x = keep2(w3.x), k3y = keep2(w3.y);
+                const uint32_t mine0x = gq_odd ? k2x : k0x, mine0y = gq_odd ? k2y : k0y, mine1x = gq_odd ? k3x : k1x, mine1y = gq_odd ? k3y : k1y;
+                uint32_t got0x = gq_odd ? k0x : k2x, got0y = gq_odd ? k0y : k2y, got1x = gq_odd ? k1x : k3x, got1y = gq_odd ? k1y : k3y;    // (what I give)
+#if defined(__HIP_DEVICE_COMPILE__)
+                // quad_perm [2,3,0,1]: the value of lane ^ 2 (executed by all lanes, outside any branch)
+                got0x = (uint32_t)__builtin_amdgcn_mov_dpp((int)got0x, 0x4E, 0xF, 0xF, true); got0y = (uint32_t)__builtin_amdgcn_mov_dpp((int)got0y, 0x4E, 0xF, 0xF, true);
+                got1x = (uint32_t)__builtin_amdgcn_mov_dpp((int)got1x, 0x4E, 0xF, 0xF, true); got1y = (uint32_t)__builtin_amdgcn_mov_dpp((int)got1y, 0x4E, 0xF, 0xF, true);
+#endif
+                // channels +0..3 and +8..11 of the item belong to the first call (A), +4..7 and +12..15 to the second (B)
+                const uint32_t a0x = gq_odd ? got0x : mine0x, a0y = gq_odd ? got0y : mine0y, a1x = gq_odd ? got1x : mine1x, a1y = gq_odd ? got1y : mine1y;
+                const uint32_t b0x = gq_odd ? mine0x : got0x, b0y = gq_odd ? mine0y : got0y, b1x = gq_odd ? mine1x : got1x, b1y = gq_odd ? mine1y : got1y;
+                const uint4 oa = make_uint4(va.x & a0x, va.y & a0y, va.z & b0x, va.w & b0y);
+                const uint4 ob = make_uint4(vb.x & a1x, vb.y & a1y, vb.z & b1x, vb.w & b1y);
                 // d1: even lane keeps its first half, odd lane takes the even lane's second half (item it_e, bytes 0..15 | 16..31);
                 // d2: odd lane keeps its second half, even lane takes the odd lane's first half (item it_o).  DPP quad_perm [1,0,3,2]
                 // = the value of lane ^ 1.
@@ -1684,19 +1697,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             for (int k = 0; k < 4; ++k) ph_oth[k] = (uint32_t)__shfl_xor((int)ph_bits[k], 32, 64);
         }
     }
-    // M16, decisions drawn in the loop: per 32-bit word of keep bits the lane needs its own or its partner's byte of every call --
-    // even cout fragments of a pair (fc & 1 == 0) take the byte drawn by the lower lane half, odd ones the upper half's -- and of
-    // that byte the nibble (q4 >> 1).  Both selections are made ONCE per word here (En / On: nibble of call byte k at bit 8k), so
-    // that the per-fragment expansion below is four constant-position bit extracts.
+    // M16, decisions drawn in the loop: group g = fp*2 + (fc>>2) left the 16 keep bits of a call at bit (7 - g)*16 of the 128 -- drawn by
+    // the lower lane half for the even fragment pairs (fc>>1 even), by the upper half for the odd ones (T0 / T1 below) -- and of that
+    // call the lane's run is u = (fc&1)*2 + (q4>>1): bits 4u .. 4u+3.  Source and the (q4>>1) part of the shift are selected ONCE per
+    // word here, so that the per-fragment expansion below is four constant-position bit extracts.
     uint32_t ph_En[4] = {0u, 0u, 0u, 0u}, ph_On[4] = {0u, 0u, 0u, 0u};
     if constexpr (M16) {
         if (drop && ph_inloop) {
             const bool up = (q4 >> 1) != 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t e = up ? ph_oth[k] : ph_bits[k], o_ = up ? ph_bits[k] : ph_oth[k];
-                ph_En[k] = up ? e >> 4 : e;
-                ph_On[k] = up ? o_ >> 4 : o_;
+                const uint32_t t0 = up ? ph_oth[k] : ph_bits[k], t1 = up ? ph_bits[k] : ph_oth[k];
+                ph_En[k] = up ? t0 >> 4 : t0;
+                ph_On[k] = up ? t1 >> 4 : t1;
             }
         }
     }
@@ -1709,17 +1722,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int2 rg = s_rng[pixl];
                 const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
                 const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
+                Philox4 rr16{0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int fc = 0; fc < FC16; ++fc) {
                     const int col = wc * WTC + fc * 16 + q4 * 4;
                     uint2 o = pk16[fc][fp];
                     if (drop && ph_inloop) {
-                        // call idx = fp*4 + (fc>>1) left its byte at a fixed position; the lane's nibble (decisions (q4>>1)*4 .. +3) sits
-                        // at that byte's bit 0 in ph_En / ph_On.  Decision d -> 16-bit lane d of the 4 packed channels.
-                        const int idx = fp * 4 + (fc >> 1);
-                        const int bitpos = (7 - (idx >> 1)) * 16 + ((idx & 1) ? 0 : 8);
+                        // the call of fragment pair fc>>1 left its 16 bits at a fixed position; the lane's nibble (run (fc&1)*2 + (q4>>1)) sits
+                        // at bit (fc&1)*8 of that field in ph_En (even pairs) / ph_On (odd pairs).  Bit r -> 16-bit lane r of the 4 packed channels.
+                        const int bitpos = (7 - (fp * 2 + (fc >> 2))) * 16 + (fc & 1) * 8;
                         const int P = bitpos & 31;
-                        const uint32_t srcw = (fc & 1) ? ph_On[bitpos >> 5] : ph_En[bitpos >> 5];
+                        const uint32_t srcw = ((fc >> 1) & 1) ? ph_On[bitpos >> 5] : ph_En[bitpos >> 5];
 #if defined(__HIP_DEVICE_COMPILE__)
                         // (v_bfe_i32 of one bit = 0 / ~0; v_perm_b32 takes the low half of one and the high half of the other)
                         o.x &= __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)srcw, P + 1, 1), (uint32_t)__builtin_amdgcn_sbfe((int)srcw, P, 1), 0x07060100u);
@@ -1728,12 +1741,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         (void)P; (void)srcw;
 #endif
                     } else if (drop) {
-                        // decisions drawn here: the call of this lane's own fragment (its partner lane draws the same one)
-                        Philox4 rr;
-                        if (ABL == 4) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rg.x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
-                        else rr = philox4x32_10((uint32_t)rg.x, dropout_group8(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
-                        o.x &= keep_mask_u16x2((q4 >> 1) ? rr.z : rr.x, thr_m1_x2);
-                        o.y &= keep_mask_u16x2((q4 >> 1) ? rr.w : rr.y, thr_m1_x2);
+                        // decisions drawn here: the call of this lane's fragment pair (its partner lane draws the same one), run (fc&1)*2 + (q4>>1)
+                        if ((fc & 1) == 0) {
+                            if (ABL == 4) rr16 = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rg.x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
+                            else rr16 = philox4x32_10((uint32_t)rg.x, dropout_group16(bc0 + col), sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
+                        }
+                        const DropPair dw = dropout_run_windows(rr16, (fc & 1) * 2 + (q4 >> 1));
+                        o.x &= keep_mask_u16x2(dw.x, thr_m1_x2);
+                        o.y &= keep_mask_u16x2(dw.y, thr_m1_x2);
                     }
                     *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = o;
                 }
@@ -1752,30 +1767,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int col = wc * WTC + i * 32 + g4 * 8 + fhalf * 4;
                     uint2 o = pk[i][j][g4];
-                    if (drop && ph_inloop) {
-                        // decisions drawn in the main loop: call q = j*8 + i*2 + (g4>>1) left its byte at a fixed bit position
-                        const int q = j * 8 + i * 2 + (g4 >> 1);
-                        const int bitpos = (7 - (q >> 1)) * 16 + ((q & 1) ? 0 : 8) + (g4 & 1) * 4;      // 4 bits: (w0.lo, w0.hi, w1.lo, w1.hi)
-                        const uint32_t word = ph_bits[bitpos >> 5];
-                        const int sh = bitpos & 31;
-                        auto bit_mask = [](uint32_t v, int pos) { return (uint32_t)((int32_t)(v << (31 - pos)) >> 31); };    // 0 or ~0
-                        o.x &= __builtin_amdgcn_perm(bit_mask(word, sh + 1), bit_mask(word, sh), 0x07060100u);
-                        o.y &= __builtin_amdgcn_perm(bit_mask(word, sh + 3), bit_mask(word, sh + 2), 0x07060100u);
-                    } else if (drop) {
-                        // dropout contract v2: one Philox call decides 8 channels with 16-bit words -- the lane's
-                        // channel groups g4 = 2p and 2p+1 share the call keyed by (col>>5, p, fhalf)
-                        if ((g4 & 1) == 0) {
+                    if (drop) {
+                        // dropout contract v3: one Philox call decides 16 channels -- the lane's four runs g4 = 0..3 of this 32-channel
+                        // fragment share the call keyed by (col>>5, fhalf), run g4 reads output word g4 (philox.h)
+                        if (g4 == 0) {
                             if (ABL == 4) rr = Philox4{(uint32_t)col * 0x9E3779B9u, (uint32_t)rng[j].x * 0x85EBCA6Bu, sample * 0xC2B2AE35u, img};
-                            else rr = philox4x32_10((uint32_t)rng[j].x, dropout_group8(bc0 + col),
+                            else rr = philox4x32_10((uint32_t)rng[j].x, dropout_group16(bc0 + col),
                                                     sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
                         }
-                        const uint32_t w0 = (g4 & 1) ? rr.z : rr.x, w1 = (g4 & 1) ? rr.w : rr.y;
-                        o.x &= keep_mask_u16x2(w0, thr_m1_x2);
-                        o.y &= keep_mask_u16x2(w1, thr_m1_x2);
-                        if (g4 & 1) __builtin_amdgcn_sched_barrier(0);   // keep the Philox chains from interleaving (registers)
+                        const DropPair dw = dropout_run_windows(rr, g4);
+                        o.x &= keep_mask_u16x2(dw.x, thr_m1_x2);
+                        o.y &= keep_mask_u16x2(dw.y, thr_m1_x2);
                     }
                     *reinterpret_cast<uint2*>(prow + ((((col >> 3) ^ pixl) & (CPR - 1)) << 4) + (col & 7) * 2) = o;
                 }
+                if (drop) __builtin_amdgcn_sched_barrier(0);   // keep the Philox chains from interleaving (registers)
             }
         }
         phase_stamp<ABL>(tstamp, 3);        // Philox mask + LDS tile writes

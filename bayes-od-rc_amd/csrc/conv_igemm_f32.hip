@@ -153,9 +153,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
                     if (drop) {
                         const uint32_t img = a.image_base + ((uint32_t)e1.y >> 16);
                         const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)e1.y & 0xFFFFu));
-                        const Philox4 r = philox4x32_10((uint32_t)e1.x, dropout_group8((uint32_t)co),
+                        const Philox4 r = philox4x32_10((uint32_t)e1.x, dropout_group16((uint32_t)co),
                                                         sample | ((uint32_t)G.layer_id << 16), img, a.seed_lo, a.seed_hi);
-                        const uint32_t w0 = (g4 & 1) ? r.z : r.x, w1 = (g4 & 1) ? r.w : r.y;   // decisions d = (g4&1)*4 + q
+                        const DropPair dw = dropout_run_windows(r, ((co >> 4) & 1) * 2 + ((co >> 3) & 1));     // contract v3 (philox.h)
+                        const uint32_t w0 = dw.x, w1 = dw.y;
                         w[0] = (w0 & 0xFFFFu) >= a.drop_threshold ? v[0] * a.drop_scale : 0.f;
                         w[1] = (w0 >> 16) >= a.drop_threshold ? v[1] * a.drop_scale : 0.f;
                         w[2] = (w1 & 0xFFFFu) >= a.drop_threshold ? v[2] * a.drop_scale : 0.f;

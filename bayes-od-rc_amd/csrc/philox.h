@@ -55,10 +55,20 @@ BOD_HD void philox_rounds(PhiloxState& s, int n) {
     }
 }
 
-// Dropout contract v2 (DESIGN.md "RNG contract"): a Philox call decides 8 channels with 16-bit words.
-// Channel c belongs to call group  (c>>5)*4 + ((c>>4)&1)*2 + ((c>>2)&1)  and uses decision
-// d = ((c>>3)&1)*4 + (c&3): 16-bit half (d&1) of word (d>>1).  (The 8 channels of a group are the two
-// 4-channel runs one MFMA lane holds in adjacent accumulator groups.)
-BOD_HD uint32_t dropout_group8(uint32_t c) { return (c >> 5) * 4u + ((c >> 4) & 1u) * 2u + ((c >> 2) & 1u); }
+// Dropout contract v3 (DESIGN.md "RNG contract"; oracle twin oracle/philox.py): a Philox call decides 16 channels.  Its 128 bits
+// (word x least significant) are read as 16 overlapping 16-bit windows at byte stride, wrapping from w back to x.  Channel c belongs
+// to call group (c>>5)*2 + ((c>>2)&1) -- the four 4-channel runs {c0, c0+8, c0+16, c0+24} one lane of the 32x32 MFMA layout holds in a
+// 32-channel fragment -- and run u = ((c>>4)&1)*2 + ((c>>3)&1) of the call looks at output word u: channel c&3 = 0, 1 at its two halves,
+// 2 at bits 8..23, 3 at bits 24..31 with bits 0..7 of word (u+1)&3 on top.  keep iff window >= threshold.  Every window is a uniform
+// 16-bit number (exact keep probability to 2^-16, as with contract v2's eight half-words per call, at half the Philox calls); two
+// windows that share a byte are independent unless the more significant byte of one ties with the threshold's (probability 2^-8).
+BOD_HD uint32_t dropout_group16(uint32_t c) { return (c >> 5) * 2u + ((c >> 2) & 1u); }
+// the two packed window pairs of run u: .x = channels 0, 1 (low, high half), .y = channels 2, 3
+struct DropPair { uint32_t x, y; };
+BOD_HD DropPair dropout_run_windows(const Philox4& r, int u) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    const uint32_t a = w[u & 3], b = w[(u + 1) & 3];
+    return DropPair{a, (a >> 8) | (b << 24)};
+}
 
 #define BOD_CAT_TAG 0x00CA7E60u

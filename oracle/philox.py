@@ -9,12 +9,15 @@ experiments/inference_utils.py:37-46), which cannot be reproduced.  The build th
 identical random numbers:
 
 dropout   counter = (pixel p in the image's p3..p7 concatenated pyramid,
-                     call group dropout_group8(c)   (8 channels per Philox call),
+                     call group dropout_group16(c)  (16 channels per Philox call, contract v3),
                      sample n | layer_id << 16,      layer_id = head*4 + layer, head cls/reg/cov = 0/1/2
                      image id)
           key     = (seed_lo, seed_hi)
-          16-bit half d&1 of word d>>1 decides channel c (d = ((c>>3)&1)*4 + (c&3)):
-          keep iff u16 >= DROP_THRESHOLD(rate)
+          the call's 128 bits are read as 16 overlapping 16-bit windows at byte stride (wrapping): channel c looks at
+          bytes b, b+1 (little endian) with b = 4*u + (0, 2, 1, 3)[c & 3], u = ((c>>4)&1)*2 + ((c>>3)&1):
+          keep iff window >= DROP_THRESHOLD(rate).  Every window is a uniform 16-bit number (the keep probability is
+          exact to 2**-16, as in contract v2); two decisions of a call that share a byte are independent unless the
+          more significant byte of one of them ties with the threshold's (probability 2**-8).
 
 categorical  counter = (anchor a, draw group g, CAT_TAG, image id); draw d = 4*g + j uses word j,
           u = (word >> 8) * 2**-24 in [0, 1)
@@ -50,33 +53,39 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def drop_threshold(rate):
     """keep iff u16 >= floor(float32(rate) * 2**16).  The rate is taken as float32, as tf.nn.dropout
-    compares its uniforms with ``rate`` cast to the tensor dtype; decisions use 16-bit words (contract v2),
+    compares its uniforms with ``rate`` cast to the tensor dtype; decisions use 16-bit numbers,
     so P[drop] = 19660/65536 = 0.29999 for rate 0.3."""
     return np.uint32(int(np.floor(float(np.float32(rate)) * 65536.0)))
 
 
-def dropout_group8(c):
-    """Philox call group of channel c (contract v2; twin of csrc/philox.h)."""
+def dropout_group16(c):
+    """Philox call group of channel c (contract v3; twin of csrc/philox.h)."""
     c = np.asarray(c, dtype=np.uint64)
-    return (c >> np.uint64(5)) * np.uint64(4) + ((c >> np.uint64(4)) & np.uint64(1)) * np.uint64(2) + ((c >> np.uint64(2)) & np.uint64(1))
+    return (c >> np.uint64(5)) * np.uint64(2) + ((c >> np.uint64(2)) & np.uint64(1))
+
+
+def dropout_window_byte(c):
+    """First byte (0..15) of channel c's 16-bit window in its call's 128 output bits (contract v3)."""
+    c = np.asarray(c, dtype=np.int64)
+    u = ((c >> 4) & 1) * 2 + ((c >> 3) & 1)
+    return 4 * u + np.array([0, 2, 1, 3], dtype=np.int64)[c & 3]
 
 
 def dropout_keep_mask(seed, image_id, sample, layer_id, num_pixels, channels, rate):
-    """bool [num_pixels, channels]: True where the activation is kept.
-    Channel c uses decision d = ((c>>3)&1)*4 + (c&3) of call group dropout_group8(c): the 16-bit half (d&1)
-    of word (d>>1)."""
+    """bool [num_pixels, channels]: True where the activation is kept (contract v3, see the module header)."""
     assert channels % 32 == 0
     p = np.arange(num_pixels, dtype=np.uint64)[:, None]
     c = np.arange(channels, dtype=np.uint64)
-    groups = np.arange(channels // 8, dtype=np.uint64)[None, :]
+    groups = np.arange(channels // 16, dtype=np.uint64)[None, :]
     z = np.uint64((int(sample) & 0xFFFF) | (int(layer_id) << 16))
     words = philox4x32_10(p, groups, z, np.uint64(image_id), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    w = np.stack(words, axis=-1)                                              # [P, C/8, 4]
-    halves = np.stack([w & np.uint32(0xFFFF), w >> np.uint32(16)], axis=-1).reshape(num_pixels, channels // 8, 8)
-    keep8 = halves >= drop_threshold(rate)                                    # decision index d = word*2 + half
-    g = dropout_group8(c).astype(np.int64)
-    d = (((c >> np.uint64(3)) & np.uint64(1)) * np.uint64(4) + (c & np.uint64(3))).astype(np.int64)
-    return keep8[:, g, d]
+    w = np.stack(words, axis=-1)                                              # [P, C/16, 4] uint32, word 0 = least significant
+    by = np.stack([(w >> np.uint32(8 * k)) & np.uint32(0xFF) for k in range(4)], axis=-1).reshape(num_pixels, channels // 16, 16)
+    win = by | (np.roll(by, -1, axis=-1) << np.uint32(8))                     # window b = bytes b, b+1 (wrapping), little endian
+    keep16 = win >= drop_threshold(rate)
+    g = dropout_group16(c).astype(np.int64)
+    b = dropout_window_byte(c)
+    return keep16[:, g, b]
 
 
 def categorical_uniforms(seed, image_id, num_anchors, num_draws=NUM_CAT_DRAWS):

@@ -311,6 +311,18 @@ def test_fp32_pipeline_matches_oracle_end_to_end(precision):
             k = min(len(idx), len(dev_idx))
             p = int(np.nonzero(idx[:k] != dev_idx[:k])[0][0]) if np.any(idx[:k] != dev_idx[:k]) else k
             assert p < k, "centre lists of different length with a common prefix"
+            # ... or a candidate whose IoU with an already selected box sits ON the hard threshold of the op (w = 0 above 0.5, variant A:
+            # oracle/nms.py): the oracle's float64 corners and the device's float32 ones may then fall on different sides of it
+            near = False
+            for cand in (int(idx[p]), int(dev_idx[p])):
+                for j in idx[:p]:
+                    for cs in (corners, dev_corners):
+                        near = near or abs(float(geometry.bbox_iou_vuvu(cs[cand][None], cs[int(j)][None])[0, 0]) - 0.5) < 2e-3
+            # ... or a candidate that is one of the boundary-ambiguous anchors compare_posterior set aside: a categorical draw within
+            # boundary_eps of a CDF edge sampled the neighbouring class on the device, its counts -- hence its score -- differ by 1/30
+            flipped = any(not np.array_equal(got["counts"][int(c)], post["counts"][int(c)].astype(np.float32)) for c in (idx[p], dev_idx[p]))
+            if near or flipped:
+                continue
             assert abs(float(sc_ref[p]) - float(sc_chain[p])) <= 1e-5 * abs(float(sc_ref[p])), (p, sc_ref[p], sc_chain[p])
             continue
         iou = geometry.bbox_iou_vuvu(post["corners"], post["corners"])

@@ -28,22 +28,49 @@ def test_dropout_mask_contract():
                                  channels=256, rate=0.3)
     assert m.shape == (500, 256) and m.dtype == bool
     assert abs(m.mean() - 0.7) < 0.01
-    # channel c: decision d = ((c>>3)&1)*4 + (c&3) of call group (c>>5)*4 + ((c>>4)&1)*2 + ((c>>2)&1)
+    # contract v3: channel c looks at the 16-bit window starting at byte 4u + (0, 2, 1, 3)[c & 3], u = ((c>>4)&1)*2 + ((c>>3)&1), of
+    # the 128 bits of call group (c>>5)*2 + ((c>>2)&1)
     thr = philox.drop_threshold(0.3)
     assert thr == 19660                    # floor(float32(0.3) * 2**16)
-    for c in (0, 5, 13, 77, 200, 255):
-        g = (c >> 5) * 4 + ((c >> 4) & 1) * 2 + ((c >> 2) & 1)
-        d = ((c >> 3) & 1) * 4 + (c & 3)
+    for c in (0, 5, 13, 30, 31, 77, 200, 255):
+        g = (c >> 5) * 2 + ((c >> 2) & 1)
+        b = 4 * (((c >> 4) & 1) * 2 + ((c >> 3) & 1)) + (0, 2, 1, 3)[c & 3]
         w = philox.philox4x32_10(17, g, 2 | (5 << 16), 3, 9, 7)
-        u16 = (int(w[d >> 1]) >> (16 * (d & 1))) & 0xFFFF
-        assert m[17, c] == (u16 >= int(thr))
-    # every channel is decided by exactly one (group, decision) pair
+        bits = sum(int(w[k]) << (32 * k) for k in range(4))
+        bits |= (bits & 0xFF) << 128           # the last window wraps to byte 0
+        u16 = (bits >> (8 * b)) & 0xFFFF
+        assert m[17, c] == (u16 >= int(thr)), c
+    # every channel is decided by exactly one (group, window) pair; a call's 16 windows start at 16 different bytes
     cs = np.arange(256)
-    pairs = set(zip(((cs >> 5) * 4 + ((cs >> 4) & 1) * 2 + ((cs >> 2) & 1)).tolist(), (((cs >> 3) & 1) * 4 + (cs & 3)).tolist()))
-    assert len(pairs) == 256
+    pairs = set(zip(philox.dropout_group16(cs).tolist(), philox.dropout_window_byte(cs).tolist()))
+    assert len(pairs) == 256 and {p[1] for p in pairs} == set(range(16)) and {p[0] for p in pairs} == set(range(16))
     other = philox.dropout_keep_mask((7 << 32) | 9, 3, 3, 5, 500, 256, 0.3)
     assert (other != m).mean() > 0.3
     assert philox.dropout_keep_mask(1, 0, 0, 0, 10, 32, 0.0).all()
+
+
+def test_dropout_windows_are_uniform_and_nearly_independent():
+    """Contract v3 reads 16 decisions out of one call as overlapping 16-bit windows.  Over 2**20 decisions per rate: the keep rate
+    of every window position matches 1 - thr/2**16 within 4 sigma, and the decisions of windows that share a byte (neighbouring
+    bytes of the call) are as good as uncorrelated (within the 4 sigma of 4 096 samples; the bound from the construction is 2**-8)."""
+    for rate in (0.3, 0.5, 0.1):
+        m = philox.dropout_keep_mask(12345, 1, 0, 3, 4096, 256, rate).astype(np.float64)      # [4096, 256]
+        thr = int(philox.drop_threshold(rate))
+        pk = 1.0 - thr / 65536.0
+        b = philox.dropout_window_byte(np.arange(256))
+        g = philox.dropout_group16(np.arange(256))
+        for byte in range(16):
+            x = m[:, b == byte]
+            n = x.size
+            assert abs(x.mean() - pk) < 4.0 * np.sqrt(pk * (1 - pk) / n), (rate, byte)
+        # channels of one call whose windows start at neighbouring bytes
+        for grp in (0, 7, 15):
+            ch = {int(b[c]): c for c in range(256) if g[c] == grp}
+            for byte in range(16):
+                x, y = m[:, ch[byte]], m[:, ch[(byte + 1) % 16]]
+                assert abs(np.corrcoef(x, y)[0, 1]) < 0.06, (rate, grp, byte)          # 4096 samples: sigma 0.016
+        x = m[:, [c for c in range(256) if g[c] == 3]]
+        assert abs(np.corrcoef(x.T) - np.eye(16)).max() < 0.08
 
 
 def test_categorical_uniforms_contract():

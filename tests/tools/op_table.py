@@ -45,7 +45,7 @@ def main():
     fwd, cur = [], None
     for r in rows:
         n = r[0]
-        if "stem_" in n:
+        if "stem_conv" in n or "stem_pool_fused" in n:
             cur = [r]
             fwd.append(cur)
         elif cur is not None and any(k in n for k in fam):
