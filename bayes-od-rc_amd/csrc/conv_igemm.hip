@@ -2153,7 +2153,8 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     if (ABL == 5 && a.groups > 1 && a.ksplit <= 1) grid = dim3(nx * a.groups, ny, 1);      // shared-input groups, interleaved (see the kernel)
     // cout tile as the fast index inside an XCD (see the kernel).  BOD_COUT_INNER=0: the (nx, ny) grid, A/B aid -- same tiles, same results
     static const bool cout_inner = [] { const char* e = getenv("BOD_COUT_INNER"); return !e || atoi(e) != 0; }();
-    if (cout_inner && !XR && ny > 1) grid = dim3(8 * ((nx >> 3) + ((nx & 7) ? 1 : 0)) * ny, 1, grid.z);
+    // (from 64 pixel tiles on: with fewer, the (nx, ny) grid spreads a pixel tile's cout tiles over all XCDs, which small launches need more)
+    if (cout_inner && !XR && ny > 1 && nx >= 64) grid = dim3(8 * ((nx >> 3) + ((nx & 7) ? 1 : 0)) * ny, 1, grid.z);
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::LDS, s, a);
     return hipGetLastError();
 }

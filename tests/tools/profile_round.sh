@@ -1,7 +1,8 @@
 #!/bin/bash
 # Every profile of a round in one call (run on the GPU box through gpurun): writes gpurun_out/<prefix>_* -- copy them under profiles/.
 #   kernel trace + stats of the bench command, HBM traffic (FETCH / WRITE PMC passes), SQ / TCC counters and the phase clock of the
-#   tower kernel on its PRODUCTION launches (512 frames per step), the training step's kernel trace.
+#   tower kernel on its PRODUCTION launches (512 frames per step), the training step's kernel trace, the per-op roofline tables
+#   (tests/tools/op_table.py) of the headline and the parity-mode forward.
 # usage: profile_round.sh <prefix, e.g. round4> "<label>"
 P=${1:-round}; LABEL="${2:-}"
 cd $GRAFT_REPO_ROOT
@@ -16,5 +17,9 @@ rm -rf gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_tcc
   B=512 python3 tests/tools/bench_head_conv.py 0:1 90:1 0:2 90:2 0:3 90:3 0:4 90:4 0:0 2>&1 | grep "phase clock\|round 1" ) > gpurun_out/${P}_phase_clock.txt
 tests/tools/profile_train.sh "$LABEL" 512 512 3 101 > gpurun_out/${P}_profile_train.log 2>&1
 cp gpurun_out/train_kernel_trace.txt gpurun_out/${P}_train_step_kernel_trace.txt
+tests/tools/op_table.sh "$LABEL" > gpurun_out/${P}_op_table.log 2>&1
+cp gpurun_out/op_table.txt gpurun_out/${P}_op_table.txt
+tests/tools/op_table.sh "$LABEL; parity mode" --precision bf16x3 --batch 256 > gpurun_out/${P}_op_table_x3.log 2>&1
+cp gpurun_out/op_table.txt gpurun_out/${P}_op_table_bf16x3.txt
 ls -la gpurun_out/${P}_*
 cat gpurun_out/${P}_head_conv_counters.json gpurun_out/${P}_phase_clock.txt
