@@ -423,6 +423,145 @@ __global__ __launch_bounds__(256, 2) void slide3x3_c64_kernel(const ConvArgs a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Sliding-window 3x3 (stride 1, SAME), 128 -> 128 channels: ResNet stage 3's `2b` layers (round 4).  The generic 128x128 tile ran them
+// at 0.79 PFLOP/s (tests/tools/op_table.py: 780 us per 512 frames for 247 us of MFMA work) -- LDS-bound: every K-tile re-stages the
+// tile's pixels for one tap, and a 64x64 wave tile reads four fragments per four MFMAs.  Same walk as the 64-channel kernel above --
+// a workgroup owns a 64-pixel column strip, three input rows of an output row in a four-slot ring, every input pixel staged once --
+// but a wave cannot hold 32 couts x 1152 k of weights (288 registers): EIGHT waves = 4 cout blocks x 2 K-HALVES (input channels
+// 0-63 / 64-127 of every tap, 36 weight fragments = 144 registers each, two waves per SIMD); a wave multiplies both 32-pixel fragments
+// of the row with its half of K, the two halves of a cout block trade one fragment's partial sums through LDS and each finishes one
+// (bias, ReLU, pack).  The sum of a pixel is (channels 0-63, taps in order) + (channels 64-127, taps in order): the generic kernel's
+// k order with ONE fp32 addition re-associated -- not bit-identical to it (tests/test_gpu_forward.py compares at the rounding floor),
+// deterministic.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void slide3x3_c128_kernel(const ConvArgs a, int nstrips, int xsegs) {
+    constexpr int SLOT = 66 * 256;                // bytes per ring slot: 64 + 2 halo pixels x 128 channels
+    constexpr int RING = 4;
+    constexpr int OB = 64 * 256;                  // one output row tile [64 px][128 ch] bf16
+    extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+    char* const ring = sl_smem;                   // [RING][SLOT]
+    char* const obuf = sl_smem + RING * SLOT;     // [2][OB]
+    float4* const xch = reinterpret_cast<float4*>(sl_smem + RING * SLOT + 2 * OB);      // [8 waves][4 groups][64 lanes] float4: a fragment's partial sums
+    float* const sbias = reinterpret_cast<float*>(sl_smem + RING * SLOT + 2 * OB + 8 * 4096);   // [128] (registers are short: 144 hold the weights)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int cb = wave & 3, kh = wave >> 2;      // cout block of 32, K half (input channels kh*64 .. +63); this wave finishes pixel fragment kh
+    const ConvGroup& G = a.g[0];
+    const int H = a.plane_h, W = a.plane_w;
+
+    // weights: A fragments of couts cb*32 .. +31 for the 36 k-steps of this K half (tap-major, 4 x 16 channels per tap)
+    pw_bf16x8 wf[36];
+    {
+        const char* wrow = reinterpret_cast<const char*>(G.w) + ((size_t)(cb * 32 + frow) * 1152 + kh * 64 + fhalf * 8) * 2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wf[t * 4 + ks] = *reinterpret_cast<const pw_bf16x8*>(wrow + (t * 128 + ks * 16) * 2);
+    }
+    if (tid < 128) sbias[tid] = G.bias[tid];
+    const bool relu = a.flags & CONV_RELU;
+
+    for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int b = strip / xsegs, xs = strip - b * xsegs;
+        const int x0 = xs * 64, nv = min(64, W - x0);
+        const int m00 = (b * H) * W + x0;
+        const int4 e0 = *reinterpret_cast<const int4*>(&a.rows[m00]);  // in_off, in_pitch, out_off, res_off
+        const int out_pitch = H > 1 ? a.rows[m00 + W].out_off - e0.z : 0;
+        const long in0 = (long)e0.x;
+        const int in_pitch = e0.y;
+        // DMA of input row `ir` into ring slot ir % RING: 1056 16-byte pieces, pixel = piece / 16, chunk swizzled by the pixel (low three
+        // bits).  Every wave issues two instructions per row, the lower half of wave 0 a third one for the last 32 pieces.
+        auto issue_row = [&](int ir) {
+            char* slot = ring + (ir % RING) * SLOT;
+            auto piece = [&](int i) {
+                const int q = i * 512 + tid;
+                int px = q >> 4;
+                const int cp = q & 15;
+                const int c = cp ^ (px & 7);
+                px = px < nv + 2 ? px : 0;
+                const char* src = reinterpret_cast<const char*>(G.in) + (((size_t)(in0 + (long)ir * in_pitch + px)) * a.in_cstride + G.in_coff + c * 8) * 2;
+                __builtin_amdgcn_global_load_lds(PW_GLOBAL_PTR(src), PW_LDS_PTR(slot + (i * 512 + wave * 64) * 16), 16, 0, 0);
+            };
+            piece(0); piece(1);
+            if (wave == 0 && lane < 32) piece(2);
+        };
+        __syncthreads();                          // the previous strip's last reads of the ring / output tiles are done
+        issue_row(0); issue_row(1); issue_row(2);
+        for (int y = 0; y < H; ++y) {
+            const bool pre = y + 1 < H;           // row y+3 exists (the padded plane has H+2 rows)
+            if (pre) issue_row(y + 3);
+            asm volatile("" ::: "memory");
+            // rows y .. y+2 have landed once at most the instructions issued BEHIND row y+2's pieces are outstanding (vmcnt retires in
+            // issue order): the pieces of row y+3 (3 on wave 0, 2 elsewhere) and the two stores of the previous output row
+            if (!pre) pw_wait_vm<0>();
+            else if (wave == 0) { if (y == 0) pw_wait_vm<3>(); else pw_wait_vm<5>(); }
+            else { if (y == 0) pw_wait_vm<2>(); else pw_wait_vm<4>(); }
+            __syncthreads();
+            pw_f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const char* slot = ring + ((y + ky) % RING) * SLOT;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int px = j * 32 + frow + kx;
+                            const pw_bf16x8 bf = *reinterpret_cast<const pw_bf16x8*>(slot + px * 256 + (((kh * 8 + ks * 2 + fhalf) ^ (px & 7)) << 4));
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(ky * 3 + kx) * 4 + ks], bf, acc[j], 0, 0, 0);
+                        }
+            }
+            // the fragment the OTHER K half finishes goes to it through LDS
+            {
+                float4* mine = xch + wave * 256;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const pw_f32x16& v = acc[1 - kh];
+                    mine[g * 64 + lane] = make_float4(v[g * 4 + 0], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
+                }
+            }
+            __syncthreads();
+            char* ob = obuf + (y & 1) * OB;
+            {
+                const float4* theirs = xch + (wave ^ 4) * 256;
+                const int px = kh * 32 + frow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = theirs[g * 64 + lane];
+                    const pw_f32x16& v = acc[kh];
+                    // (channels 0-63) + (channels 64-127), whichever half this wave holds
+                    const float s0 = kh ? t.x + v[g * 4 + 0] : v[g * 4 + 0] + t.x, s1 = kh ? t.y + v[g * 4 + 1] : v[g * 4 + 1] + t.y;
+                    const float s2 = kh ? t.z + v[g * 4 + 2] : v[g * 4 + 2] + t.z, s3 = kh ? t.w + v[g * 4 + 3] : v[g * 4 + 3] + t.w;
+                    const float4 bvg = *reinterpret_cast<const float4*>(sbias + cb * 32 + g * 8 + fhalf * 4);
+                    uint2 o;
+                    o.x = pw_pack(__builtin_fmaf(s0, 1.0f, bvg.x), __builtin_fmaf(s1, 1.0f, bvg.y));
+                    o.y = pw_pack(__builtin_fmaf(s2, 1.0f, bvg.z), __builtin_fmaf(s3, 1.0f, bvg.w));
+                    if (relu) { o.x = pw_relu(o.x); o.y = pw_relu(o.y); }
+                    *reinterpret_cast<uint2*>(ob + px * 256 + (((cb * 4 + g) ^ (px & 7)) << 4) + fhalf * 8) = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = i * 512 + tid, px = q >> 4, cp = q & 15;
+                const int c = cp ^ (px & 7);
+                const uint4 v = *reinterpret_cast<const uint4*>(ob + q * 16);
+                uint4* dst = px < nv ? reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(G.out) + ((size_t)e0.z + (size_t)y * out_pitch + px) * a.out_cstride + c * 8)
+                                     : &pw_sink[lane];
+                *dst = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
 bool conv_slide3x3_eligible(const ConvArgs& a) {
     static const bool on = [] { const char* e = getenv("BOD_SLIDE3X3"); return !e || atoi(e) != 0; }();
     if (!on) return false;
@@ -430,7 +569,11 @@ bool conv_slide3x3_eligible(const ConvArgs& a) {
     if (a.variant != 0 || a.split || a.xreuse || a.ksplit > 1 || a.groups != 1 || a.taps != 9 || a.KW != 3 || a.fan_count > 1) return false;
     if (a.flags & (CONV_DROPOUT | CONV_OUT_F32 | CONV_ACCUM)) return false;
     if (g.w2 || g.ch_w2 || g.out_relu || g.agg_kind || g.res) return false;
-    if (a.cin != 64 || a.cout_pad != 64 || a.cout_valid != 64 || a.plane_h < 1 || a.plane_w < 1) return false;
+    const bool c64 = a.cin == 64 && a.cout_pad == 64 && a.cout_valid == 64;
+    // (128 -> 128: BOD_SLIDE3X3_C128=0 plans the generic launches)
+    static const bool c128_on = [] { const char* e = getenv("BOD_SLIDE3X3_C128"); return !e || atoi(e) != 0; }();
+    const bool c128 = c128_on && a.cin == 128 && a.cout_pad == 128 && a.cout_valid == 128;
+    if ((!c64 && !c128) || a.plane_h < 1 || a.plane_w < 1) return false;
     if ((a.in_cstride & 7) || (a.out_cstride & 7) || (g.in_coff & 7)) return false;
     if (a.M % (a.plane_h * a.plane_w) != 0) return false;
     // A workgroup owns one 64-pixel column strip of one image for the whole launch and walks down it: the grid is images x strips,
@@ -442,10 +585,26 @@ bool conv_slide3x3_eligible(const ConvArgs& a) {
     static const int min_m = [] { const char* e = getenv("BOD_POINTWISE_MIN_M"); return e ? atoi(e) : -1; }();
     if (min_m >= 0) return a.M >= min_m;
     const long nstrips = (long)(a.M / (a.plane_h * a.plane_w)) * ((a.plane_w + 63) / 64);
+    // (the 128-channel kernel: one workgroup of eight waves per compute unit -- from one strip per CU on)
+    if (c128) return nstrips >= (long)launch_cus(a);
     return 2 * nstrips >= 3 * (long)launch_cus(a);
 }
 
 hipError_t launch_conv_slide3x3(const ConvArgs& a, hipStream_t s) {
+    if (a.cin == 128) {
+        constexpr int LDS128 = 4 * 66 * 256 + 2 * 64 * 256 + 8 * 4096 + 512;
+        static PerDeviceOnce once128;
+        bool& set128 = *once128.slot();
+        if (!set128) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(slide3x3_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+            if (e != hipSuccess) return e;
+            set128 = true;
+        }
+        const int xsegs = (a.plane_w + 63) / 64;
+        const int nstrips = a.M / (a.plane_h * a.plane_w) * xsegs;
+        hipLaunchKernelGGL(slide3x3_c128_kernel, dim3(std::min(nstrips, launch_cus(a))), dim3(512), LDS128, s, a, nstrips, xsegs);
+        return hipGetLastError();
+    }
     constexpr int LDS = 6 * 66 * 128 + 2 * 64 * 128;
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();

@@ -2072,6 +2072,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         ConvArgs a = base_args(pc, d_rows, B * OH * OW, Cin, Cout);
         a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id, nullptr, nullptr, nullptr, 0, 0};
         a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
+        if (stride == 1 && same_padding && KH == 3 && KW == 3) { a.plane_h = OH; a.plane_w = OW; }      // (the sliding-window kernels walk planes)
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
         a.drop_threshold = (uint32_t)std::floor((double)dropout_rate * 65536.0);
         a.drop_scale = (float)(1.0 / (1.0 - (double)dropout_rate));

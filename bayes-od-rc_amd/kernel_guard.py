@@ -291,7 +291,7 @@ def verify_aux(host_obj, wanted=AUX_PRODUCTION):
 # conv_pointwise.o: the streaming 1x1 kernels share a CU two or three at a time, which only works while they stay inside their
 # register budget without spilling
 POINTWISE_PRODUCTION = ["pw_conv_kernelILi64ELi64E", "pw_conv_kernelILi128ELi64E", "pw_conv_kernelILi256ELi32E", "pw_conv_kernelILi512ELi32E",
-                        "slide3x3_c64_kernelILi1E"]
+                        "slide3x3_c64_kernelILi1E", "slide3x3_c128_kernel"]
 
 
 def verify_pointwise(host_obj):

@@ -237,3 +237,56 @@ def test_bf16x3_split_k(monkeypatch, b, h, w, cin, cout, k, stride, padding, spl
     if res:
         ref = np.maximum(ref + residual, 0)
     assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 1e-4
+
+
+@pytest.mark.parametrize("ch", [64, 128])
+def test_sliding_window_3x3_kernels_on_single_layers(ch):
+    """The sliding-window 3x3 kernels of the backbone (conv_pointwise.hip: 64 -> 64 of stage 2, 128 -> 128 of stage 3 -- the latter
+    splits the input channels over two waves and adds the halves) against the ORACLE conv and against the generic kernel, one
+    layer at a time: strips of 64 pixels that are full, ragged (70 = 64 + 6) and several per row (130), one-row and tall planes,
+    bias + ReLU, bf16 stores.  Against the oracle: bf16 rounding of the output (2^-9 relative).  Against the generic launch
+    (BOD_SLIDE3X3=0): identical for 64 channels (same k order); for 128 channels the one re-associated fp32 addition may move
+    a result across a rounding boundary -- at most one bf16 ulp, on a small fraction of the elements.
+    (BOD_POINTWISE_MIN_M=1 sends these small shapes down the streaming kernels.)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(2, 5, 64), (1, 1, 70), (2, 9, 130), (3, 33, 32), (1, 64, 64)]
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd.engine import stage_conv\n"
+            "out = {}\n"
+            "for i, (b, h, w) in enumerate(%r):\n"
+            "    rng = np.random.default_rng(100 + i)\n"
+            "    x = rng.normal(0, 1, (b, h, w, %d)).astype(np.float32)\n"
+            "    wt = (rng.normal(0, 1, (3, 3, %d, %d)) * np.sqrt(2.0 / (9 * %d))).astype(np.float32)\n"
+            "    bias = rng.normal(0, 0.5, %d).astype(np.float32)\n"
+            "    out['y%%d' %% i] = stage_conv(x, wt, bias, relu=True, round_output_bf16=True)\n"
+            "np.savez(sys.argv[1], **out)\n" % (root, shapes, ch, ch, ch, ch, ch))
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_SLIDE3X3=on, BOD_POINTWISE_MIN_M="1")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    for i, (b, h, w) in enumerate(shapes):
+        rng = np.random.default_rng(100 + i)
+        x = rng.normal(0, 1, (b, h, w, ch)).astype(np.float32)
+        wt = (rng.normal(0, 1, (3, 3, ch, ch)) * np.sqrt(2.0 / (9 * ch))).astype(np.float32)
+        bias = rng.normal(0, 0.5, ch).astype(np.float32)
+        ref = _oracle(x, wt, bias, 1, "same", relu=True)
+        slide, generic = outs[0]["y%d" % i].astype(np.float64), outs[1]["y%d" % i].astype(np.float64)
+        assert slide.shape == ref.shape
+        rms = float(np.sqrt((ref ** 2).mean()))
+        assert rel_err(slide, ref, floor=rms) < 2.0 ** -8, (i, rel_err(slide, ref, floor=rms))
+        if ch == 64:
+            assert np.array_equal(slide, generic), i
+        else:
+            # one bf16 ulp is at most 2^-7 of the value; sums that cancel to ~0 may land on either side of the ReLU (fp32 round-off of O(1) terms)
+            ulp = np.maximum(np.abs(generic), np.abs(slide)) * 2.0 ** -7 + 1e-5
+            assert (np.abs(slide - generic) <= ulp).all(), (i, float(np.abs(slide - generic).max()))
+            assert (slide != generic).mean() < 0.02, (i, float((slide != generic).mean()))

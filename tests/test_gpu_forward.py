@@ -452,6 +452,50 @@ def test_pointwise_kernel_is_bit_identical():
         assert np.isfinite(outs[0][k]).all(), k
 
 
+def test_sliding_window_3x3_128_channel_kernel_matches_the_generic_launches():
+    """ResNet stage 3's 3x3 layers (128 -> 128 channels) run on their own sliding-window kernel since round 4 (conv_pointwise.hip:
+    eight waves = 4 cout blocks x 2 halves of the input channels, partial sums traded through LDS).  Its sum per pixel is the generic
+    kernel's with ONE fp32 addition re-associated ((channels 0-63) + (channels 64-127)), so the comparison with BOD_SLIDE3X3_C128=0 is
+    not bit-exact: a layer's bf16 outputs flip by one ulp here and there (tests/test_gpu_conv.py pins exactly that on single layers),
+    and thirty layers further down the two pyramids are two bf16 roundings of the same network -- every level within 1e-2 relative
+    RMS of the other, as far as either is from the oracle (test_forward_at_bf16_noise_floor) -- widths that are and are not multiples
+    of 64, one and several strips per row, ResNet-50 and -101.  The two plans must really differ."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b, depth in (('a', (128, 128), 3, 50), ('b', (96, 160), 1, 50), ('c', (192, 624), 2, 50), ('d', (128, 128), 2, 101), ('e', (256, 256), 9, 50), ('f', (512, 1040), 2, 50)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=2, backbone_depth=depth))\n"
+            "    eng.load_weights(synthetic.make_weights(depth=depth))\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=3), seed=11, first_image_id=2)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % root)
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_SLIDE3X3_C128=on, BOD_POINTWISE_MIN_M="1", BOD_CONV_SPLITK="0")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) == 30
+    differs = 0
+    for k in sorted(outs[0]):
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        assert np.isfinite(a).all() and np.abs(a).max() > 0, k
+        rel = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
+        assert rel < 1e-2, (k, rel)
+        differs += int(not np.array_equal(a, b))
+    assert differs > 0, "BOD_SLIDE3X3_C128 did not change the plan"
+
+
 def test_plane_row_reuse_layers_are_bit_identical():
     """Round 4: the plane -> plane 3x3 stride-1 layers of 256 -> 256 channels (stage 4's `2b`, P3-P5) run on the tower kernel's
     row-reuse loop once their launch fills the chip with 256x256 tiles (engine.hip add_conv; BOD_PLANE_XREUSE=0: the generic loop).
@@ -528,7 +572,8 @@ def test_sliding_window_3x3_kernel_is_bit_identical():
     for on in ("1", "0"):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "o.npz")
-            env = dict(os.environ, BOD_SLIDE3X3=on, BOD_POINTWISE_MIN_M="1", BOD_CHAIN_FUSION="0")
+            # (stage 3's 128-channel sliding window is not bit-identical by construction: off here, tested on its own)
+            env = dict(os.environ, BOD_SLIDE3X3=on, BOD_SLIDE3X3_C128="0", BOD_POINTWISE_MIN_M="1", BOD_CHAIN_FUSION="0")
             r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr[-3000:]
             z = np.load(path)
@@ -664,7 +709,9 @@ def test_streaming_backbone_kernels_are_bit_identical_at_full_size(hw, batch):
     by), three forwards each: checksums of every pyramid level and of the raw head outputs must agree exactly.  Round 4: also at
     the reference's real frame sizes -- 720 x 1280 (stage-2 rows of 320 pixels: 5 column strips) and 512 x 1696 (424
     pixels: 7 strips, the last one 40 pixels wide; ragged pointwise tiles).  The planner's batch floors are lowered so that every
-    streaming kernel really runs at these batches (BOD_POINTWISE_MIN_M / BOD_STEM_POOL_FUSED_MIN_B)."""
+    streaming kernel really runs at these batches (BOD_POINTWISE_MIN_M / BOD_STEM_POOL_FUSED_MIN_B).  (Stage 3's 128-channel
+    sliding-window kernel re-associates one fp32 addition per output and is therefore off in both runs: its own tests are
+    test_sliding_window_3x3_128_channel_kernel_matches_the_generic_launches and tests/test_gpu_conv.py.)"""
     import os
     import subprocess
     import sys
@@ -691,7 +738,8 @@ def test_streaming_backbone_kernels_are_bit_identical_at_full_size(hw, batch):
     sums = []
     for streaming in ("1", "0"):
         env = dict(os.environ, BOD_POINTWISE=streaming, BOD_SLIDE3X3=streaming, BOD_STEM_POOL_FUSED=streaming, BOD_PW_FUSE_NEXT=streaming,
-                   BOD_PW_FUSE_DUAL=streaming, BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_STEM_POOL_FUSED_MIN_B="1")
+                   BOD_PW_FUSE_DUAL=streaming, BOD_CHAIN_FUSION="0", BOD_POINTWISE_MIN_M="1", BOD_STEM_POOL_FUSED_MIN_B="1",
+                   BOD_SLIDE3X3_C128="0")
         if streaming == "0":
             env["BOD_STEM_SEG64"] = "1"
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
