@@ -749,7 +749,7 @@ bod_status build_plan(bod_context* h) {
     // its launch is on the 256x256 tile (conv_igemm.hip: from 1 024 tiles on): activation reads x4.5 -> x1.2 of the
     // algorithmic bytes (profiles/round1_head_conv_pmc.json, launch 0).  BOD_FAN_XREUSE=0: A/B aid.
     RowEnt* d1x = nullptr; int2* dext1 = nullptr; int m1x = 0;
-    bool xreuse0 = xreuse && N > 1;
+    bool xreuse0 = xreuse;          // (N = 1: no fan-out, a plain three-head launch over the pyramid -- on the same loop since round 4: 1.07 -> 1.23 PFLOP/s)
     if (const char* e = getenv("BOD_FAN_XREUSE")) xreuse0 = xreuse0 && atoi(e) != 0;
     {
         ConvArgs probe{};
