@@ -338,6 +338,42 @@ def timed_pipeline(eng, steps, warmup, fwd_only, B, first_id=0, image_buffer=Non
     return time.perf_counter() - t0
 
 
+def pyramid_pixels(hw):
+    """Pixels of the p3..p7 pyramid of an H x W frame (SAME stride-2 chain from the stride-8 map)."""
+    lh, lw = -(-hw[0] // 8), -(-hw[1] // 8)
+    p = 0
+    for _ in range(5):
+        p += lh * lw
+        lh, lw = -(-lh // 2), -(-lw // 2)
+    return p
+
+
+def train_step_ms(device):
+    """BASELINE config 5: (ms per training step, total loss) of ResNet-101 RetinaNet + full-covariance loss at the yaml's minibatch
+    of three 512x512 frames: 3 untimed steps, 10 timed."""
+    from bayes_od_rc_amd import constants, synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    from bayes_od_rc_amd.run_training import synthetic_samples
+    hw, B = (512, 512), 3
+    samples = synthetic_samples(B, hw, ANCHOR_CFG, 7)
+    eng = Engine(make_config(hw, batch=B, mc_samples=1, device=device, training=True, backbone_depth=101))
+    eng.load_weights(synthetic.make_weights(depth=101))
+    eng.set_anchors(np.asarray(samples[0][constants.ANCHORS_KEY], np.float32))
+    st = lambda k: np.stack([s[k] for s in samples])
+    eng.upload_images(st(constants.IMAGE_NORMALIZED_KEY))
+    targets = (st(constants.ANCHORS_CLASS_TARGETS_KEY), st(constants.ANCHORS_BOX_TARGETS_KEY),
+               st(constants.POSITIVE_ANCHORS_MASK_KEY), st(constants.NEGATIVE_ANCHOR_MASK_KEY))
+    for i in range(3):
+        eng.train_step(None, *targets, seed=1, first_image_id=i * B)
+    steps = 10
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = eng.train_step(None, *targets, seed=1, first_image_id=(3 + i) * B)
+    dt = time.perf_counter() - t0
+    eng.close()
+    return dt / steps * 1e3, float(loss["total_loss"])
+
+
 def secondary_configs(device, weights, lo):
     """BASELINE.json configs 2, 4 (its geometry on one GPU) and 5, each on its own handle, a few steps each."""
     import torch
@@ -385,29 +421,31 @@ def secondary_configs(device, weights, lo):
         entry("the reference's real geometry: %s (SURVEY F7), ResNet-50 RetinaNet + covar head, N=10 MC-dropout, full BayesOD pipeline, "
               "%d frames/step" % (name, B), dt / steps * 1e3, B * steps / dt, "images/sec", image_gflop(hw, eng.P, n), B)
         eng.close()
-    # ---- config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (the yaml's minibatch of 3)
+    # ---- config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (the yaml's minibatch of 3).  The step is a chain of
+    # ~1 200 small dependent launches: its time is launch latency, and that depends on what the process did before -- measured on MI355X
+    # (.ab/train_probe.py in round 4): 10.9 ms in a fresh process, 12.4 ms once a torch HIP context exists, 13.4 ms after a large handle
+    # was created and destroyed.  A training run is its own process: the step is therefore timed in a CHILD process (this file with
+    # --train-step-probe), in-process only if that fails.
     hw, B = (512, 512), 3
-    samples = synthetic_samples(B, hw, ANCHOR_CFG, 7)
-    eng = Engine(make_config(hw, batch=B, mc_samples=1, device=device, training=True, backbone_depth=101))
-    eng.load_weights(synthetic.make_weights(depth=101))
-    eng.set_anchors(np.asarray(samples[0][constants.ANCHORS_KEY], np.float32))
-    st = lambda k: np.stack([s[k] for s in samples])
-    eng.upload_images(st(constants.IMAGE_NORMALIZED_KEY))
-    targets = (st(constants.ANCHORS_CLASS_TARGETS_KEY), st(constants.ANCHORS_BOX_TARGETS_KEY),
-               st(constants.POSITIVE_ANCHORS_MASK_KEY), st(constants.NEGATIVE_ANCHOR_MASK_KEY))
-    for i in range(3):
-        eng.train_step(None, *targets, seed=1, first_image_id=i * B)
-    steps = 10
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = eng.train_step(None, *targets, seed=1, first_image_id=(3 + i) * B)
-    dt = time.perf_counter() - t0
+    ms = loss = None
+    how = "timed in a fresh child process"
+    try:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-step-probe", str(device)], capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("TRAIN_STEP_MS ")]
+        if r.returncode == 0 and line:
+            ms, loss = float(line[-1].split()[1]), float(line[-1].split()[2])
+    except Exception:
+        ms = None
+    if ms is None:
+        ms, loss = train_step_ms(device)
+        how = "timed in this process (the child process failed)"
+    P101 = pyramid_pixels(hw)
     # forward + input-gradient + weight-gradient GEMMs = 3 x the forward's conv FLOPs (no de-duplication at N=1)
     entry("BASELINE config 5: ResNet-101 RetinaNet + full-covariance loss, one training step (forward, backward, clip, Adam), "
-          "bf16, %d frames of 512x512 (the yaml's minibatch)" % B, dt / steps * 1e3, B * steps / dt, "images/sec",
-          3.0 * image_gflop(hw, eng.P, 1, depth=101, dedup=False), B,
-          note="algorithmic GFLOP = 3 x forward conv FLOPs (forward, dgrad, wgrad GEMMs); total_loss %.3f" % loss["total_loss"])
-    eng.close()
+          "bf16, %d frames of 512x512 (the yaml's minibatch)" % B, ms, B / (ms * 1e-3), "images/sec",
+          3.0 * image_gflop(hw, P101, 1, depth=101, dedup=False), B,
+          note="algorithmic GFLOP = 3 x forward conv FLOPs (forward, dgrad, wgrad GEMMs); total_loss %.3f; %s" % (loss, how))
     torch.cuda.synchronize()
     return out
 
@@ -433,7 +471,13 @@ def main():
     ap.add_argument("--precision", choices=("bf16", "fp32", "bf16x3"), default="bf16",
                     help="bf16 = throughput path (BASELINE.json north_star); bf16x3 = its 1e-3 end-to-end parity mode; "
                          "fp32 = exact-fp32 MFMA")
+    ap.add_argument("--train-step-probe", type=int, default=None, metavar="DEVICE",
+                    help="(internal) time BASELINE config 5's training step on DEVICE in this fresh process and print TRAIN_STEP_MS")
     args = ap.parse_args()
+    if args.train_step_probe is not None:
+        ms, loss = train_step_ms(args.train_step_probe)
+        print("TRAIN_STEP_MS %.4f %.6f" % (ms, loss))
+        return
 
     import torch
     import torch.distributed as dist
