@@ -496,6 +496,37 @@ def test_sliding_window_3x3_128_channel_kernel_matches_the_generic_launches():
     assert differs > 0, "BOD_SLIDE3X3_C128 did not change the plan"
 
 
+def test_cout_inner_grid_order_is_bit_identical():
+    """Round 4: launches of the generic kernel with several cout tiles per pixel tile (ResNet stage 5: 2 and 8 of them) are one grid
+    row with the cout tile as the fast index inside an XCD from 64 pixel tiles on (conv_igemm.hip; BOD_COUT_INNER=0: the (nx, ny)
+    grid).  Only WHERE a tile runs changes: 64 frames of 512 x 512 (64 pixel tiles in stage 5, 1 024 in stage 3's projection) and a
+    ragged 70-frame batch (XCDs with one pixel tile less retire their last slots at once) must give the same pyramid, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys, json; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = []\n"
+            "for b in (64, 70):\n"
+            "    eng = Engine(make_config((512, 512), batch=b, mc_samples=1))\n"
+            "    eng.load_weights(synthetic.make_weights())\n"
+            "    eng.forward(synthetic.make_frames(b, 512, 512, seed=4), seed=1, first_image_id=0)\n"
+            "    for l in range(5):\n"
+            "        v = np.ascontiguousarray(eng.get_pyramid(l)).view(np.uint32).ravel()\n"
+            "        out.append([int(v.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(v))])\n"
+            "    eng.close()\n"
+            "print('CHECKSUMS ' + json.dumps(out))\n" % root)
+    sums = []
+    for on in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOD_COUT_INNER=on), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        import json
+        sums.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("CHECKSUMS ")][0][len("CHECKSUMS "):]))
+    assert sums[0] == sums[1] and len(sums[0]) == 10 and all(s[0] != 0 for s in sums[0])
+
+
 def test_plane_row_reuse_layers_are_bit_identical():
     """Round 4: the plane -> plane 3x3 stride-1 layers of 256 -> 256 channels (stage 4's `2b`, P3-P5) run on the tower kernel's
     row-reuse loop once their launch fills the chip with 256x256 tiles (engine.hip add_conv; BOD_PLANE_XREUSE=0: the generic loop).
