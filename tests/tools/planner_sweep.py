@@ -2,13 +2,18 @@
 """Sweep (GPU): the forward plan's kernel choices against their alternatives, by batch and geometry.
 For B in {1, 3, 8, 32, 128, 256} x {512x512, 384x1248}: median-of-5 wall time (engine synchronised on both sides, several forwards per sample) of the N=1 forward (backbone + FPN + one-sample heads:
 the launches the streaming kernels -- sliding-window 3x3, pointwise 1x1, fused stem + pool -- compete for) under the default plan and
-with each of those kernels switched off (BOD_SLIDE3X3=0 / BOD_POINTWISE=0 / BOD_STEM_POOL_FUSED=0).  Every configuration runs in a child
+with each of those kernels switched off (BOD_SLIDE3X3=0 / BOD_POINTWISE=0 / BOD_STEM_POOL_FUSED=0) and, since round 4, with each of that
+round's plan changes undone (BOD_PLANE_XREUSE=0 / BOD_SLIDE3X3_C128=0 / BOD_COUT_INNER=0 / BOD_STEM_WAVES=4).  Every configuration runs in a child
 process (the switches are read once per process).  usage: planner_sweep.py [--json]   (tests/test_gpu_planner.py asserts on it)"""
 import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SWITCHES = {"default": {}, "no_slide3x3": {"BOD_SLIDE3X3": "0"}, "no_pointwise": {"BOD_POINTWISE": "0"},
-            "no_fused_stem_pool": {"BOD_STEM_POOL_FUSED": "0"}}
+            "no_fused_stem_pool": {"BOD_STEM_POOL_FUSED": "0"},
+            # round 4: 256 -> 256 3x3 layers on the tower loop, stage 3's 128-channel sliding window, cout tiles side by side on an XCD,
+            # the eight-wave stem + pool kernel
+            "no_plane_row_reuse": {"BOD_PLANE_XREUSE": "0"}, "no_slide3x3_c128": {"BOD_SLIDE3X3_C128": "0"},
+            "no_cout_inner": {"BOD_COUT_INNER": "0"}, "stem_four_waves": {"BOD_STEM_WAVES": "4"}}
 CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r)
