@@ -680,8 +680,13 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         # (the plan fuses them whenever the launch uses the full-cout tile: from about 8 frames per step on; below that
         # they are separate small launches and are not counted here)
         algo_flops = n * 8 * conv_flops * B * prof_steps
-        kernel_name = "conv_igemm_kernel<256,256,2,4,0,true%s> (head towers, 3x3 256->256, layers 1-3; mid-tile-barrier loop)" % (
-            ",SPLIT: 3 MFMA products per MAC" if args.precision == "bf16x3" else "")
+        layers = "layers 1-3"
+        if n == 1 and eng.plan_info()["fan_out_row_reuse"]:
+            # N = 1: no fan-out -- the first tower layer is a plain three-head launch of the same kernel symbol (round 4)
+            algo_flops += 3 * conv_flops * B * prof_steps
+            layers = "layers 0-3 (N = 1: no fan-out launch)"
+        kernel_name = "conv_igemm_kernel<256,256,2,4,0,true%s> (head towers, 3x3 256->256, %s; mid-tile-barrier loop)" % (
+            ",SPLIT: 3 MFMA products per MAC" if args.precision == "bf16x3" else "", layers)
     else:                                # no row-reuse kernel in the plan (fp32 / bf16x3 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))
         eng.profile_begin(which=0)
