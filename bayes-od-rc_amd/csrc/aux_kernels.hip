@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __rest
             patch[buf][1][r][c] = (uint16_t)lo;
         }
     };
-    // this lane's B source: plane (lq >> 1), pixel wave*16 + li, chunk parity lq & 1
-    const int role = lq >> 1, k1 = lq & 1;
+    // this lane's B source: plane (lq & 1), pixel wave*16 + li, chunk parity lq >> 1 (see SR_ROWE: the two planes of one chunk share a 32-lane LDS access)
+    const int role = lq & 1, k1 = lq >> 1;
     int task = blockIdx.x, buf = 0;
     if (task < ntasks) { fetch(task); commit(0); }
     __syncthreads();
@@ -222,9 +222,13 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const float* __rest
 // the backbone stage moves by 0.2 ms (25.5 -> 25.3): the old kernel's steady-state time is the low end of its trace range.
 constexpr int SR_SEG = 256;                               // output pixels per task (4 waves x 4 fragments x 16)
 constexpr int SR_ROWF = 2 * SR_SEG * 3 + 5 * 3 + 5;       // 1556 floats: (2*255+7)*3 = 1551 real + 3 zero-weight k slots, padded
-constexpr int SR_ROWE = 1560;                             // uint16 per staged LDS row
+// uint16 per staged LDS row.  1568 = 784 dwords = 16 mod 32: the B fragments are read dword-wise (12-byte pixel stride), a 32-lane LDS
+// access = 16 pixels x the (hi, lo) planes of ONE chunk, and with the planes 16 banks apart the two 3-dword-stride combs interleave
+// without a collision (round 4: with 1560 and the planes in different accesses -- lanes paired by chunk parity instead -- four banks
+// of every access were hit twice: 40 % of the fused kernel's LDS cycles, tests/tools/pmc_kernel.sh)
+constexpr int SR_ROWE = 1568;
 constexpr int SR_PLANE = 7 * SR_ROWE;                     // one (hi or lo) plane of a buffer
-constexpr int SR_LDS_BYTES = 2 * 2 * SR_PLANE * 2;        // [buffer][hi / lo][ky][element] = 87 360 B; the weight table aliases buffer 1
+constexpr int SR_LDS_BYTES = 2 * 2 * SR_PLANE * 2;        // [buffer][hi / lo][ky][element] = 87 808 B; the weight table aliases buffer 1
 constexpr int SR_LDS_TOTAL = SR_LDS_BYTES + 4 * 8192;     // + one 8 KB epilogue tile per wave
 
 __global__ __launch_bounds__(256, 1) void stem_conv_bf16_row_kernel(const float* __restrict__ img, const float* __restrict__ w,
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_bf16_row_kernel(const float*
         *reinterpret_cast<uint2*>(pb + r * SR_ROWE + c) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(pb + SR_PLANE + r * SR_ROWE + c) = make_uint2(l0, l1);
     };
-    const int role = lq >> 1, k1 = lq & 1;                              // this lane's B source: plane, chunk parity
+    const int role = lq & 1, k1 = lq >> 1;                              // this lane's B source: plane, chunk parity (see SR_ROWE)
     // (Measured and not kept: the next patch's conversion + LDS writes one quad per k-step behind that step's MFMAs, with one or
     // two register stages -- 1.95 ms against 1.39 ms for the plain order below: at one wave per SIMD the interleaved VALU / LDS
     // traffic delays the MFMA issue more than the overlap returns.)
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_bf16_row_kernel(const float*
 // re-read.  Same MFMAs in the same order as the row kernel above, the same packs and the same maxima as stem_pool_kernel:
 // bit-identical pooled plane (tests/test_gpu_forward.py::test_fused_stem_pool_is_bit_identical; BOD_STEM_POOL_FUSED=0: separate).
 constexpr int SF_RING = 8;
-constexpr int SF_LDS_BYTES = SF_RING * 2 * SR_ROWE * 2 + 256 * 128;      // ring [8][hi / lo][1560] uint16 + tile [256 px][64 ch]
+constexpr int SF_LDS_BYTES = SF_RING * 2 * SR_ROWE * 2 + 256 * 128;      // ring [8][hi / lo][SR_ROWE] uint16 + tile [256 px][64 ch]
 
 __device__ __forceinline__ uint32_t sf_max(uint32_t a, uint32_t b) {
     uint32_t r;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256 * NCH, 1) void stem_pool_fused_kernel(const flo
     for (int ir = 0; ir < 7; ++ir)
         for (int q = tid; q < ROWQ; q += THREADS) commit_quad(ir, q, fetch_quad(ir, q));
     __syncthreads();
-    const int role = lq >> 1, k1 = lq & 1;                              // this lane's B source: plane, chunk parity
+    const int role = lq & 1, k1 = lq >> 1;                              // this lane's B source: plane, chunk parity (see SR_ROWE)
     stem_bf16x8_t aqr[11][FW];
 #pragma unroll
     for (int s = 0; s < 11; ++s)
