@@ -8,7 +8,8 @@ A forward starts at a stem kernel; its conv-family launches follow in plan order
 the fused kernel, flavour-1 ("raw") ops are not run by bod_infer, a split-K reduce belongs to the launch before it).  Times are the
 MEAN over the last forwards that match the plan; GB/s = algorithmic bytes / time (input pixels, outputs, shortcut and weights once),
 `hbm` = the time those bytes take at 4.6 TB/s (the copy rate tests/tools/hbm_rw_probe.hip measures on this part), `mfma` = the
-op's flops at 2.5 PFLOP/s.  The ratio column is time / max(hbm, mfma): what a perfect kernel for that op would still have to gain.
+op's flops at 2.5 PFLOP/s.  The ratio column is time / max(hbm, mfma): what a perfect kernel for that op would still have to gain;
+gap_us = idle time of the queue in front of the launch.
 """
 import re
 import sqlite3
@@ -71,23 +72,27 @@ def main():
         return
     good = good[-6:]
     print("# mean of the last %d forwards; bytes = algorithmic (in + out + shortcut + weights, once); hbm @ %.1f TB/s, mfma @ %.1f PFLOP/s" % (len(good), HBM / 1e12, MFMA / 1e15))
-    print("%-36s %-44s %9s %8s %8s %8s %8s %6s" % ("op", "kernel", "us", "GB/s", "TFLOP/s", "hbm_us", "mfma_us", "ratio"))
+    print("%-36s %-44s %9s %8s %8s %8s %8s %6s %7s" % ("op", "kernel", "us", "GB/s", "TFLOP/s", "hbm_us", "mfma_us", "ratio", "gap_us"))
     tot = tot_floor = 0.0
-    front = front_floor = 0.0
+    front = front_floor = front_gap = 0.0
     for i, o in enumerate(want):
         us = sum(sum(r[2] - r[1] for r in g[i]) for g in good) / len(good) / 1e3
+        # idle time of the queue in front of this launch: its start minus the previous launch's end
+        gap = sum(max(0, g[i][0][1] - g[i - 1][-1][2]) for g in good) / len(good) / 1e3 if i > 0 else 0.0
         k = short(good[-1][i][0][0])
         hbm_us = o["bytes"] / HBM * 1e6
         mfma_us = o["flops"] / MFMA * 1e6
         floor = max(hbm_us, mfma_us, 1e-9)
-        print("%-36s %-44s %9.1f %8.0f %8.1f %8.1f %8.1f %6.2f" % (o["name"][:36], k[:44], us, o["bytes"] / us / 1e3 if us else 0, o["flops"] / us / 1e6 if us else 0,
-                                                               hbm_us, mfma_us, us / floor))
+        print("%-36s %-44s %9.1f %8.0f %8.1f %8.1f %8.1f %6.2f %7.1f" % (o["name"][:36], k[:44], us, o["bytes"] / us / 1e3 if us else 0, o["flops"] / us / 1e6 if us else 0,
+                                                                     hbm_us, mfma_us, us / floor, gap))
         tot += us
         tot_floor += floor
         if "head_" not in o["name"] and not o["name"].startswith(("cls", "reg", "cov")):
             front += us
             front_floor += floor
+            front_gap += gap
     print("# stem + backbone + FPN launches: %.1f us, floors %.1f us; all launches %.1f us, floors %.1f us" % (front, front_floor, tot, tot_floor))
+    print("# queue idle between the stem + backbone + FPN launches (start of a launch - end of the one before): %.1f us in all" % front_gap)
 
 
 if __name__ == "__main__":
