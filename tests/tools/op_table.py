@@ -53,6 +53,14 @@ def main():
             cur.append(r)
         elif cur is not None and ("post_" in n or "nms" in n or "cluster" in n):
             cur = None
+    # idle time of the stream in front of each forward: the stem's start minus the end of the last kernel before it (any kernel of the
+    # process that is not on a side queue would do; the trace is in start order, so take the latest end among the earlier kernels)
+    step_gaps, latest_end = [], None
+    for r in rows:
+        if ("stem_conv" in r[0] or "stem_pool_fused" in r[0]) and latest_end is not None:
+            step_gaps.append((r[1] - latest_end) / 1e3)
+        if not any(k in r[0] for k in ("nms", "cluster")):        # (side-stream kernels of the previous batch overlap the next forward)
+            latest_end = r[2] if latest_end is None else max(latest_end, r[2])
     fused_stem = any("stem_pool_fused" in r[0] for r in rows)
     want = [o for o in ops if o["flavour"] != 1 and not (o["kind"] == 1 and fused_stem)]
     good = []
@@ -92,6 +100,9 @@ def main():
             front_floor += floor
             front_gap += gap
     print("# stem + backbone + FPN launches: %.1f us, floors %.1f us; all launches %.1f us, floors %.1f us" % (front, front_floor, tot, tot_floor))
+    if step_gaps:
+        print("# stream idle in front of a forward (stem start - end of the last main-stream kernel before it), last steps: %s us" %
+              ", ".join("%.0f" % g for g in step_gaps[-5:]))
     print("# queue idle between the stem + backbone + FPN launches (start of a launch - end of the one before): %.1f us in all" % front_gap)
 
 
