@@ -739,9 +739,8 @@ __device__ __forceinline__ float iou_plus1(const float4 p, const float4 q) {
 template <int C>
 __global__ __launch_bounds__(CL_BLOCK) void cluster_fuse_kernel(ClusterArgs a) {
     __shared__ float red[CL_BLOCK];
-    __shared__ float top_kl[CL_BLOCK * 3];
-    __shared__ int top_ix[CL_BLOCK * 3];
-    __shared__ int s_cnt;
+    __shared__ float top_kl[4 * 3];              // the four waves' three best (kl, anchor) each
+    __shared__ int top_ix[4 * 3];
     const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (k >= a.num_selected[b]) return;
     const int M = a.num_kept[b];
@@ -823,33 +822,66 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_fuse_kernel(ClusterArgs a) {
             }
         }
     }
-    // ---- block reductions
-    auto block_sum = [&](float v) -> float {
-        red[tid] = v;
-        __syncthreads();
-        for (int s = CL_BLOCK / 2; s > 0; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
-        const float r = red[0];
-        __syncthreads();
-        return r;
+    // ---- block reductions (round 4): wave-wide butterflies + one LDS exchange of the four waves' partials -- two barriers for all 15
+    // sums (the tree reduction per value they replace: 140), the global top-3 as three rounds of wave-wide arg-min + a 12-entry merge
+    // (replaced: one thread scanning 768 entries).  Sums are re-associated (fp32 round-off); the top-3 selection is exact.
+    const int wave = tid >> 6, lane = tid & 63;
+    auto wsum = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
     };
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    atomicAdd(&s_cnt, cnt);
+    {
+        float vals[15];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) psum[q] = block_sum(psum[q]);
+        for (int q = 0; q < 10; ++q) vals[q] = psum[q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pmsum[q] = block_sum(pmsum[q]);
-    const int total = s_cnt;
+        for (int q = 0; q < 4; ++q) vals[10 + q] = pmsum[q];
+        vals[14] = (float)cnt;                                  // (at most A < 2^24: exact)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { top_kl[tid * 3 + q] = tk[q]; top_ix[tid * 3 + q] = ti[q]; }
-    if (total <= 3) {
+        for (int q = 0; q < 15; ++q) {
+            const float r = wsum(vals[q]);
+            if (lane == 0) red[wave * 16 + q] = r;
+        }
+    }
+    // this wave's three best (kl asc, index asc) of its threads' sorted candidates
+    {
+        int p = 0;
 #pragma unroll
-        for (int j = 0; j < C; ++j) { ssum[j] = block_sum(ssum[j]); csum[j] = block_sum(csum[j]); }
+        for (int r = 0; r < 3; ++r) {
+            const float ck = p == 0 ? tk[0] : p == 1 ? tk[1] : p == 2 ? tk[2] : INFINITY;
+            const int ci = p == 0 ? ti[0] : p == 1 ? ti[1] : p == 2 ? ti[2] : 0x7fffffff;
+            float bk = ck; int bi = ci;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ok = __shfl_xor(bk, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ok < bk || (ok == bk && oi < bi))) { bk = ok; bi = oi; }
+            }
+            if (lane == 0) { top_kl[wave * 3 + r] = bk; top_ix[wave * 3 + r] = bi; }
+            if (bi != 0x7fffffff && ci == bi) ++p;              // (an anchor belongs to exactly one thread: the winner advances)
+        }
     }
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) psum[q] = (red[q] + red[16 + q]) + (red[32 + q] + red[48 + q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pmsum[q] = (red[10 + q] + red[26 + q]) + (red[42 + q] + red[58 + q]);
+    const int total = (int)((red[14] + red[30]) + (red[46] + red[62]));
+    if (total <= 3) {                                           // (block-uniform)
+        __syncthreads();                                        // every thread has read the first exchange
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float r0 = wsum(ssum[j]), r1 = wsum(csum[j]);
+            if (lane == 0) { red[wave * 16 + j] = r0; red[64 + wave * 16 + j] = r1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            ssum[j] = (red[j] + red[16 + j]) + (red[32 + j] + red[48 + j]);
+            csum[j] = (red[64 + j] + red[80 + j]) + (red[96 + j] + red[112 + j]);
+        }
+    }
     if (tid != 0) return;
     const size_t ob = (size_t)b * a.max_out + k;
     // fused Gaussian: cov = inv(sum prec), mean = cov * sum(prec*mean)  (:321-331), x70 (:361)
@@ -875,7 +907,7 @@ __global__ __launch_bounds__(CL_BLOCK) void cluster_fuse_kernel(ClusterArgs a) {
         // global top-3 over the per-thread candidates (:338-349)
         float bk[3] = {INFINITY, INFINITY, INFINITY};
         int bx[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-        for (int t = 0; t < CL_BLOCK * 3; ++t) {
+        for (int t = 0; t < 4 * 3; ++t) {                       // the four waves' three best each
             const float kl = top_kl[t]; const int ix = top_ix[t];
             if (ix == 0x7fffffff) continue;
             if (kl < bk[2] || (kl == bk[2] && ix < bx[2])) {
