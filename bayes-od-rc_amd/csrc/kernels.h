@@ -52,6 +52,10 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     // + bias + ReLU) of the SAME input tile -- a ConvBlock's `2a` riding on its projection shortcut `branch1` -- instead of one of
     // the finished output tile.
     int32_t ch_dual;
+    // f16mx precision (ConvArgs.mx != 0): 1 = this group's output rows leave in the tower format "hx" (conv_igemm.hip: per 64 channels
+    // 64 f16 hi + 128 bytes of e5m2 copies of hi and of lo * 2^12) for the next tower layer; 0 = (hi, lo) bf16 pairs (what the fused
+    // 1x1 + aggregation and every other consumer read)
+    int32_t out_hx;
 };
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
 
@@ -111,6 +115,10 @@ struct ConvArgs {
     // late, so that the ten-fold store bursts of the CUs' epilogues interleave with other CUs' main loops instead of all hitting HBM
     // at once (conv_igemm.hip).  0 = off.
     int32_t stagger_ticks;
+    // f16mx precision, head towers on the row-reuse loop (with `split`: same slot counts, same 1 KiB pixel rows): 1 = activations and
+    // weights in the hx format, one f16 product + one block-scaled e5m2 product (the two cross terms) per multiplication; 2 = (hi, lo)
+    // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer).  0 = off.
+    int32_t mx;
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
