@@ -29,6 +29,20 @@
 // pixel strides are given in slots); the product is hi*hi + hi*lo + lo*hi on the same MFMA (fp32 accumulate, the
 // lo*lo term is below 2^-16), i.e. six k-steps per K-tile instead of four: three times the MFMA work of bf16 mode for
 // twice the bytes, and fp32-class results (end-to-end 1e-3 against the float64 oracle) on the bf16 matrix pipe.
+//
+// f16mx precision (ConvArgs.mx, template value MXK; round 5) -- the parity mode's head towers at HALF the matrix-pipe time of bf16x3.
+// x = hi + lo with hi = f16(x) (11 bits): hi*hi is ONE f16 product, exact in the fp32 accumulator; the two cross terms hi*lo + lo*hi
+// need 3-4 bits only and go through the block-scaled MX pipe (v_mfma_scale_f32_32x32x64_f8f6f4 on e2m3 operands: four times the
+// f16 rate) as one product: per 16 channels a block of 32 elements {hi6, lo6'} (activations) against {lo6', hi6} (weights),
+// lo' = lo * 2^11 (|lo'| <= |hi|: one shared block scale 2^e, e = floor(log2(max * 16/15)) - 2, nothing saturates; the 2^-11 is
+// folded into the weights' scale byte).  1.5 bf16-product equivalents per multiplication instead of 3; per-layer error 1.3e-5 of the
+// output RMS against bf16x3's 4e-6 and the 1e-3 gate (tests/tools/tower_numerics.py; operand layout and sustained rates:
+// tests/tools/mx_probe.hip, profiles/round5_mx_probe.txt).  The "hx" row of a pixel / of a weight (cout, tap) keeps the bf16x3 row's
+// size and slot counts (4 bytes per channel): per 64 channels a 128-byte H chunk (64 f16 hi, natural order: the k-steps of an
+// f16 K-tile) and a 128-byte X chunk of four 32-byte slots (m, b) -- m = 32-channel half, b = MFMA K block = lane >> 5 -- split in
+// two 16-byte pieces at X offsets 64m + 16b and 64m + 32 + 16b (k-steps 2m, 2m+1 of the K-tile: the fragment reads of the loop are
+// the bf16 ones); a slot holds the 16 channels 32m + 8*g4 + 4b + r (the accumulator layout of a lane) as elements 2k = hi6 / lo6',
+// 2k+1 = lo6' / hi6 (k = 4*g4 + r; activations / weights), element e at bits [6e, 6e+6), and its scale byte at byte 28.
 #include "kernels.h"
 #include "philox.h"
 #include <cstdlib>
@@ -39,6 +53,15 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(6))) int i32x6;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16v;
+// the two 16-byte pieces of an MX operand (32 bytes per lane: 24 of e2m3 elements, the block's E8M0 scale in byte 28)
+__device__ __forceinline__ i32x8 mx_cat(const bf16x8& p0, const bf16x8& p1) {
+    return __builtin_shufflevector(__builtin_bit_cast(i32x4, p0), __builtin_bit_cast(i32x4, p1), 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -162,6 +185,22 @@ __device__ __forceinline__ void mfma16_inplace(f32x4& c, const bf16x8& a, const 
 #endif
 }
 
+// The block-scaled product of the f16mx X tiles, D = C tied in place like mfma16_inplace: the builtin form leaves the choice of the
+// destination to the register allocator, which moves the 32x32 accumulators through fresh tuples and spills them (844 bytes per
+// lane in the first build).  Sources come straight from LDS reads (no VALU write in front of the MFMA: kernel_guard checks).
+__device__ __forceinline__ void mfma_mx6_inplace(f32x16& c, const i32x6& a, const i32x6& b, const int sa, const int sb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#endif
+}
+
+// (the H tiles' f16 product in the same tied form: with the builtin in one branch and tied asm in the other the allocator spills)
+__device__ __forceinline__ void mfma_f16_32_inplace(f32x16& c, const bf16x8& a, const bf16x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+
 template <int FC, int FP, int ROWB>
 struct KTilePipe {
     const char* smem; int wa; int xb[FP];
@@ -232,6 +271,56 @@ struct KTilePipe {
                 for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // f16mx: an H tile (64 f16 hi per row: four f16 k-steps) or an X tile (the 64 channels' cross terms: two block-scaled e2m3
+    // products of K = 64, operands = the pieces of k-steps (2m, 2m+1), scale bytes inside the operands)
+    template <class XT>
+    __device__ __forceinline__ void run_hx(f32x16 (&acc)[FC][FP], XT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!XT::value) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 Bf[FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) { if (ks == 0) Bf[j] = Bc[j]; else Bf[j] = ldB(j, ks); }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    bf16x8 Af;
+                    if (ks == 0 && i < (FC == 4 ? 2 : FC)) Af = Ac[i]; else Af = ldA(i, ks);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        mfma_f16_32_inplace(acc[i][j], Af, Bf[j]);
+                }
+            }
+        } else {
+            // an operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read
+            // straight into a 6-register tuple and one scale register -- assembling it from two 16-byte reads costs copies and registers
+            // the 128 accumulators do not leave
+            auto ld6 = [&](int base, int m, int& sc) {
+                const char* p1 = smem + (base ^ ((2 * m + 1) << 5));
+                const i32x4 a = *reinterpret_cast<const i32x4*>(smem + (base ^ ((2 * m) << 5)));
+                const int2 b = *reinterpret_cast<const int2*>(p1);
+                sc = *reinterpret_cast<const int*>(p1 + 12);
+                i32x6 r;
+                r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b.x; r[5] = b.y;
+                return r;
+            };
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                i32x6 B6[FP];
+                int sb[FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) B6[j] = ld6(xb[j], m, sb[j]);
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    int sa;
+                    const i32x6 A6 = ld6(wa + i * 32 * ROWB, m, sa);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) mfma_mx6_inplace(acc[i][j], A6, B6[j], sa, sb[j]);
+                }
             }
         }
     }
@@ -388,9 +477,10 @@ __device__ __forceinline__ void agg_reduce_cov(const ConvGroup& G, const float* 
 }
 #pragma clang fp contract(fast)
 
-template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false>
+template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false, int MXK = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
     static_assert(!(SPLIT && ABL != 0), "the bf16x3 mode exists as production build only");
+    static_assert(MXK == 0 || (SPLIT && XR), "f16mx: the row-reuse loop of the (hi, lo) data path only");
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = THREADS;            // threads that stage
@@ -821,6 +911,57 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ar[0]), "+v"(Ar[1]), "+v"(Ar[2]), "+v"(Ar[3]), "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]), "+v"(Bc[0][3]),
                          "+v"(Bc[1][0]), "+v"(Bc[1][1]), "+v"(Bc[1][2]), "+v"(Bc[1][3]) :: "memory");
 #endif
+        } else if constexpr (MXK == 1) {
+            // ---- f16mx: the (hi, lo) loop's staging (top-of-K-tile barrier, next tile's pieces under the first fragment loads) with the
+            // K-tile flavour fixed per loop: chunk cc = 2p is the H chunk of 64-channel group p (f16 hi: four f16 k-steps), cc = 2p + 1 its
+            // X chunk (two block-scaled e2m3 products).  Three groups (ky) of one flavour, then three of the other, as two loops in
+            // sequence -- one body with a flavour branch per K-tile makes the register allocator spill accumulators (792 bytes per lane).
+            auto group = [&](const int g, auto XT) {
+                constexpr bool xt = decltype(XT)::value;
+                const bool xnext = g + 1 < NG;
+                const bool next_row = ky + 1 < 3;
+                const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
+#pragma unroll
+                for (int kxc = 0; kxc < 3; ++kxc) {
+                    const int kt = g * 3 + kxc;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const bool wnext = kt + 1 < KT;
+                    int woff;
+                    if (kxc < 2) woff = ((ky * 3 + kxc + 1) * a.cin + cc * BK) * 2;
+                    else woff = next_row ? (((ky + 1) * 3) * a.cin + cc * BK) * 2 : ((cc + 1) * BK) * 2;
+                    const int wdst = ((kt + 1) & 1) * WST;
+                    KTilePipe<FC, FP, ROWB> pipe;
+                    pipe.smem = smem;
+                    pipe.wa = (kt & 1) * WST + a_row;
+                    const int xbase = 2 * WST + (g & 1) * XBUF;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
+                    if constexpr (!xt) pipe.first_loads();
+                    if (wnext) {
+#pragma unroll
+                        for (int i = 0; i < NW; ++i) {
+                            int off = woff + i * wrs;
+                            asm volatile("" : "+s"(off));
+                            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + wdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                        }
+                    }
+                    if (xnext) {
+#pragma unroll
+                        for (int i = 0; i < NXE; ++i)
+                            if (i == 2 * kxc || i == 2 * kxc + 1) {
+                                xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
+                                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]), LDS_PTR(smem + xdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                            }
+                    }
+                    pipe.run_hx(acc, XT);
+                }
+                if (++ky == 3) { ky = 0; ++cc; }
+            };
+            for (int g0 = 0; g0 < NG; g0 += 6) {
+                for (int t = 0; t < 3; ++t) group(g0 + t, std::false_type{});
+                for (int t = 0; t < 3; ++t) group(g0 + 3 + t, std::true_type{});
+            }
         } else
         for (int g = 0; g < NG; ++g) {
             const bool xnext = g + 1 < NG;
@@ -1110,7 +1251,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
     }
 
-    if constexpr (M16) {
+    if constexpr (M16 || MXK == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last in-place MFMAs have retired before any VALU reads an accumulator
 #endif
@@ -1254,6 +1395,66 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int ro = s_res[pixl];
                 const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
                 const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
+                if constexpr (MXK != 0) {
+                    if (G.out_hx) {
+                        // ---- f16mx: the row leaves in the hx format (header of this file).  A lane's 16 channels of cout fragment i --
+                        // 32i + 8*g4 + 4*fhalf + r -- are exactly one MX block: f16 hi to the H chunk (4 x 8 bytes), then ONE
+                        // v_cvt_scalef32_2xpk16_fp6_f32 packs {hi6, lo6'} of the 16 channels (it interleaves its two sources) under the
+                        // block's scale, 24 bytes + the scale byte to the lane's slot of the X chunk.  Dropout zeroes the VALUES (the
+                        // fields of a 6-bit stream cannot be masked), same decisions as the pair form.
+                        static_assert(BC == 256 && WC == 2, "hx epilogue: 256-cout tile, two cout halves");
+#pragma unroll
+                        for (int i = 0; i < FC; ++i) {
+                            int fr_i = frow, fh_i = fhalf;
+#if defined(__HIP_DEVICE_COMPILE__)
+                            asm volatile("" : "+v"(fr_i), "+v"(fh_i));
+#endif
+                            const int lr = wp * WPP + jj * 32 + fr_i;
+                            char* prow = smem + lr * ROW2;
+                            const int col0 = wc * WTC + i * 32 + fh_i * 4;            // channel of (g4 = 0, r = 0)
+                            Philox4 rr{0u, 0u, 0u, 0u};
+                            if (drop) rr = philox4x32_10((uint32_t)rg.x, dropout_group16(bc0 + col0), sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
+                            f32x16v hv, lv;
+                            float mx = 6.103515625e-05f;                              // 2^-14: |lo'| of an f16-subnormal value stays below it
+                            const int q = col0 >> 6;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int col = col0 + g4 * 8;
+                                const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
+                                float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
+                                              __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
+                                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                                if (drop) {
+                                    const DropPair dw = dropout_run_windows(rr, g4);
+                                    const uint32_t thr = a.drop_threshold;
+                                    v[0] = (dw.x & 0xFFFFu) >= thr ? v[0] : 0.f; v[1] = (dw.x >> 16) >= thr ? v[1] : 0.f;
+                                    v[2] = (dw.y & 0xFFFFu) >= thr ? v[2] : 0.f; v[3] = (dw.y >> 16) >= thr ? v[3] : 0.f;
+                                }
+                                uint16_t hb[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const _Float16 hh = (_Float16)v[r];
+                                    hb[r] = __builtin_bit_cast(uint16_t, hh);
+                                    const float hf = (float)hh;
+                                    hv[g4 * 4 + r] = hf;
+                                    lv[g4 * 4 + r] = (v[r] - hf) * 2048.0f;
+                                    mx = fmaxf(mx, fabsf(v[r]));
+                                }
+                                const int c64 = col & 63, chH = q * 16 + (c64 >> 3);
+                                *reinterpret_cast<uint2*>(prow + (((chH ^ lr) & (CPR2 - 1)) << 4) + (c64 & 7) * 2) =
+                                    make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+                            }
+                            // block scale 2^e, e = floor(log2(max * 16/15)) - 2: the largest element lands in [2, 7.5]
+                            const uint32_t eb = (__float_as_uint(mx * 1.0666667f) >> 23) - 2u;      // biased exponent = the E8M0 byte
+                            const i32x6 pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(hv, lv, __uint_as_float(eb << 23));
+                            const int chX = q * 16 + 8 + ((col0 >> 5) & 1) * 4 + fh_i;
+                            *reinterpret_cast<uint4*>(prow + (((chX ^ lr) & (CPR2 - 1)) << 4)) = make_uint4((uint32_t)pk[0], (uint32_t)pk[1], (uint32_t)pk[2], (uint32_t)pk[3]);
+                            *reinterpret_cast<uint4*>(prow + ((((chX + 2) ^ lr) & (CPR2 - 1)) << 4)) = make_uint4((uint32_t)pk[4], (uint32_t)pk[5], 0u, eb);
+                            __builtin_amdgcn_sched_barrier(0);           // one fragment at a time (register pressure)
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < FC; ++i) {
                     Philox4 rr{0u, 0u, 0u, 0u};
@@ -2095,6 +2296,33 @@ __global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1))
     conv_tile<BC, BP, WC, WP, ABL, XR, SPLIT>(a, gz, bx, by, smem);
 }
 
+// f16mx precision (header of this file): the head towers' launches under their own symbol.  MXK 1: hx rows in -- per multiplication one
+// f16 product + half a block-scaled e2m3 product; MXK 2: (hi, lo) bf16 pairs in (the bf16x3 loop: the first tower layer reads the
+// pyramid).  Either writes hx rows or (hi, lo) pairs per group (ConvGroup.out_hx), fans out, fuses the 1x1 + aggregation.
+template <int MXK>
+__global__ __launch_bounds__(512, 1) void conv_igemm_mx_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bx = blockIdx.x;
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;      // XCD x owns a contiguous range of pixel tiles
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    conv_tile<256, 256, 2, 4, 0, true, true, MXK>(a, blockIdx.z, bx, 0, smem);
+}
+
+template <int MXK>
+static hipError_t launch_mx(const ConvArgs& a, hipStream_t s) {
+    using Cfg = ConvCfg<256, 256, 2, 4, true>;
+    static PerDeviceOnce once;
+    bool& attr_set = *once.slot();
+    auto kern = conv_igemm_mx_kernel<MXK>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.M + 255) / 256, 1, a.groups), dim3(Cfg::THREADS), Cfg::LDS, s, a);
+    return hipGetLastError();
+}
+
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
 // items, XCD x owning a contiguous eighth of them (neighbouring tiles share halo rows in that XCD's L2).  Removes the
 // workgroup retire / dispatch gap between tiles (measured with the phase clock: tiles cover 1.26-1.30 ms of a
@@ -2301,6 +2529,14 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
+    if (a.mx) {                                      // f16mx precision: head-tower launches on the row-reuse loop, whatever the tile heuristics say
+        if ((a.mx != 1 && a.mx != 2) || !a.split || a.xreuse != 2 || a.cout_pad != 256 || a.cin != 512 || a.taps != 9 || a.KW != 3 || !a.ext || a.M % 256 != 0 ||
+            (a.flags & (CONV_OUT_F32 | CONV_NT_OUT)) || a.ksplit > 1 || a.variant != 0 || a.groups < 1 || a.groups > 3)
+            return hipErrorInvalidValue;
+        for (int g = 0; g < a.groups; ++g)
+            if (a.g[g].res || a.g[g].out_relu || a.g[g].ch_w2 || a.g[g].ch_w3 || (a.g[g].w2 && (a.g[g].out_hx || a.fan_count > 1))) return hipErrorInvalidValue;
+        return a.mx == 1 ? launch_mx<1>(a, s) : launch_mx<2>(a, s);
+    }
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_pointwise_eligible(a)) return launch_conv_pointwise(a, s);   // streaming 1x1 kernel (bit-identical)
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_slide3x3_eligible(a)) return launch_conv_slide3x3(a, s);     // sliding-window 3x3, 64 -> 64 (bit-identical)

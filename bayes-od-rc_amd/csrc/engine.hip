@@ -63,6 +63,105 @@ uint16_t f2bf(float f) {
 }
 float bf2f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
+// ---- f16mx precision: the "hx" row of conv_igemm.hip (header there), packed on the host for weights (and for the test entry
+// point's activations): float -> IEEE half, round to nearest even, subnormals kept (the f16 MFMA honours them:
+// profiles/round5_mx_probe.txt)
+uint16_t f2h(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x47800000u) return (uint16_t)(sign | (u > 0x7F800000u ? 0x7E00u : 0x7C00u));      // >= 65536: inf (NaN stays NaN)
+    if (u < 0x38800000u) {                         // below 2^-14: subnormal half = round(|f| * 2^24)
+        float a; std::memcpy(&a, &u, 4);
+        return (uint16_t)(sign | (uint32_t)std::nearbyint(a * 16777216.0f));
+    }
+    u += 0xFFFu + ((u >> 13) & 1u);                // round the 13 dropped mantissa bits to nearest even
+    return (uint16_t)(sign | ((u - 0x38000000u) >> 13));      // (a mantissa carry runs into the exponent, up to inf, correctly)
+}
+float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    float f;
+    if (e == 0) { f = (float)m * (1.0f / 16777216.0f); uint32_t u; std::memcpy(&u, &f, 4); u |= sign; std::memcpy(&f, &u, 4); return f; }
+    const uint32_t u = sign | ((e == 31 ? 255u : e + 112u) << 23) | (m << 13);
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// e2m3 (OCP fp6, bias 1): round to nearest even, saturating at 7.5
+uint32_t f2e2m3(float x) {
+    const uint32_t sign = std::signbit(x) ? 32u : 0u;
+    const float a = std::fabs(x);
+    uint32_t code;
+    if (a < 1.0f) code = (uint32_t)std::nearbyint(a * 8.0f);
+    else if (a < 2.0f) code = 8u + (uint32_t)std::nearbyint((a - 1.0f) * 8.0f);
+    else if (a < 4.0f) code = 16u + (uint32_t)std::nearbyint((a - 2.0f) * 4.0f);
+    else code = 24u + (uint32_t)std::nearbyint((std::min(a, 7.5f) - 4.0f) * 2.0f);
+    return sign | std::min(code, 31u);
+}
+float e2m3_to_f(uint32_t c) {
+    const uint32_t e = (c >> 3) & 3u, m = c & 7u;
+    const float r = e == 0 ? m / 8.0f : std::ldexp(1.0f + m / 8.0f, (int)e - 1);
+    return (c & 32u) ? -r : r;
+}
+// One hx row: C channels (multiple of 64) -> 4 C bytes.  Per 64 channels: H chunk = 64 f16 hi; X chunk = four 32-byte slots (m, b),
+// pieces at X offsets 64m + 16b and 64m + 32 + 16b; a slot = the 16 channels 32m + 8 g4 + 4b + r as 32 e2m3 elements under one scale
+// 2^(eb - 127), eb = biased exponent of (max(|v|, 2^-14) * 16/15) - 2: element 2k = hi6 (weights: lo6'), 2k + 1 = lo6' (weights:
+// hi6), lo' = (v - hi) * 2^11; scale byte at byte 28 of the slot (weights: eb - 11, which undoes the 2^11 of both cross products).
+void pack_hx_row(const float* v, int C, uint8_t* dst, bool weights) {
+    std::memset(dst, 0, (size_t)C * 4);
+    for (int q = 0; q < C / 64; ++q) {
+        uint8_t* H = dst + (size_t)q * 256;
+        uint8_t* X = H + 128;
+        for (int c = 0; c < 64; ++c) { const uint16_t hb = f2h(v[q * 64 + c]); std::memcpy(H + 2 * c, &hb, 2); }
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < 2; ++b) {
+                float hi[16], lo[16], mx = 6.103515625e-05f;
+                for (int k = 0; k < 16; ++k) {
+                    const float x = v[q * 64 + 32 * m + 8 * (k >> 2) + 4 * b + (k & 3)];
+                    hi[k] = h2f(f2h(x)); lo[k] = (x - hi[k]) * 2048.0f;
+                    mx = std::max(mx, std::fabs(x));
+                }
+                const float mxs = mx * 1.0666667f;
+                uint32_t ub; std::memcpy(&ub, &mxs, 4);
+                const uint32_t eb = (ub >> 23) - 2u;
+                const float inv = std::ldexp(1.0f, 127 - (int)eb);
+                uint8_t slot[32] = {0};
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t h6 = f2e2m3(hi[k] * inv), l6 = f2e2m3(lo[k] * inv);
+                    const uint32_t e0 = weights ? l6 : h6, e1 = weights ? h6 : l6;
+                    const int bit0 = 12 * k;
+                    for (int t = 0; t < 6; ++t) {
+                        if ((e0 >> t) & 1u) slot[(bit0 + t) >> 3] |= (uint8_t)(1u << ((bit0 + t) & 7));
+                        if ((e1 >> t) & 1u) slot[(bit0 + 6 + t) >> 3] |= (uint8_t)(1u << ((bit0 + 6 + t) & 7));
+                    }
+                }
+                slot[28] = (uint8_t)(weights ? eb - 11u : eb);
+                std::memcpy(X + 64 * m + 16 * b, slot, 16);
+                std::memcpy(X + 64 * m + 32 + 16 * b, slot + 16, 16);
+            }
+    }
+}
+// ... and back (test entry point: the epilogue's hx output): value = hi + lo' * 2^-11 with lo' from the slot's odd elements
+void unpack_hx_row(const uint8_t* src, int C, float* v) {
+    for (int q = 0; q < C / 64; ++q) {
+        const uint8_t* H = src + (size_t)q * 256;
+        const uint8_t* X = H + 128;
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < 2; ++b) {
+                uint8_t slot[32];
+                std::memcpy(slot, X + 64 * m + 16 * b, 16);
+                std::memcpy(slot + 16, X + 64 * m + 32 + 16 * b, 16);
+                const float sc = std::ldexp(1.0f, (int)slot[28] - 127);
+                for (int k = 0; k < 16; ++k) {
+                    const int c = 32 * m + 8 * (k >> 2) + 4 * b + (k & 3);
+                    uint16_t hb; std::memcpy(&hb, H + 2 * c, 2);
+                    uint32_t l6 = 0;
+                    for (int t = 0; t < 6; ++t) l6 |= (uint32_t)((slot[(12 * k + 6 + t) >> 3] >> ((12 * k + 6 + t) & 7)) & 1u) << t;
+                    v[q * 64 + c] = h2f(hb) + e2m3_to_f(l6) * sc * (1.0f / 2048.0f);
+                }
+            }
+    }
+}
+
 }  // namespace
 
 struct bod_context {
@@ -104,6 +203,8 @@ struct bod_context {
     char* stem_out = nullptr;
     int es = 2;                                          // bytes per activation / weight CHANNEL (2 = bf16; 4 = fp32, or a (hi, lo) bf16 pair)
     bool split = false;                                  // bf16x3 precision: (hi, lo) bf16 pairs, three MFMA products (conv_igemm.hip)
+    bool plan_mx = false;                                // ... and the plan really runs them that way (BOD_TOWER_MX=0 / BOD_CONV_XREUSE=0: bf16x3 towers)
+    bool mx = false;                                     // f16mx precision: bf16x3 everywhere but the head towers, which run one f16 + half a block-scaled e2m3 product per multiplication (conv_igemm.hip header)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
     char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
     char* head_act_t[3][4] = {{nullptr}};            // training: one buffer per tower layer
@@ -267,8 +368,9 @@ const HostTensor* find_w(bod_context* h, const std::string& name, int kind) {
 
 // Fold BN (double), pack OHWI bf16 padded to cout_pad, upload.
 bod_status pack_conv(bod_context* h, const std::string& name, const std::string& bn, int cout_pad_to,
-                     PackedConv* out) {
-    auto it = h->packed.find(name);
+                     PackedConv* out, bool hx = false) {
+    const std::string ckey = hx ? name + ":hx" : name;             // (f16mx: tower layers 1.. are packed as hx rows, everything else as pairs)
+    auto it = h->packed.find(ckey);
     if (it != h->packed.end()) { *out = it->second; return BOD_OK; }
     const HostTensor* k = find_w(h, name, 0);
     if (!k || k->shape.size() != 4) return h->fail(BOD_ERR_NOT_READY, "missing conv kernel '%s'", name.c_str());
@@ -308,13 +410,23 @@ bod_status pack_conv(bod_context* h, const std::string& name, const std::string&
                 else w32[idx] = (float)v;
             }
     }
+    if (hx) {                                  // one hx row per (cout, tap): same bytes as the pair form
+        if (!h->split || cin % 64 != 0) return h->fail(BOD_ERR_INVALID_ARG, "hx weights need the (hi, lo) data path and cin %% 64 == 0");
+        std::vector<float> row(cin);
+        uint8_t* wb = reinterpret_cast<uint8_t*>(w.data());
+        for (int o = 0; o < cout; ++o)
+            for (int t = 0; t < pc.taps; ++t) {
+                for (int c = 0; c < cin; ++c) row[c] = (float)((double)k->data[((size_t)t * cin + c) * cout + o] * scale[o]);
+                pack_hx_row(row.data(), cin, wb + ((size_t)o * pc.taps + t) * cin * 4, true);
+            }
+    }
     BODCHK(h->dalloc(&pc.w, nw * h->es, false));
     BODCHK(h->dalloc(&pc.bias, bias.size(), false));
     HIPCHK(h, hipMemcpyAsync(pc.w, as_f32 ? (const void*)w32.data() : (const void*)w.data(), nw * h->es,
                              hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->packed[name] = pc;
+    h->packed[ckey] = pc;
     *out = pc;
     return BOD_OK;
 }
@@ -725,10 +837,14 @@ bod_status build_plan(bod_context* h) {
     RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
     bool xreuse = (h->es == 2 || h->split) && !train_mode;      // bf16 and bf16x3 (the per-sample tower layers; the fan-out layer of bf16x3 stays on the generic loop)
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
+    // f16mx precision: the towers' arithmetic exists in the row-reuse kernel only, which therefore runs them at every size (the tile
+    // heuristics below choose between kernels of equal results; here the kernel IS the arithmetic).  BOD_TOWER_MX=0: plain bf16x3 towers.
+    bool mx_plan = h->mx && xreuse;
+    if (const char* e = getenv("BOD_TOWER_MX")) mx_plan = mx_plan && atoi(e) != 0;
     {
         ConvArgs probe{};
         probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
-        xreuse = xreuse && conv_igemm_uses_full_cout_tile(probe);
+        xreuse = xreuse && (mx_plan || conv_igemm_uses_full_cout_tile(probe));
     }
     // rows -> 256-slot tiles of x-adjacent runs + each tile's extended input rows (kernels.h, ConvArgs::ext)
     static_assert(sizeof(ExtRow) == sizeof(int2), "ExtRow is the host-side twin of int2");
@@ -756,6 +872,7 @@ bod_status build_plan(bod_context* h) {
         probe.M = B * h->P; probe.cout_pad = 256; probe.fan_count = N; probe.flags = CONV_RELU | CONV_DROPOUT; probe.groups = c.has_covar_head ? 3 : 2;
         xreuse0 = xreuse0 && conv_igemm_uses_full_cout_tile(probe);
     }
+    if (mx_plan) xreuse0 = true;           // (the first tower layer writes the hx rows the next one reads)
     if (xreuse0) BODCHK(make_xr_tiles(t1, &d1x, &dext1, &m1x));
 
     const bool mc = train_mode || std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77); training: dropout on (:113-129)
@@ -773,7 +890,7 @@ bod_status build_plan(bod_context* h) {
     {
         ConvArgs probe{};
         probe.M = B * N * h->P; probe.cout_pad = 256; probe.fan_count = 1; probe.flags = CONV_RELU;
-        fuse_out = fuse_out && conv_igemm_uses_full_cout_tile(probe);
+        fuse_out = fuse_out && (mx_plan || conv_igemm_uses_full_cout_tile(probe));
     }
     // ---- MC aggregation fused into the last tower layers' epilogues (inference_utils.py:31-60,
     // :220-244): a tile of those layers must hold ALL N samples of its pixels, so they get their own row table -- tiles of
@@ -801,7 +918,7 @@ bod_status build_plan(bod_context* h) {
     } else {
         BODCHK(ensure_raw(h));                 // the ops below reference the raw tensors directly
     }
-    h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0;
+    h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0; h->plan_mx = mx_plan;
     // A layer's launch takes the sample-complete ("aggregated") tiling only for the heads that END there (fused 1x1 + MC aggregation): such
     // a tile holds 25 pixels x 10 samples = 250 of its 256 rows (240 at N = 30), so every other head's conv of that layer -- the
     // classification and covariance towers at layer 2 -- would pay 2.8 % (6 %) more MFMA work for nothing.  Round 4: those heads run the
@@ -821,7 +938,7 @@ bod_status build_plan(bod_context* h) {
             if (layer >= kHeadConvs[hd]) continue;
             if (split_launch && (part == 1) != (layer == kHeadConvs[hd] - 1)) continue;
             PackedConv pc;
-            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc));
+            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc, mx_plan && layer > 0));
             if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
                 return h->fail(BOD_ERR_INVALID_ARG, "head conv %s_%d must be 3x3 256->256", kHeadPrefix[hd], layer);
             op.wname[g] = std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer);
@@ -830,6 +947,7 @@ bod_status build_plan(bod_context* h) {
             cg.w = pc.w; cg.bias = pc.bias;
             cg.out = train_mode ? h->head_act_t[hd][layer] : h->head_act[hd][layer & 1];
             cg.layer_id = hd * 4 + layer;
+            cg.out_hx = (mx_plan && layer < kHeadConvs[hd] - 1) ? 1 : 0;      // read by the head's next tower layer: hx rows; a last layer feeds the 1x1: pairs
             if (fuse_out && layer == kHeadConvs[hd] - 1) {
                 PackedConv po;
                 BODCHK(pack_conv(h, kHeadPrefix[hd], "", 32, &po));
@@ -857,6 +975,7 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
+        a.mx = mx_plan ? (layer == 0 ? 2 : 1) : 0;
         if (xreuse0 && layer == 0) { a.rows = d1x; a.M = m1x; a.ext = dext1; a.xreuse = 2; }
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;
@@ -1306,10 +1425,11 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) return bail(h->fail(BOD_ERR_INVALID_ARG, "dropout_rate must be in [0,1)"));
     if (c.num_categorical_draws < 1 || c.num_categorical_draws > 1024) return bail(h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range"));
     if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
-    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32 && c.precision != BOD_PRECISION_BF16X3)
-        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0), BOD_PRECISION_FP32 (1) or BOD_PRECISION_BF16X3 (2)"));
+    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32 && c.precision != BOD_PRECISION_BF16X3 && c.precision != BOD_PRECISION_F16MX)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0), BOD_PRECISION_FP32 (1), BOD_PRECISION_BF16X3 (2) or BOD_PRECISION_F16MX (3)"));
     h->es = c.precision == BOD_PRECISION_BF16 ? 2 : 4;
-    h->split = c.precision == BOD_PRECISION_BF16X3;
+    h->split = c.precision == BOD_PRECISION_BF16X3 || c.precision == BOD_PRECISION_F16MX;
+    h->mx = c.precision == BOD_PRECISION_F16MX;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
     // BOD_MAIN_CUS_PER_XCD=k (development aid, tests/tools): the main stream owns only CU slots [0, k) of each of the 8 XCDs
     // (mask bit i = slot i / 8 of XCD i % 8: tests/tools/cu_mask_probe.hip)
@@ -1969,9 +2089,12 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           int32_t round_output_bf16, int32_t precision, float* out) {
     bod_context ctx;                      // scratch context: owns the temporary device buffers
     bod_context* h = &ctx;
-    const bool f32 = precision == BOD_PRECISION_FP32, x3 = precision == BOD_PRECISION_BF16X3;
+    const bool mxp = precision == BOD_PRECISION_F16MX;                 // f16mx tower kernel; round_output_bf16 = data path under test (bayesod.h)
+    const int mx_mode = mxp ? round_output_bf16 : 0;
+    const bool f32 = precision == BOD_PRECISION_FP32, x3 = precision == BOD_PRECISION_BF16X3 || mxp;
+    if (mxp) round_output_bf16 = 1;
     h->es = (f32 || x3) ? 4 : 2;
-    h->split = x3;
+    h->split = x3; h->mx = mxp;
     auto done = [&](bod_status s) {
         if (s != BOD_OK) g_create_error = h->err;
         if (h->stream) hipStreamSynchronize(h->stream);
@@ -1983,6 +2106,8 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
     if (!x || !w || !out || B < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || stride > 2)
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad argument"));
     if (precision != BOD_PRECISION_BF16 && !f32 && !x3) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad precision"));
+    if (mxp && (KH != 3 || KW != 3 || stride != 1 || !same_padding || Cin != 256 || Cout != 256 || residual || mx_mode < 0 || mx_mode > 2))
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: BOD_PRECISION_F16MX runs a head-tower layer (3x3, stride 1, SAME, 256 -> 256, no residual), round_output_bf16 in 0..2"));
     if (f32 && round_output_bf16) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: round_output_bf16 is meaningless in fp32 precision"));
     if (Cin % 64 != 0 || ((round_output_bf16 || (dropout_rate > 0.f && !f32)) && Cout % 4 != 0))
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: Cin must be a multiple of 64 (and Cout of 4 for bf16 output); got %d, %d", Cin, Cout));
@@ -2012,7 +2137,14 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         };
         std::vector<uint16_t> hx(f32 ? 0 : (size_t)B * in.bstride * Cin * (x3 ? 2 : 1), 0);
         std::vector<float> hx32(f32 ? (size_t)B * in.bstride * Cin : 0, 0.f);
-        for (int b = 0; b < B; ++b)
+        const bool hx_in = mxp && mx_mode != 2;
+        for (int b = 0; b < B && hx_in; ++b)
+            for (int y = 0; y < H; ++y)
+                for (int xx = 0; xx < W; ++xx) {
+                    const size_t pix = (size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1);
+                    pack_hx_row(x + (((size_t)b * H + y) * W + xx) * Cin, Cin, reinterpret_cast<uint8_t*>(hx.data()) + pix * Cin * 4, false);
+                }
+        for (int b = 0; b < B && !hx_in; ++b)
             for (int y = 0; y < H; ++y)
                 for (int xx = 0; xx < W; ++xx)
                     for (int c = 0; c < Cin; ++c) {
@@ -2045,7 +2177,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         h->host_w["stage/0"] = std::move(k);
         if (bias) { HostTensor bt; bt.shape = {Cout}; bt.data.assign(bias, bias + Cout); h->host_w["stage/1"] = std::move(bt); }
         PackedConv pc;
-        BODCHK(pack_conv(h, "stage", "", 64, &pc));
+        BODCHK(pack_conv(h, "stage", "", 64, &pc, hx_in));
         // dense fp32 / bf16 output [B,OH,OW,Cout]
         const bool drop = dropout_rate > 0.f;
         const size_t n_out = (size_t)B * OH * OW * Cout;
@@ -2071,6 +2203,20 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         HIPCHK(h, hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
         ConvArgs a = base_args(pc, d_rows, B * OH * OW, Cin, Cout);
         a.g[0] = ConvGroup{in.d, pc.w, pc.bias, f32_out ? (void*)d_out32 : (void*)d_out16, residual ? res.d : nullptr, nullptr, 0, layer_id, nullptr, nullptr, nullptr, 0, 0};
+        if (mxp) {                  // the tower kernel lives on the row-reuse loop: 256-slot tiles of x-adjacent runs + extended rows (plan_tables.h)
+            std::vector<RowEnt> tiled;
+            std::vector<ExtRow> ext;
+            if (!xr_tile_rows(rows, tiled, ext)) return h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: row-reuse tiling failed");
+            RowEnt* d_tiled = nullptr; int2* d_ext = nullptr;
+            BODCHK(h->dalloc(&d_tiled, tiled.size(), false));
+            BODCHK(h->dalloc(&d_ext, ext.size(), false));
+            HIPCHK(h, hipMemcpyAsync(d_tiled, tiled.data(), tiled.size() * sizeof(RowEnt), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(d_ext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            a.rows = d_tiled; a.M = (int)tiled.size(); a.ext = d_ext; a.xreuse = 2;
+            a.mx = mx_mode == 2 ? 2 : 1;
+            a.g[0].out_hx = mx_mode != 0;
+        }
         a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
         if (stride == 1 && same_padding && KH == 3 && KW == 3) { a.plane_h = OH; a.plane_w = OW; }      // (the sliding-window kernels walk planes)
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.image_base = image_id;
@@ -2092,7 +2238,9 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
             std::vector<uint16_t> ho(n_out * (x3 ? 2 : 1));
             HIPCHK(h, hipMemcpyAsync(ho.data(), d_out16, ho.size() * 2, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (x3) {
+            if (mxp && mx_mode != 0) {
+                for (size_t px = 0; px < n_out / Cout; ++px) unpack_hx_row(reinterpret_cast<const uint8_t*>(ho.data()) + px * Cout * 4, Cout, out + px * Cout);
+            } else if (x3) {
                 for (size_t px = 0; px < n_out / Cout; ++px)
                     for (int c = 0; c < Cout; ++c) {
                         const size_t slot = px * 2 * Cout + (size_t)(c >> 5) * 64 + (c & 31);
@@ -2453,6 +2601,7 @@ bod_status bod_plan_info(bod_handle h, int32_t* info8) {
     info8[0] = h->agg_plan; info8[1] = h->plan_fused_out; info8[2] = h->plan_xreuse; info8[3] = h->plan_xreuse0;
     info8[4] = (int32_t)h->ops.size();
     for (const Op& o : h->ops) if (o.kind == Op::CONV && !o.is_head3x3 && o.conv.xreuse) ++info8[5];
+    info8[6] = h->plan_mx;
     return BOD_OK;
 }
 

@@ -12,7 +12,7 @@ from ._lib import BodConfig, BodSizes, as_f32, fptr, iptr
 _KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
 # bod_config.precision (include/bayesod.h): bf16 = throughput path; fp32 = exact-fp32 MFMA; bf16x3 = (hi, lo) bf16 pairs with
 # three MFMA products, the 1e-3 end-to-end parity mode on the bf16 matrix pipe
-PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2}
+PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2, "f16mx": 3}
 
 
 def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
@@ -422,12 +422,12 @@ class Engine(object):
         return out
 
     def plan_info(self):
-        """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops', 'plane_row_reuse_layers'} of the forward plan
-        (bod_plan_info)."""
+        """{'aggregating', 'fused_head_outputs', 'row_reuse', 'fan_out_row_reuse', 'ops', 'plane_row_reuse_layers', 'tower_mx'} of the
+        forward plan (bod_plan_info)."""
         info = (C.c_int32 * 8)()
         self._chk(self.lib.bod_plan_info(self.h, info))
         return {"aggregating": bool(info[0]), "fused_head_outputs": bool(info[1]), "row_reuse": bool(info[2]),
-                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4]), "plane_row_reuse_layers": int(info[5])}
+                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4]), "plane_row_reuse_layers": int(info[5]), "tower_mx": bool(info[6])}
 
     @property
     def aggregating(self):
@@ -451,7 +451,8 @@ class Engine(object):
 def stage_conv(x, w, bias=None, stride=1, padding="same", relu=False, residual=None, dropout_rate=0.0,
                seed=0, layer_id=0, image_id=0, round_output_bf16=False, device=0, precision='bf16'):
     """One convolution through the pipeline's MFMA kernel (``bod_stage_conv``), for parity tests.
-    x [B,H,W,Cin], w HWIO; returns [B,OH,OW,Cout] float32."""
+    x [B,H,W,Cin], w HWIO; returns [B,OH,OW,Cout] float32.  precision='f16mx' (a head-tower layer: 3x3, SAME, 256 -> 256):
+    round_output_bf16 = 0 / 1 / 2 selects hx -> pairs / hx -> hx / pairs -> hx (include/bayesod.h)."""
     lib = _lib.load()
     x, w = as_f32(x), as_f32(w)
     b, h, wd, cin = x.shape

@@ -52,8 +52,12 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi64ELi128ELi1ELi4ELi0ELb0ELb1EE",
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi0ELb1ELb1EE",     # bf16x3 on the row-reuse loop (fused 1x1 + MC aggregation)
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi9ELb1ELb0EE",     # head towers on the round-2 loop (top-of-K-tile barrier): A/B twin, BOD_TOWER_MIDBAR=0
+    "conv_igemm_mx_kernelILi1EE",                              # f16mx precision: head towers, hx rows in (f16 + block-scaled e2m3 products, tied inline asm)
+    "conv_igemm_mx_kernelILi2EE",                              # f16mx precision: first tower layer ((hi, lo) pairs in, hx rows out)
 ]
-INLINE_ASM_MFMA = PRODUCTION[:3] + PRODUCTION[-1:]             # the kernels on the 16x16x32 inline-asm loop
+MX_ASM_MFMA = ["conv_igemm_mx_kernelILi1EE"]                   # ... whose two MFMA flavours are tied inline asm on the 32x32 accumulators
+MX_MFMA_RE = r"(?:v_mfma_scale_f32_32x32x64_f8f6f4|v_mfma_f32_32x32x16_f16)"
+INLINE_ASM_MFMA = PRODUCTION[:3] + PRODUCTION[12:13]           # the kernels on the 16x16x32 inline-asm loop
 INLINE_ASM_LDS = PRODUCTION[:3]                                # ... whose fragment reads and lgkmcnt waits are hand-written too (mid-tile barrier)
 
 
@@ -144,9 +148,12 @@ def _regs(tok):
 MFMA = "v_mfma_f32_16x16x32_bf16"
 
 
-def check_inline_asm_mfma(body, want, window=16, min_mfma=192):
-    """`body`: instruction list of one kernel.  Returns the number of MFMAs checked."""
-    mf = [i for i, l in enumerate(body) if l.startswith(MFMA)]
+def check_inline_asm_mfma(body, want, window=16, min_mfma=192, mfma_re=None):
+    """`body`: instruction list of one kernel.  Returns the number of MFMAs checked.  mfma_re: regex of the tied inline-asm MFMA
+    mnemonics (default: the 16x16x32 bf16 form of the tower loop)."""
+    MFMA = mfma_re or globals()["MFMA"]
+    is_mfma = (lambda l: re.match(MFMA, l) is not None) if mfma_re else (lambda l: l.startswith(MFMA))
+    mf = [i for i, l in enumerate(body) if is_mfma(l)]
     if len(mf) < min_mfma:                          # three unrolled K-tiles of 64
         raise GuardError("%s: only %d %s found (the loop changed shape: re-derive the guard)" % (want, len(mf), MFMA))
     for i in mf:
@@ -168,13 +175,13 @@ def check_inline_asm_mfma(body, want, window=16, min_mfma=192):
                 slots += 1
             k -= 1
         # (a) nothing but MFMAs on the same accumulator may touch the destination in the next `window` slots
-        dst = _regs(re.match(MFMA + r" (v\[\d+:\d+\])", body[i]).group(1))
+        dst = _regs(re.match((MFMA if mfma_re else re.escape(MFMA)) + r" (v\[\d+:\d+\])", body[i]).group(1))
         slots, k = 0, i + 1
         while k < len(body) and slots < window:
             l = body[k]
             mm = re.match(r"s_nop (\d+)", l)
             slots += int(mm.group(1)) + 1 if mm else 1
-            if not l.startswith(MFMA) and re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
+            if not is_mfma(l) and re.match(r"(v_|ds_|buffer_|global_|flat_)", l):
                 toks = re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l)
                 touched = set().union(*[_regs(t) for t in toks]) if toks else set()
                 if touched & dst:
@@ -322,6 +329,11 @@ def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
                 raise GuardError("kernel %s not found in the disassembly" % want)
             for n in names:
                 check_inline_asm_mfma(funcs[n], want)
+        for want in MX_ASM_MFMA:
+            if want in wanted:
+                for n in [n for n in funcs if want in n]:
+                    # (a K-tile: 32 f16 or 16 block-scaled MFMAs per wave; three unrolled K-tiles of each flavour)
+                    check_inline_asm_mfma(funcs[n], want, min_mfma=144, mfma_re=MX_MFMA_RE)
         if any(w in INLINE_ASM_LDS for w in asm_kernels):
             funcs_a = disassemble(co, with_addr=True)
             for want in INLINE_ASM_LDS:

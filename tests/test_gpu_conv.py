@@ -239,6 +239,77 @@ def test_bf16x3_split_k(monkeypatch, b, h, w, cin, cout, k, stride, padding, spl
     assert rel_err(got, ref, floor=float(np.sqrt((ref ** 2).mean()))) < 1e-4
 
 
+# ---------------------------------------------------------------------------------------------- f16mx precision (round 5)
+def _tower_case(rng, b, h, w):
+    """a head-tower layer's operands: ReLU'd, dropped-out activations (65 % zeros), he-normal weights"""
+    x = np.maximum(rng.normal(0, 1, (b, h, w, 256)), 0).astype(np.float32) * (rng.random((b, h, w, 256)) >= 0.3).astype(np.float32) / np.float32(0.7)
+    wt = (rng.normal(0, 1, (3, 3, 256, 256)) * np.sqrt(2.0 / (9 * 256))).astype(np.float32)
+    bias = rng.normal(0, 0.5, 256).astype(np.float32)
+    return x, wt, bias
+
+
+@pytest.mark.parametrize("mode,b,h,w", [(0, 2, 16, 16), (0, 1, 21, 37), (1, 2, 16, 16), (1, 3, 9, 13), (2, 2, 16, 16), (2, 1, 30, 7)])
+def test_f16mx_tower_layer_matches_oracle(mode, b, h, w):
+    """f16mx precision, one head-tower layer (multitask_headers.py:98-123: 3x3, 256 -> 256) on the f16mx kernel of the row-reuse loop
+    against float64 on the UNROUNDED fp32 operands: x = f16 hi + lo, hi*hi on v_mfma_f32_32x32x16_f16 (exact products), the cross
+    terms hi*lo + lo*hi as ONE block-scaled e2m3 product (v_mfma_scale_f32_32x32x64_f8f6f4; conv_igemm.hip header).  Per-layer
+    error 1.3e-5 rms / 7e-5 max of the output RMS on the CPU model of the arithmetic (tests/tools/tower_numerics.py): 1e-4 here,
+    the bf16x3 kernel's own gate.  mode 0: hx rows in, (hi, lo) pairs out (a head's last layer: exact to 2^-17); 1: hx in, hx out
+    (the decoded hx row carries f16 hi + e2m3 lo: 2^-14); 2: pairs in -- the bf16x3 loop -- hx out (the first layer).  Ragged
+    sizes: tiles with invalid slots, runs of x-adjacent pixels shorter than a tile."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(100 * mode + h + w)
+    x, wt, bias = _tower_case(rng, b, h, w)
+    got = stage_conv(x, wt, bias, padding="same", relu=True, precision="f16mx", round_output_bf16=mode)
+    ref = np.maximum(network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same"), 0)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    err = rel_err(got, ref, floor=rms)
+    print("f16mx mode %d %dx%dx%d: max |d| / (|ref| + rms) = %.2e" % (mode, b, h, w, err))
+    assert got.shape == ref.shape and np.all(got >= 0)
+    assert err < (1e-4 if mode == 0 else 2e-4)
+
+
+def test_f16mx_tower_layer_dropout_and_bf16x3_agreement():
+    """The head-tower dropout in the hx epilogue (values are zeroed before the split: the Philox contract's decisions, exact
+    zeros) and, on the same layer, agreement with the bf16x3 kernel (both within 1e-4 of float64, hence 2e-4 of each other)."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network, philox
+    rng = np.random.default_rng(77)
+    b, h, w = 3, 12, 20
+    x, wt, bias = _tower_case(rng, b, h, w)
+    conv = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same")
+    keep = np.stack([philox.dropout_keep_mask(11, 5, s, 6, h * w, 256, 0.3).reshape(h, w, 256) for s in range(b)])
+    ref = np.maximum(conv, 0) * np.float64(np.float32(1.0 / 0.7)) * keep
+    rms = float(np.sqrt((ref ** 2).mean()))
+    for mode in (0, 1, 2):
+        got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=0.3, seed=11, layer_id=6, image_id=5, precision="f16mx", round_output_bf16=mode)
+        assert np.all(got[~keep] == 0), mode
+        assert rel_err(got, ref, floor=rms) < (1e-4 if mode == 0 else 2e-4), mode
+    a = stage_conv(x, wt, bias, padding="same", relu=True, precision="f16mx", round_output_bf16=0)
+    c = stage_conv(x, wt, bias, padding="same", relu=True, precision="bf16x3", round_output_bf16=True)
+    assert rel_err(a, c, floor=float(np.sqrt((c.astype(np.float64) ** 2).mean()))) < 2e-4
+
+
+def test_f16mx_extreme_magnitudes():
+    """Blocks of tiny values (f16-subnormal range: the lo part carries them), of large ones, all-zero blocks and mixed signs in the
+    weights: the block scale follows the block's maximum, nothing saturates, zeros stay zeros."""
+    from bayes_od_rc_amd.engine import stage_conv
+    from oracle import network
+    rng = np.random.default_rng(5)
+    b, h, w = 1, 16, 16
+    x, wt, bias = _tower_case(rng, b, h, w)
+    scale = np.ones(256, np.float32)
+    scale[0:16] = 3e-6; scale[16:32] = 1e-3; scale[64:96] = 900.0; scale[128:144] = 0.0       # per-channel magnitudes of the input
+    x = x * scale
+    wt = wt * rng.choice([1e-3, 1.0, 30.0], size=(1, 1, 256, 1)).astype(np.float32)
+    ref = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same")
+    rms = float(np.sqrt((ref ** 2).mean()))
+    for mode in (0, 1):
+        got = stage_conv(x, wt, bias, padding="same", precision="f16mx", round_output_bf16=mode)
+        assert rel_err(got, ref, floor=rms) < 2e-4, mode
+
+
 @pytest.mark.parametrize("ch", [64, 128])
 def test_sliding_window_3x3_kernels_on_single_layers(ch):
     """The sliding-window 3x3 kernels of the backbone (conv_pointwise.hip: 64 -> 64 of stage 2, 128 -> 128 of stage 3 -- the latter
