@@ -5,12 +5,10 @@ import os
 
 import numpy as np
 
-# A handle drives up to five HIP streams (main, NMS / cluster side stream, upload stream; a training handle two weight-gradient
-# streams more) and the runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): streams that
-# share a queue serialise.  Measured on MI355X (docs/DESIGN_HISTORY.md A.1): the training step 11.2 -> 10.85 ms with 8 queues, 13.3 with
-# 2 -- and 13.4 with the default after other handles' streams had come and gone in the process; the inference headline does not move.
-# Only a default: an explicit GPU_MAX_HW_QUEUES wins, and it has no effect once another library has initialised HIP.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES: a handle drives up to five HIP streams -- a training handle seven -- which the runtime multiplexes onto that many
+# hardware queues (default 4).  Only the training step gains from 8 (docs/DESIGN_HISTORY.md A.1), and the variable changes queue
+# multiplexing for every HIP user of the process: it is a default of the ENTRY POINTS that benefit -- run_training.py, bench.py,
+# which records the effective value in its JSON line -- not of importing this package.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbayesod_hip.so")

@@ -276,29 +276,38 @@ struct KTilePipe {
     }
 
     // f16mx: an H tile (64 f16 hi per row: four f16 k-steps) or an X tile (the 64 channels' cross terms: two block-scaled e2m3
-    // products of K = 64, operands = the pieces of k-steps (2m, 2m+1), scale bytes inside the operands)
+    // products of K = 64, operands = the pieces of k-steps (2m, 2m+1), scale bytes inside the operands).  The MFMAs are tied inline
+    // asm (program order); the A operand of the NEXT cout fragment is requested in front of the current fragment's MFMAs
+    // (double-buffered), the next k-step's B operands behind the MFMAs of the current k-step's last cout fragment, one by one as
+    // each dies.
     template <class XT>
     __device__ __forceinline__ void run_hx(f32x16 (&acc)[FC][FP], XT) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!XT::value) {
+            bf16x8 Bf[FP], Af[2];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 Bf[FP];
+            for (int j = 0; j < FP; ++j) Bf[j] = Bc[j];
+            Af[0] = Ac[0];
 #pragma unroll
-                for (int j = 0; j < FP; ++j) { if (ks == 0) Bf[j] = Bc[j]; else Bf[j] = ldB(j, ks); }
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int i = 0; i < FC; ++i) {
-                    bf16x8 Af;
-                    if (ks == 0 && i < (FC == 4 ? 2 : FC)) Af = Ac[i]; else Af = ldA(i, ks);
+                    const int cur = (ks * FC + i) & 1;
+                    if (i + 1 < FC) { if (ks == 0 && i + 1 < (FC == 4 ? 2 : FC)) Af[cur ^ 1] = Ac[i + 1]; else Af[cur ^ 1] = ldA(i + 1, ks); }
+                    else if (ks + 1 < 4) Af[cur ^ 1] = ldA(0, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < FP; ++j)
-                        mfma_f16_32_inplace(acc[i][j], Af, Bf[j]);
+                    for (int j = 0; j < FP; ++j) {
+                        mfma_f16_32_inplace(acc[i][j], Af[cur], Bf[j]);
+                        if (i == FC - 1 && ks + 1 < 4) Bf[j] = ldB(j, ks + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
         } else {
             // an operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read
-            // straight into a 6-register tuple and one scale register -- assembling it from two 16-byte reads costs copies and registers
-            // the 128 accumulators do not leave
+            // straight into a 6-register tuple and one scale register.  (Two 16-byte reads into an 8-register tuple would be free of
+            // the 2- / 4-way bank conflicts of the 8- and 4-byte reads, but the MFMA wants a SIX-register operand: the compiler then
+            // builds it with v_mov copies right in front of the tied MFMA -- a VALU write of a source inside its two wait states.)
             auto ld6 = [&](int base, int m, int& sc) {
                 const char* p1 = smem + (base ^ ((2 * m + 1) << 5));
                 const i32x4 a = *reinterpret_cast<const i32x4*>(smem + (base ^ ((2 * m) << 5)));
@@ -308,20 +317,26 @@ struct KTilePipe {
                 r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b.x; r[5] = b.y;
                 return r;
             };
+            i32x6 B6[FP], A6[2];
+            int sb[FP], sa[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                i32x6 B6[FP];
-                int sb[FP];
+            for (int j = 0; j < FP; ++j) B6[j] = ld6(xb[j], 0, sb[j]);
+            A6[0] = ld6(wa, 0, sa[0]);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) B6[j] = ld6(xb[j], m, sb[j]);
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int i = 0; i < FC; ++i) {
-                    int sa;
-                    const i32x6 A6 = ld6(wa + i * 32 * ROWB, m, sa);
+                    const int cur = (m * FC + i) & 1;
+                    if (i + 1 < FC) A6[cur ^ 1] = ld6(wa + (i + 1) * 32 * ROWB, m, sa[cur ^ 1]);
+                    else if (m == 0) A6[cur ^ 1] = ld6(wa, 1, sa[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) mfma_mx6_inplace(acc[i][j], A6, B6[j], sa, sb[j]);
+                    for (int j = 0; j < FP; ++j) {
+                        mfma_mx6_inplace(acc[i][j], A6[cur], B6[j], sa[cur], sb[j]);
+                        if (i == FC - 1 && m == 0) B6[j] = ld6(xb[j], 1, sb[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
         }
     }
 
@@ -924,8 +939,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
                 for (int kxc = 0; kxc < 3; ++kxc) {
                     const int kt = g * 3 + kxc;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
+                    // This K-tile needs its weights (and, in a group's first K-tile, the group's extended rows) -- NOT the next group's extended
+                    // rows that went out behind the weights during the group's first two K-tiles (HBM / Infinity Cache: a microsecond under
+                    // load; a K-tile here is half as long as the bf16x3 loop's).  Loads retire in order: the wait leaves exactly those pieces
+                    // outstanding -- three behind the first K-tile's weights, two behind the second's.
+                    if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if (xnext && kxc == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
                     const bool wnext = kt + 1 < KT;
                     int woff;
                     if (kxc < 2) woff = ((ky * 3 + kxc + 1) * a.cin + cc * BK) * 2;
@@ -938,20 +959,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
 #pragma unroll
                     for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
                     if constexpr (!xt) pipe.first_loads();
+                    // (LDS-DMA pieces as buffer_load_dwordx4 ... lds -- resource in SGPRs, one 32-bit lane offset, scalar piece offset -- like the
+                    // bf16 tower loop: the issue parks the wave for fewer cycles than global_load_lds_dwordx4, and a K-tile here has half the
+                    // MFMA time to hide it in)
                     if (wnext) {
 #pragma unroll
                         for (int i = 0; i < NW; ++i) {
                             int off = woff + i * wrs;
                             asm volatile("" : "+s"(off));
-                            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wbase + off), LDS_PTR(smem + wdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + wdst + (i * THREADS + wave * 64) * 16), 16, (int)wlane, off, 0, 0);
                         }
                     }
                     if (xnext) {
 #pragma unroll
                         for (int i = 0; i < NXE; ++i)
-                            if (i == 2 * kxc || i == 2 * kxc + 1) {
+                            if ((kxc == 0 && i < 3) || (kxc == 1 && i >= 3)) {      // pieces 0..2 in the group's first K-tile, 3..4 in its second
                                 xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
-                                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(in_base + xo[i]), LDS_PTR(smem + xdst + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(smem + xdst + (i * THREADS + wave * 64) * 16), 16, (int)xo[i], 0, 0, 0);
                             }
                     }
                     pipe.run_hx(acc, XT);
@@ -1376,8 +1400,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         // (uniform: the Philox key schedule -- 20 values -- stays in scalar registers)
         rng_seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng_seed_lo);
         rng_seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng_seed_hi);
-        // (row-reuse launches never fan out in this mode -- launch_conv_igemm refuses it: no sample loop there, so that nothing
-        // loop-invariant is hoisted in front of the passes, where all 128 accumulators are live)
+        // (the fan-out launch of this mode runs on the row-reuse loop too since round 4 -- xreuse == 2 with fan_count > 1: the sample
+        // loop below re-runs both passes per sample; kernel_guard's no-spill check covers that build, <256,256,2,4,0,true,true>, and
+        // the f16mx kernels)
         const int fan = (drop && a.fan_count > 1) ? a.fan_count : 1;
         const uint32_t thr_m1 = a.drop_threshold > 0 ? a.drop_threshold - 1u : 0u;
         const uint32_t thr_m1_x2 = thr_m1 | (thr_m1 << 16);

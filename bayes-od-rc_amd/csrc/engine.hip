@@ -255,6 +255,7 @@ struct bod_context {
     bool side_pending[2] = {false, false};
     char* host_stage[2] = {nullptr, nullptr};     // pinned host copy of a slot's records (filled on the side stream)
     float* rec_send = nullptr; float* rec_recv = nullptr; size_t rec_recv_elems = 0;      // bod_gather_detections: packed records, gathered blocks
+    hipEvent_t ev_gather = nullptr; hipStream_t gather_stream = nullptr;                  // last use of rec_send / rec_recv and the stream it went to
     void select_slot(int sidx) {
         slot = sidx;
         nms_sel = nms_sel_s[sidx]; nms_nsel = nms_nsel_s[sidx];
@@ -835,7 +836,7 @@ bod_status build_plan(bod_context* h) {
     // Activation row reuse for the per-sample 3x3 tower layers: re-pack the rows into 256-slot tiles made
     // of runs of x-adjacent pixels and list each tile's extended input rows (kernels.h, ConvArgs::ext).
     RowEnt* d2x = nullptr; int2* dext = nullptr; int m2x = 0;
-    bool xreuse = (h->es == 2 || h->split) && !train_mode;      // bf16 and bf16x3 (the per-sample tower layers; the fan-out layer of bf16x3 stays on the generic loop)
+    bool xreuse = (h->es == 2 || h->split) && !train_mode;      // bf16, bf16x3 and f16mx: the per-sample tower layers (and, `xreuse0` below, the fan-out layer) on the row-reuse loop
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
     // f16mx precision: the towers' arithmetic exists in the row-reuse kernel only, which therefore runs them at every size (the tile
     // heuristics below choose between kernels of equal results; here the kernel IS the arithmetic).  BOD_TOWER_MX=0: plain bf16x3 towers.
@@ -1161,8 +1162,13 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         if (h->l0_pending[par]) { HIPCHK(h, hipStreamWaitEvent(fs, h->ev_l0_done[par], 0)); h->l0_pending[par] = false; }
     }
     if (!only_flavoured) h->pyr_last = par;
-    const int cus_front = ov && h->overlap_mode == 1 ? h->ov_front_slots * 8 : h->n_cu;
-    const int cus_back = ov && h->overlap_mode == 1 ? (h->ov_slots - h->ov_front_slots) * 8 : h->n_cu;
+    // Kernel CHOICES (sliding-window / pointwise / fused-stem eligibility: launch_conv_igemm, workgroups against compute units) are made
+    // against the WHOLE chip on every stream: a CU-masked front stream that chose by its own 32 CUs ran other kernels than bod_infer
+    // and a serial handle at mid-size batches (64 frames at 512x512: 64 column strips >= 32 take slide3x3_c128, which re-associates one
+    // fp32 add per output, < 256 do not) and broke the header's "bit-identical to the serial pipeline" (round-4 advisor finding).  The
+    // overlap mode is an opt-in A/B switch that measured slower: the contract wins over its planner.
+    const int cus_front = h->n_cu;
+    const int cus_back = h->n_cu;
     // BOD_TRACE_OPS=k: the k-th forward call is traced op by op (HIP events on the engine stream) and a table
     // is printed to stderr -- a development aid (tests/tools), off by default.
     static const int trace_call = getenv("BOD_TRACE_OPS") ? atoi(getenv("BOD_TRACE_OPS")) : 0;
@@ -1505,6 +1511,7 @@ bod_status bod_destroy(bod_handle h) {
     for (int sidx = 0; sidx < 2; ++sidx) if (h->host_stage[sidx]) hipHostFree(h->host_stage[sidx]);
     if (h->rec_recv && h->rec_recv != h->rec_send) hipFree(h->rec_recv);
     if (h->rec_send) hipFree(h->rec_send);
+    if (h->ev_gather) hipEventDestroy(h->ev_gather);
     for (void* p : h->allocs) hipFree(p);
     if (h->iou_scratch) hipFree(h->iou_scratch);
     if (h->affinity) hipFree(h->affinity);
@@ -2562,6 +2569,9 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     }
     if (!h->rec_send && hipMalloc(reinterpret_cast<void**>(&h->rec_send), block * 4) != hipSuccess)
         return h->fail(BOD_ERR_OOM, "bod_gather_detections: %zu bytes", block * 4);
+    // rec_send / rec_recv are shared by the ticket gathers (side stream) and the synchronous form (main stream): a gather that goes to
+    // the other stream than the previous one waits for it -- nothing else orders the two streams against each other (round-4 advisor finding)
+    if (h->ev_gather && h->gather_stream && h->gather_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_gather, 0));
     HIPCHK(h, launch_pack_records(h->nms_nsel_s[sidx], h->out_scores_s[sidx], h->out_means_s[sidx], h->out_covs_s[sidx],
                                   h->out_counts_s[sidx], h->rec_send, B, K, C, st));
     float* recv = nullptr;
@@ -2583,10 +2593,15 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
         const int rc = rccl().gather(h->rec_send, recv, block, /*ncclFloat32*/ 7, root, nccl_comm, st);
         if (rc != 0) return h->fail(BOD_ERR_HIP, "ncclGather: %s", rccl().errstr ? rccl().errstr(rc) : "error");
     }
+    if (!h->ev_gather) HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
     if (rank == root && gathered_host) {
         HIPCHK(h, hipMemcpyAsync(gathered_host, recv, block * world * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipEventRecord(h->ev_gather, st)); h->gather_stream = st;
         HIPCHK(h, hipStreamSynchronize(st));
-    } else if (slot >= 0) {
+    } else {
+        HIPCHK(h, hipEventRecord(h->ev_gather, st)); h->gather_stream = st;
+    }
+    if (!(rank == root && gathered_host) && slot >= 0) {
         // keep bod_collect / the next bod_infer_async of this slot behind the send: re-record the slot's event
         HIPCHK(h, hipEventRecord(h->ev_done[slot], st));
     }

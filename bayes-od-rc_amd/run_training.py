@@ -12,6 +12,11 @@ import argparse
 import os
 import time
 
+# the training step is a chain of ~1 200 small launches on three streams: 8 hardware queues instead of the runtime's 4 keep its
+# weight-gradient streams from sharing a queue with the main one (11.2 -> 10.85 ms, docs/DESIGN_HISTORY.md A.1).  Set by this entry
+# point, before HIP initialises; an explicit GPU_MAX_HW_QUEUES wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 from . import config_utils, constants, synthetic

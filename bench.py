@@ -30,6 +30,11 @@ import traceback
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP runtime: hardware queues the process's streams are multiplexed onto (default 4).  The training step of `secondary` gains from 8
+# (docs/DESIGN_HISTORY.md A.1; the inference headline does not move); set here, before anything initialises HIP, and recorded in the
+# JSON line (`config.gpu_max_hw_queues`).  An explicit GPU_MAX_HW_QUEUES wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 
 ANCHOR_CFG = {"layers": [3, 4, 5, 6, 7], "aspect_ratios": [[1.0, 1.0], [1.0, 2.0], [2.0, 1.0]],
@@ -468,7 +473,7 @@ def main():
     ap.add_argument("--forward-only", action="store_true",
                     help="time RetinaNetModel.call only (BASELINE config 2: raw head outputs); implied by --mc 1, "
                          "where the Bayesian stages are undefined (sample covariance divides by N-1)")
-    ap.add_argument("--precision", choices=("bf16", "fp32", "bf16x3"), default="bf16",
+    ap.add_argument("--precision", choices=("bf16", "fp32", "bf16x3", "f16mx"), default="bf16",
                     help="bf16 = throughput path (BASELINE.json north_star); bf16x3 = its 1e-3 end-to-end parity mode; "
                          "fp32 = exact-fp32 MFMA")
     ap.add_argument("--train-step-probe", type=int, default=None, metavar="DEVICE",
@@ -687,6 +692,9 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             layers = "layers 0-3 (N = 1: no fan-out launch)"
         kernel_name = "conv_igemm_kernel<256,256,2,4,0,true%s> (head towers, 3x3 256->256, %s; mid-tile-barrier loop)" % (
             ",SPLIT: 3 MFMA products per MAC" if args.precision == "bf16x3" else "", layers)
+        if args.precision == "f16mx" and eng.plan_info()["tower_mx"]:
+            kernel_name = ("conv_igemm_mx_kernel<1> (head towers, 3x3 256->256, %s; f16mx: one f16 product + half a block-scaled e2m3 product "
+                           "per multiplication = 1.5 bf16-product equivalents)" % layers)
     else:                                # no row-reuse kernel in the plan (fp32 / bf16x3 mode, BOD_CONV_XREUSE=0): all head 3x3 launches, three extra steps
         prof_steps = max(1, min(3, args.steps))
         eng.profile_begin(which=0)
@@ -694,6 +702,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         prof = eng.profile_end()
         algo_flops = head_flops_per_image(eng.P, n) * B * prof_steps
         kernel_name = {"fp32": "conv_igemm_f32_kernel", "bf16x3": "conv_igemm_kernel<..., SPLIT> (3 MFMA products per MAC)",
+                       "f16mx": "conv_igemm_kernel<..., SPLIT> (3 MFMA products per MAC; BOD_TOWER_MX=0)",
                        "bf16": "conv_igemm_kernel"}[args.precision] + " (head towers, 3x3 256->256)"
     if abs(prof["head_conv_flops"] - algo_flops) / algo_flops > 1e-6:       # the plan fused the 1x1 output convs into these launches
         algo_flops += n * out_flops * B * prof_steps
@@ -707,7 +716,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         more_steps(3)
         fo = eng.profile_end()
         if fo["head_conv_launches"] > 0:
-            fan_out = {"kernel": "conv_igemm_kernel<256,256,2,4,5,true> (tower layer 0, %d-way dropout fan-out)" % n,
+            fan_out = {"kernel": ("conv_igemm_mx_kernel<2>" if args.precision == "f16mx" else "conv_igemm_kernel<256,256,2,4,5,true>") + " (tower layer 0, %d-way dropout fan-out)" % n,
                        "achieved": round(fo["head_conv_flops"] / (fo["head_conv_ms"] * 1e-3) / 1e12, 2),
                        "avg_launch_ms": round(fo["head_conv_ms"] / fo["head_conv_launches"], 4), "launches_per_step": 1}
         eng.profile_begin(which=0)
@@ -742,6 +751,8 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                 "share_of_step": round(prof["head_conv_ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
     if args.precision == "bf16x3":
         roofline["mfma_issue_tflops"] = round(3 * achieved, 2)
+    if args.precision == "f16mx":
+        roofline["mfma_issue_tflops_bf16_equivalent"] = round(1.5 * achieved, 2)
     if fan_out:
         roofline["other_head_launch"] = fan_out
         # "the conv heads" as a whole: the de-duplicated 3 + 8 N head convs and the N 1x1 sets of a step = the tower launches of
@@ -774,11 +785,11 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                                     "full BayesOD pipeline (forward+posterior+soft-NMS+cluster-fuse)"),
                      "frames_per_gpu_per_step": B, "global_batch": world * B, "mc_samples": n,
                      "anchors": eng.A, "kept_anchors_M": [int(k) for k in kept[:4]],
-                     "parallelism": "image-sharded x%d, one RCCL gather/step" % world,
+                     "parallelism": ("image-sharded x%d, one RCCL gather/step" % world) if world > 1 else "one GPU (no exchange; N > 1: image-sharded, one RCCL gather/step)",
                      "per_rank_images_per_sec": [round(v, 1) for v in per_rank],
                      # valid detections in the records rank 0 received from each rank in the last gathered step (N > 1 path)
                      "gathered_detections_per_rank": ([int(g[:, :, 0].sum().item()) for g in gathered] if gathered is not None else None),
-                     "visible_gpus": torch.cuda.device_count(),
+                     "visible_gpus": torch.cuda.device_count(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                      # posterior launches only; the default run (extras) replaces both fields with the stage's full cost: posterior +
                      # the A/B-measured share of the tower launches that is the fused MC aggregation (see below)
                      "per_anchor_covariance_latency_ns": round(post_us_per_anchor * 1e3, 4),

@@ -155,6 +155,43 @@ def test_async_pipeline_equals_synchronous():
                 assert np.array_equal(a[key][img, :k], b[key][img, :k])
 
 
+def test_overlapped_pipeline_equals_serial_at_mid_size_batches(monkeypatch):
+    """Round-4 advisor finding: the CU-masked front stream chose its kernels by ITS OWN compute units (32), the serial pipeline by the
+    chip's 256 -- at 64 frames of 512 x 512 stage 3 has 64 column strips: >= 32 took the 128-channel sliding-window kernel (one fp32
+    add re-associated per output), < 256 the generic one, and the overlapped handle was no longer bit-identical to the serial one
+    (the small test below has no launch between the two thresholds).  Kernel choices are now made against the whole chip on every
+    stream (engine.hip run_forward): same pyramid, same detections, bit for bit."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, n, batch = (512, 512), 2, 64
+    weights = synthetic.make_weights(cls_fg_bias=-1.0)
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=12)
+    got = []
+    for overlap in (False, True):
+        if overlap:
+            monkeypatch.setenv("BOD_OVERLAP", "1")
+        e = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True, pipeline_overlap=overlap))
+        if overlap:
+            monkeypatch.delenv("BOD_OVERLAP")
+        e.load_weights(weights)
+        e.set_anchors(anchors)
+        e.upload_images(frames)
+        s0 = e.infer_async(None, seed=3, first_image_id=0)
+        s1 = e.infer_async(None, seed=3, first_image_id=batch)
+        d0 = {k: v.copy() for k, v in e.collect(s0).items()}
+        d1 = {k: v.copy() for k, v in e.collect(s1).items()}
+        got.append((d0, d1, e.get_pyramid(2).copy()))
+        e.close()
+    assert got[0][0]["num"].sum() > 0
+    for a, b in ((got[0][0], got[1][0]), (got[0][1], got[1][1])):
+        assert np.array_equal(a["num"], b["num"])
+        for key in ("scores", "means", "covs", "counts"):
+            assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(got[0][2], got[1][2])
+
+
 @pytest.mark.parametrize("mode", ["cu_masks", "plain_streams"])
 def test_overlapped_pipeline_equals_serial(mode, monkeypatch):
     """bod_config.pipeline_overlap: the front (stem, backbone, FPN) of batch i+1 on its own CU-partitioned stream underneath the
@@ -235,7 +272,7 @@ def test_overlapped_pipeline_equals_serial(mode, monkeypatch):
     serial.close(); ov.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
 def test_fp32_pipeline_matches_oracle_end_to_end(precision):
     """fp32 / bf16x3 precision modes, whole pipeline against the float64 oracle run from the raw frame.  EVERY image goes through
     every stage comparison -- nothing is skipped:
