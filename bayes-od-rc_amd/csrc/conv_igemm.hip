@@ -201,6 +201,100 @@ __device__ __forceinline__ void mfma_f16_32_inplace(f32x16& c, const bf16x8& a, 
 #endif
 }
 
+// f16mx: an H tile (64 f16 hi per row: four f16 k-steps) or an X tile (the 64 channels' cross terms: two block-scaled e2m3 products of
+// K = 64, operands = the pieces of k-steps (2m, 2m+1), scale bytes inside the operands) of the row-reuse loop.  `wa` / `xb[j]`: LDS byte
+// offsets of the lane's A / B fragment rows incl. the swizzled chunk of k-step 0 (KTilePipe); `wa_n` / `xb_n`: the NEXT K-tile's.
+//  * The MFMAs are tied inline asm (program order).  The A operand of the next cout-fragment step is requested in front of the current
+//    step's MFMAs (double-buffered), the next k-step's B operands behind the MFMAs of the current k-step's last step, one by one as each dies.
+//  * ONE barrier per K-tile, in front of the LAST step's MFMAs (`sync()`: the caller's vmcnt wait + s_barrier): by then every LDS read of
+//    this K-tile has returned -- its weight stage is free for the K-tile after next -- and the next K-tile's pieces have landed, so its
+//    first operands (`HxCarry`) are requested right behind the barrier, under the last step's MFMAs, and the K-tile boundary itself has
+//    neither a barrier nor an exposed LDS round trip (phase clock of the top-of-K-tile form: 845 of 2 380 cycles per K-tile with no wave of
+//    the SIMD issuing an MFMA; the bf16 tower loop's "barrier two fragment steps before the K-tile's end", compiler-scheduled reads here).
+//  * `slot(k, wr)`, k = 0..7, behind the MFMAs of every (second, in an H tile) step -- k = 7 behind the barrier: the caller issues one
+//    LDS-DMA piece there (destination = wr + offset), so that the issue (60-185 cycles with the wave parked) runs under in-flight MFMAs.
+//  * `rd` and `wr` are the SAME LDS block, declared __restrict__: every read of this function goes through `rd`, every LDS-DMA destination
+//    through `wr`, and they never overlap between two barriers (the stage / extended-row buffer being read against the ones being filled)
+//    -- without that the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows an LDS-DMA issue (it cannot tell the
+//    stages apart): a full L2 / HBM round trip with the matrix pipe idle per piece.
+template <int FP>
+struct HxCarry {                 // the first step's operands of a K-tile, requested during the K-tile before
+    bf16x8 hA, hB[FP];
+    i32x6 xA, xB[FP];
+    int xsa, xsb[FP];
+};
+template <int FC, int FP, int ROWB, bool XT, bool NXT, class SYNC, class SLOT>
+__device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __restrict__ rd, char* __restrict__ wr, const int wa, const int (&xb)[FP],
+                                         const int wa_n, const int (&xb_n)[FP], const bool has_next, HxCarry<FP>& c, SYNC&& sync, SLOT&& slot) {
+    auto ldH = [&](int base, int ks) { return *reinterpret_cast<const bf16x8*>(rd + (base ^ (ks << 5))); };
+    // an X operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read straight
+    // into a 6-register tuple and one scale register.  The 8- and 4-byte reads run 2- / 4-way bank conflicts (rows r and r + 16 of a
+    // 32-lane group: 42 % of the kernel's LDS cycles); the conflict-free alternative -- two 16-byte reads, registers 4, 5 copied into
+    // the SIX-register operand the MFMA wants, `s_nop 1` in front of the MFMA for the copies' two wait states -- measured 3 % SLOWER on
+    // the towers on two boxes (199 / 205 ms against 193.6 per 256 frames): the copies and their waits cost more than the conflicts.
+    auto ld6 = [&](int base, int m, int& sc) {
+        const char* p1 = rd + (base ^ ((2 * m + 1) << 5));
+        const i32x4 a = *reinterpret_cast<const i32x4*>(rd + (base ^ ((2 * m) << 5)));
+        const int2 b = *reinterpret_cast<const int2*>(p1);
+        sc = *reinterpret_cast<const int*>(p1 + 12);
+        i32x6 r;
+        r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b.x; r[5] = b.y;
+        return r;
+    };
+    // X tiles: the A operand double-buffered (requested one step ahead; single-buffered measured 3 % slower on the towers)
+    constexpr bool XA2 = true;
+    auto next_A = [&]() { if constexpr (NXT) c.xA = ld6(wa_n, 0, c.xsa); else c.hA = ldH(wa_n, 0); };
+    auto next_B = [&](int j) { if constexpr (NXT) c.xB[j] = ld6(xb_n[j], 0, c.xsb[j]); else c.hB[j] = ldH(xb_n[j], 0); };
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!XT) {
+        constexpr int NIT = 4 * FC;
+        bf16x8 Bf[FP], Af[2];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) Bf[j] = c.hB[j];
+        Af[0] = c.hA;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ks = it / FC, i = it % FC, cur = it & 1;
+            if (it + 1 < NIT) Af[cur ^ 1] = ldH(wa + ((it + 1) % FC) * 32 * ROWB, (it + 1) / FC);
+            if (it == NIT - 1) { sync(); if (has_next) next_A(); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                mfma_f16_32_inplace(acc[i][j], Af[cur], Bf[j]);
+                if (i == FC - 1 && ks + 1 < 4) Bf[j] = ldH(xb[j], ks + 1);
+                if (it == NIT - 1 && has_next) next_B(j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (it & 1) slot(it >> 1, wr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        constexpr int NIT = 2 * FC;
+        i32x6 B6[FP], A6[2];
+        int sb[FP], sa[2];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) { B6[j] = c.xB[j]; sb[j] = c.xsb[j]; }
+        A6[0] = c.xA; sa[0] = c.xsa;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = it / FC, i = it % FC, cur = XA2 ? (it & 1) : 0;
+            if (XA2) { if (it + 1 < NIT) A6[cur ^ 1] = ld6(wa + ((it + 1) % FC) * 32 * ROWB, (it + 1) / FC, sa[cur ^ 1]); }
+            else if (it > 0) A6[0] = ld6(wa + i * 32 * ROWB, m, sa[0]);
+            if (it == NIT - 1) { sync(); if (has_next) next_A(); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                mfma_mx6_inplace(acc[i][j], A6[cur], B6[j], sa[cur], sb[j]);
+                if (i == FC - 1 && m == 0) B6[j] = ld6(xb[j], 1, sb[j]);
+                if (it == NIT - 1 && has_next) next_B(j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            slot(it, wr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int FC, int FP, int ROWB>
 struct KTilePipe {
     const char* smem; int wa; int xb[FP];
@@ -272,71 +366,6 @@ struct KTilePipe {
 #pragma unroll
                 for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[j], acc[i][j], 0, 0, 0);
             }
-        }
-    }
-
-    // f16mx: an H tile (64 f16 hi per row: four f16 k-steps) or an X tile (the 64 channels' cross terms: two block-scaled e2m3
-    // products of K = 64, operands = the pieces of k-steps (2m, 2m+1), scale bytes inside the operands).  The MFMAs are tied inline
-    // asm (program order); the A operand of the NEXT cout fragment is requested in front of the current fragment's MFMAs
-    // (double-buffered), the next k-step's B operands behind the MFMAs of the current k-step's last cout fragment, one by one as
-    // each dies.
-    template <class XT>
-    __device__ __forceinline__ void run_hx(f32x16 (&acc)[FC][FP], XT) {
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!XT::value) {
-            bf16x8 Bf[FP], Af[2];
-#pragma unroll
-            for (int j = 0; j < FP; ++j) Bf[j] = Bc[j];
-            Af[0] = Ac[0];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    const int cur = (ks * FC + i) & 1;
-                    if (i + 1 < FC) { if (ks == 0 && i + 1 < (FC == 4 ? 2 : FC)) Af[cur ^ 1] = Ac[i + 1]; else Af[cur ^ 1] = ldA(i + 1, ks); }
-                    else if (ks + 1 < 4) Af[cur ^ 1] = ldA(0, ks + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) {
-                        mfma_f16_32_inplace(acc[i][j], Af[cur], Bf[j]);
-                        if (i == FC - 1 && ks + 1 < 4) Bf[j] = ldB(j, ks + 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        } else {
-            // an operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read
-            // straight into a 6-register tuple and one scale register.  (Two 16-byte reads into an 8-register tuple would be free of
-            // the 2- / 4-way bank conflicts of the 8- and 4-byte reads, but the MFMA wants a SIX-register operand: the compiler then
-            // builds it with v_mov copies right in front of the tied MFMA -- a VALU write of a source inside its two wait states.)
-            auto ld6 = [&](int base, int m, int& sc) {
-                const char* p1 = smem + (base ^ ((2 * m + 1) << 5));
-                const i32x4 a = *reinterpret_cast<const i32x4*>(smem + (base ^ ((2 * m) << 5)));
-                const int2 b = *reinterpret_cast<const int2*>(p1);
-                sc = *reinterpret_cast<const int*>(p1 + 12);
-                i32x6 r;
-                r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b.x; r[5] = b.y;
-                return r;
-            };
-            i32x6 B6[FP], A6[2];
-            int sb[FP], sa[2];
-#pragma unroll
-            for (int j = 0; j < FP; ++j) B6[j] = ld6(xb[j], 0, sb[j]);
-            A6[0] = ld6(wa, 0, sa[0]);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    const int cur = (m * FC + i) & 1;
-                    if (i + 1 < FC) A6[cur ^ 1] = ld6(wa + (i + 1) * 32 * ROWB, m, sa[cur ^ 1]);
-                    else if (m == 0) A6[cur ^ 1] = ld6(wa, 1, sa[cur ^ 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) {
-                        mfma_mx6_inplace(acc[i][j], A6[cur], B6[j], sa[cur], sb[j]);
-                        if (i == FC - 1 && m == 0) B6[j] = ld6(xb[j], 1, sb[j]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
         }
     }
 
@@ -496,6 +525,11 @@ template <int BC, int BP, int WC, int WP, int ABL, bool XR, bool SPLIT = false, 
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const int bx, const int by, char* smem) {
     static_assert(!(SPLIT && ABL != 0), "the bf16x3 mode exists as production build only");
     static_assert(MXK == 0 || (SPLIT && XR), "f16mx: the row-reuse loop of the (hi, lo) data path only");
+    // the f16mx loop; 11 = its phase-clock twin (tests/tools/bench_head_conv.py variant 90), 12 = the same without the loop's LDS-DMA (variant 91)
+    constexpr bool MXL = MXK == 1 || MXK == 11 || MXK == 12;
+    constexpr bool MXI = MXK == 11 || MXK == 12;
+    unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0;
+    if constexpr (MXI) mx_t0 = __builtin_amdgcn_s_memtime();
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
     constexpr int LTHREADS = THREADS;            // threads that stage
@@ -926,65 +960,107 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ar[0]), "+v"(Ar[1]), "+v"(Ar[2]), "+v"(Ar[3]), "+v"(Bc[0][0]), "+v"(Bc[0][1]), "+v"(Bc[0][2]), "+v"(Bc[0][3]),
                          "+v"(Bc[1][0]), "+v"(Bc[1][1]), "+v"(Bc[1][2]), "+v"(Bc[1][3]) :: "memory");
 #endif
-        } else if constexpr (MXK == 1) {
-            // ---- f16mx: the (hi, lo) loop's staging (top-of-K-tile barrier, next tile's pieces under the first fragment loads) with the
-            // K-tile flavour fixed per loop: chunk cc = 2p is the H chunk of 64-channel group p (f16 hi: four f16 k-steps), cc = 2p + 1 its
-            // X chunk (two block-scaled e2m3 products).  Three groups (ky) of one flavour, then three of the other, as two loops in
-            // sequence -- one body with a flavour branch per K-tile makes the register allocator spill accumulators (792 bytes per lane).
-            auto group = [&](const int g, auto XT) {
+        } else if constexpr (MXL) {
+            // ---- f16mx: the K-tile flavour is fixed per loop -- chunk cc = 2p is the H chunk of 64-channel group p (f16 hi: four f16
+            // k-steps), cc = 2p + 1 its X chunk (two block-scaled e2m3 products): three groups (ky) of one flavour, then three of the other, as
+            // two loops in sequence (one body with a flavour branch per K-tile makes the register allocator spill accumulators: 792 bytes
+            // per lane).  Barrier inside the K-tile, first operands carried across its boundary, LDS-DMA pieces in the slots of the MFMA
+            // stream: hx_ktile.  Schedule of the pieces (buffer_load_dwordx4 ... lds: resource in SGPRs, one 32-bit lane offset, scalar piece
+            // offset -- the issue parks the wave for fewer cycles than global_load_lds_dwordx4): the stage K-tile kt read is free behind
+            // ITS barrier, so weight piece 0 of K-tile kt + 2 goes out in slot 7 of kt and pieces 1..3 in slots 0..2 of kt + 1; the next
+            // group's extended rows in slots 3..5 -- pieces 0..2 in the group's first K-tile, 3..4 in its second (HBM / Infinity Cache: a
+            // microsecond under load).  The wait in front of the barrier of kt needs the weights of kt + 1, not the extended rows issued
+            // behind them in this K-tile: loads retire in order, vmcnt(3) / vmcnt(2) leaves exactly those outstanding.
+            auto woff_of = [&](const int kt) {          // K-tile kt = tap kt % 9 of chunk kt / 9 (chunk outer, ky, kx inner)
+                const int ch = kt / 9, tap = kt - ch * 9;
+                return (tap * a.cin + ch * BK) * 2;
+            };
+            auto dma_w = [&](const int piece, const int kt_, char* __restrict__ wr) {
+                int off = woff_of(kt_) + piece * wrs;
+                asm volatile("" : "+s"(off));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, off, 0, 0);
+            };
+            HxCarry<FP> carry;
+            // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); piece 0 of K-tile 1 behind them
+            if (KT > 1 && MXK != 12) dma_w(0, 1, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            {
+                carry.hA = *reinterpret_cast<const bf16x8*>(smem + a_row);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) { const int r = xrow[j]; carry.hB[j] = *reinterpret_cast<const bf16x8*>(smem + 2 * WST + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4)); }
+            }
+            auto group = [&](const int g, auto XT, auto LASTB) {
                 constexpr bool xt = decltype(XT)::value;
-                const bool xnext = g + 1 < NG;
+                constexpr bool last_of_block = decltype(LASTB)::value;          // the next group has the other flavour
+                const bool xnext = g + 1 < NG && MXK != 12;
                 const bool next_row = ky + 1 < 3;
                 const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
-#pragma unroll
-                for (int kxc = 0; kxc < 3; ++kxc) {
+                auto ktile = [&](auto KXC) {
+                    constexpr int kxc = decltype(KXC)::value;
+                    constexpr bool nxt = (kxc == 2 && last_of_block) ? !xt : xt;
                     const int kt = g * 3 + kxc;
-                    // This K-tile needs its weights (and, in a group's first K-tile, the group's extended rows) -- NOT the next group's extended
-                    // rows that went out behind the weights during the group's first two K-tiles (HBM / Infinity Cache: a microsecond under
-                    // load; a K-tile here is half as long as the bf16x3 loop's).  Loads retire in order: the wait leaves exactly those pieces
-                    // outstanding -- three behind the first K-tile's weights, two behind the second's.
-                    if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else if (xnext && kxc == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-                    const bool wnext = kt + 1 < KT;
-                    int woff;
-                    if (kxc < 2) woff = ((ky * 3 + kxc + 1) * a.cin + cc * BK) * 2;
-                    else woff = next_row ? (((ky + 1) * 3) * a.cin + cc * BK) * 2 : ((cc + 1) * BK) * 2;
-                    const int wdst = ((kt + 1) & 1) * WST;
-                    KTilePipe<FC, FP, ROWB> pipe;
-                    pipe.smem = smem;
-                    pipe.wa = (kt & 1) * WST + a_row;
-                    const int xbase = 2 * WST + (g & 1) * XBUF;
+                    const bool has_next = kt + 1 < KT;
+                    // (the lane's row offsets re-derived behind an opaque barrier per K-tile: otherwise every (stage, buffer, tap, k-step)
+                    // variant of the fragment addresses -- loop-invariant, some seventy registers -- is hoisted out of the loop and the
+                    // kernel spills)
+                    int a_row_ = a_row, xrow_[FP];
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) { const int r = xrow[j] + kxc; pipe.xb[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4); }
-                    if constexpr (!xt) pipe.first_loads();
-                    // (LDS-DMA pieces as buffer_load_dwordx4 ... lds -- resource in SGPRs, one 32-bit lane offset, scalar piece offset -- like the
-                    // bf16 tower loop: the issue parks the wave for fewer cycles than global_load_lds_dwordx4, and a K-tile here has half the
-                    // MFMA time to hide it in)
-                    if (wnext) {
+                    for (int j = 0; j < FP; ++j) xrow_[j] = xrow[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(a_row_));
 #pragma unroll
-                        for (int i = 0; i < NW; ++i) {
-                            int off = woff + i * wrs;
-                            asm volatile("" : "+s"(off));
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + wdst + (i * THREADS + wave * 64) * 16), 16, (int)wlane, off, 0, 0);
-                        }
+                    for (int j = 0; j < FP; ++j) asm volatile("" : "+v"(xrow_[j]));
+#endif
+                    const int wa_ = (kt & 1) * WST + a_row_, wa_n = ((kt + 1) & 1) * WST + a_row_;
+                    const int xbase = 2 * WST + (g & 1) * XBUF, xbase_n = kxc < 2 ? xbase : 2 * WST + ((g + 1) & 1) * XBUF;
+                    int xb_[FP], xb_n[FP];
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) {
+                        const int r = xrow_[j] + kxc, rn = kxc < 2 ? r + 1 : xrow_[j];
+                        xb_[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4);
+                        xb_n[j] = xbase_n + rn * ROWB + ((fhalf ^ ((rn >> 1) & 7)) << 4);
                     }
-                    if (xnext) {
-#pragma unroll
-                        for (int i = 0; i < NXE; ++i)
-                            if ((kxc == 0 && i < 3) || (kxc == 1 && i >= 3)) {      // pieces 0..2 in the group's first K-tile, 3..4 in its second
-                                xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(smem + xdst + (i * THREADS + wave * 64) * 16), 16, (int)xo[i], 0, 0, 0);
+                    unsigned long long mx_tb = 0;
+                    if constexpr (MXI) mx_tb = __builtin_amdgcn_s_memtime();
+                    hx_ktile<FC, FP, ROWB, xt, nxt>(acc, smem, smem, wa_, xb_, wa_n, xb_n, has_next, carry,
+                        [&]() {
+                            unsigned long long ta = 0;
+                            if constexpr (MXI) ta = __builtin_amdgcn_s_memtime();
+                            if (xnext && kxc == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                            else if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+                            if constexpr (MXI) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); mx_t_wait += tb - ta; mx_tb += tb - ta; }
+                        },
+                        [&](const int k, char* __restrict__ wr) {
+                            if (MXK == 12) return;
+                            if (k == 7) { if (kt + 2 < KT) dma_w(0, kt + 2, wr); }
+                            else if (k < 3) { if (kt + 1 < KT) dma_w(k + 1, kt + 1, wr); }
+                            else if (xnext && k < 6 && kxc < 2) {
+                                const int i = kxc == 0 ? k - 3 : k;          // pieces 0..2 | 3..4
+                                if (i < NXE) {
+                                    xo[i] += next_row ? (uint32_t)xp[i] : (uint32_t)(BK * 2 - 2 * xp[i]);
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(wr + xdst + (i * THREADS + wave * 64) * 16), 16, (int)xo[i], 0, 0, 0);
+                                }
                             }
-                    }
-                    pipe.run_hx(acc, XT);
-                }
+                        });
+                    if constexpr (MXI) mx_t_body += __builtin_amdgcn_s_memtime() - mx_tb;
+                };
+                ktile(std::integral_constant<int, 0>{}); ktile(std::integral_constant<int, 1>{}); ktile(std::integral_constant<int, 2>{});
                 if (++ky == 3) { ky = 0; ++cc; }
             };
             for (int g0 = 0; g0 < NG; g0 += 6) {
-                for (int t = 0; t < 3; ++t) group(g0 + t, std::false_type{});
-                for (int t = 0; t < 3; ++t) group(g0 + 3 + t, std::true_type{});
+                group(g0, std::false_type{}, std::false_type{}); group(g0 + 1, std::false_type{}, std::false_type{}); group(g0 + 2, std::false_type{}, std::true_type{});
+                group(g0 + 3, std::true_type{}, std::false_type{}); group(g0 + 4, std::true_type{}, std::false_type{}); group(g0 + 5, std::true_type{}, std::true_type{});
+            }
+            if constexpr (MXI) {
+                if (threadIdx.x == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    atomicAdd(&g_phase_cycles[6], mx_t_wait); atomicAdd(&g_phase_cycles[7], mx_t_body);
+                    atomicAdd(&g_phase_cycles[8], now - mx_t0); atomicAdd(&g_phase_cycles[15], 1ull);
+                    mx_t0 = now;
+                }
             }
         } else
         for (int g = 0; g < NG; ++g) {
@@ -1275,7 +1351,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         }
     }
 
-    if constexpr (M16 || MXK == 1) {
+    if constexpr (M16 || MXL) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last in-place MFMAs have retired before any VALU reads an accumulator
 #endif
@@ -2330,7 +2406,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_mx_kernel(const ConvArgs a)
     int bx = blockIdx.x;
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;      // XCD x owns a contiguous range of pixel tiles
     bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    unsigned long long t0 = 0;
+    if constexpr (MXK == 11 || MXK == 12) t0 = __builtin_amdgcn_s_memtime();
     conv_tile<256, 256, 2, 4, 0, true, true, MXK>(a, blockIdx.z, bx, 0, smem);
+    if constexpr (MXK == 11 || MXK == 12) { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[9], __builtin_amdgcn_s_memtime() - t0); }      // whole tile incl. epilogue
 }
 
 template <int MXK>
@@ -2556,10 +2635,12 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     if (a.mx) {                                      // f16mx precision: head-tower launches on the row-reuse loop, whatever the tile heuristics say
         if ((a.mx != 1 && a.mx != 2) || !a.split || a.xreuse != 2 || a.cout_pad != 256 || a.cin != 512 || a.taps != 9 || a.KW != 3 || !a.ext || a.M % 256 != 0 ||
-            (a.flags & (CONV_OUT_F32 | CONV_NT_OUT)) || a.ksplit > 1 || a.variant != 0 || a.groups < 1 || a.groups > 3)
+            (a.flags & (CONV_OUT_F32 | CONV_NT_OUT)) || a.ksplit > 1 || (a.variant != 0 && a.variant != 90 && a.variant != 91) || a.groups < 1 || a.groups > 3)
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g)
             if (a.g[g].res || a.g[g].out_relu || a.g[g].ch_w2 || a.g[g].ch_w3 || (a.g[g].w2 && (a.g[g].out_hx || a.fan_count > 1))) return hipErrorInvalidValue;
+        if (a.variant == 90 && a.mx == 1) return launch_mx<11>(a, s);          // phase clock (tests/tools/bench_head_conv.py)
+        if (a.variant == 91 && a.mx == 1) return launch_mx<12>(a, s);          // ... without the loop's LDS-DMA
         return a.mx == 1 ? launch_mx<1>(a, s) : launch_mx<2>(a, s);
     }
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();

@@ -10,7 +10,7 @@ from bayes_od_rc_amd.engine import Engine, make_config
 
 variants = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else None) for v in sys.argv[1:]] or [(0, None)]
 B = int(os.environ.get("B", "8"))
-eng = Engine(make_config((512, 512), batch=B, mc_samples=10))
+eng = Engine(make_config((512, 512), batch=B, mc_samples=10, precision=os.environ.get("PRECISION", "bf16")))
 eng.load_weights(synthetic.make_weights())
 eng.upload_images(synthetic.make_frames(B, 512, 512))
 eng.forward(None)          # real (random-data) activations in the buffers
