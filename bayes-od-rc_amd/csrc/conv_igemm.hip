@@ -2627,8 +2627,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // launches +0.5 ms beside it (net 0); bit 1 costs the towers 1 % and the fan-out launch 4 %: the outputs are re-read by the next
     // launch's neighbouring tiles through L2 after all.  Kept as an A/B switch.
     static const int nt_stores = getenv("BOD_NT_STORES") ? atoi(getenv("BOD_NT_STORES")) : 0;
+    // bit 2 (round 5): the fan-out launch ALONE -- its ten masked copies (42.9 GB per 512 frames) are what pushes the three heads' weights
+    // and the shared pyramid rows out of L2 (11.2 GB fetched for 1.4 GB algorithmic, profiles/round4_head_conv_pmc.json launch 0)
     if (!(a_local.flags & CONV_OUT_F32) && !a_local.split && a_local.ksplit <= 1 &&
-        (((nt_stores & 1) && !a_local.xreuse) || ((nt_stores & 2) && a_local.xreuse)))
+        (((nt_stores & 1) && !a_local.xreuse) || ((nt_stores & 2) && a_local.xreuse) || ((nt_stores & 4) && a_local.xreuse && a_local.fan_count > 1)))
         a_local.flags |= CONV_NT_OUT;
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;

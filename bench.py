@@ -14,8 +14,10 @@ only inter-GPU traffic is one RCCL gather of the final detection records per ste
 The ONE JSON line carries, beside the headline (bf16, BASELINE config 3):
   roofline       the dominant kernel's achieved TFLOP/s from HIP events inside the timed region
   cpu_baseline   the CPU port timed on this host (rank 0, N=1 only)
-  parity_mode    the bf16x3 precision mode -- the throughput path's 1e-3 end-to-end mode -- timed in the same run, with
-                 its max relative error against the CPU port's fp32 forward of the same frame and Philox masks
+  parity_mode    the f16mx precision mode -- the throughput path's 1e-3 end-to-end mode (round 5: head towers on one f16 + half a
+                 block-scaled e2m3 product per multiplication) -- timed in the same run, with its max relative error against the CPU
+                 port's fp32 forward of the same frame and Philox masks and the detection-level distance over every frame of the CPU
+                 leg; parity_mode_bf16x3: the bf16x3 mode of rounds 2-4 beside it
   secondary      BASELINE configs 2 (N=1 forward), 4's geometry (384x1248, N=30, one GPU) and 5 (ResNet-101 training step)
   value_with_h2d the headline with the uint8 frames crossing PCIe every step (copy stream, overlapped with the convolutions)
 """
@@ -49,6 +51,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # f32-in MFMA = fp32 vector rate (fp32 precis
 # at 512x512 with synthetic.make_weights() (python bench.py --calibrate)
 CALIBRATED_FG_BIAS = -3.2
 METRIC = "images/sec at N=10 MC samples, 512x512; per-anchor covariance latency"
+N_CMP_FRAMES = 16                  # frames whose device detections are kept for the comparison with the CPU leg (it computes ~15 in its budget)
 USE_DIST = False                   # process group initialised (N > 1, or BOD_BENCH_FORCE_DIST=1 on one rank)
 # conv FLOPs (2 MACs) of backbone + FPN per 512x512 image, linear in the pixel count
 BACKBONE_FPN_GFLOP_512 = {50: 49.05, 101: 49.05 + 17 * 2.0 * 1024 * (1024 * 256 + 2304 * 256 + 256 * 1024) / 1e9}
@@ -76,13 +79,16 @@ def image_gflop(hw, P, n, depth=50, dedup=True):
 
 
 def _rel_errs(got, ref):
-    """(max |got-ref| / (|ref| + rms(ref)),  rms(got-ref) / rms(ref))"""
+    """(max |got-ref| / (|ref| + rms(ref)),  rms(got-ref) / rms(ref),  strict: max |got-ref| / max(|ref|, 1e-5) over |ref| >= 1 % of rms(ref))"""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     rms = float(np.sqrt((ref ** 2).mean()))
-    return float(np.max(np.abs(got - ref) / (np.abs(ref) + rms))), float(np.sqrt(((got - ref) ** 2).mean()) / rms)
+    d = np.abs(got - ref)
+    big = np.abs(ref) >= 1e-2 * rms
+    strict = float((d[big] / np.maximum(np.abs(ref[big]), 1e-5)).max()) if big.any() else 0.0
+    return float(np.max(d / (np.abs(ref) + rms))), float(np.sqrt(((got - ref) ** 2).mean()) / rms), strict
 
 
-def detection_parity(dev, ref):
+def detection_parity(dev, ref, arrays=False):
     """Final output of the path for one frame -- cluster-fused detections (scores [K,C], means [K,4] or [K,4,1], covs [K,4,4],
     counts [K,C]) -- device vs the CPU leg, both from the same frame, Philox dropout masks and categorical uniforms.
     Every CPU detection is paired with the device detection whose box overlaps it most (IoU > 0.5, each device detection used
@@ -129,7 +135,42 @@ def detection_parity(dev, ref):
                 "median_rel_dSigma": float("%.3g" % np.median(rel_sig.reshape(len(ri), -1).max(axis=1))),
                 "max_dscore": float("%.3g" % dsc.max()), "median_dscore": float("%.3g" % np.median(dsc.max(axis=1))),
                 "counts_equal": bool(np.array_equal(np.asarray(dev[3], np.float64)[di], np.asarray(ref[3], np.float64)[ri]))})
+    if arrays:           # per matched detection: worst coordinate / entry / class (detection_statistics aggregates them over frames)
+        out["_dmu_px"] = dmu.max(axis=1)
+        out["_rel_dsigma"] = rel_sig.reshape(len(ri), -1).max(axis=1)
+        out["_dscore"] = dsc.max(axis=1)
     return out
+
+
+def _posterior_pmc_bytes(B, n, hw):
+    """HBM bytes (FETCH_SIZE corrected + WRITE_SIZE) of the unfused posterior's kernels per step from the committed PMC passes of the
+    same configuration, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round5_posterior_pmc.json")) as fp:
+            pmc = json.load(fp)
+        c = pmc["config"]
+        if (c["height"], c["width"], c["mc_samples"], c["batch"]) == (hw[0], hw[1], n, B):
+            return {"bytes_per_step": int(pmc["hbm_bytes_per_step"]), "source": "profiles/round5_posterior_pmc.json"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def detection_statistics(per_frame):
+    """Detection-level distance of one precision mode to the CPU leg over EVERY frame the CPU leg computed (round-4 review: one frame is
+    an anecdote): match rate, frames whose detections come out in the CPU leg's order, and median / p95 / max of the per-detection worst
+    box coordinate error (pixels), covariance entry error (relative, floor 1 % of the matrix's largest entry) and score error."""
+    per_frame = [p for p in per_frame if p is not None]
+    if not per_frame:
+        return None
+    q = lambda name: np.concatenate([p[name] for p in per_frame if name in p]) if any(name in p for p in per_frame) else np.zeros(0)
+    st = lambda v: ({"median": float("%.3g" % np.median(v)), "p95": float("%.3g" % np.quantile(v, 0.95)), "max": float("%.3g" % v.max())} if len(v) else None)
+    return {"frames": len(per_frame),
+            "cpu_detections": int(sum(p["cpu_detections"] for p in per_frame)), "device_detections": int(sum(p["device_detections"] for p in per_frame)),
+            "matched": int(sum(p["matched"] for p in per_frame)),
+            "frames_in_same_order": int(sum(1 for p in per_frame if p.get("same_order"))),
+            "frames_counts_equal": int(sum(1 for p in per_frame if p.get("counts_equal"))),
+            "abs_dmu_px": st(q("_dmu_px")), "rel_dSigma": st(q("_rel_dsigma")), "dscore": st(q("_dscore"))}
 
 
 def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_raw=None, seed=0, first_image_id=0, device_dets=None):
@@ -140,8 +181,10 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
     The CPU forward of frame 0 then runs with the SAME Philox dropout masks, so the two are directly comparable: the
     returned ``parity`` maps each mode to its max relative error / relative RMS distance against this CPU forward
     (north_star: "outputs match the CPU reference within 1e-3 rel on identical inputs, CPU baseline timed in the same run").
-    ``device_dets``: {mode name: (scores, means, covs, counts)} the device's final detections of frame 0 from the same call;
-    ``parity[mode]["detections"]`` compares them with this leg's own posterior -> soft-NMS -> cluster-and-fuse output."""
+    ``device_dets``: {mode name: [(scores, means, covs, counts) of frame 0, of frame 1, ...]} the device's final detections from the same
+    call; ``parity[mode]["detections"]`` compares frame 0's with this leg's own posterior -> soft-NMS -> cluster-and-fuse output, and
+    ``parity[mode]["detections_all_frames"]`` is the statistic over EVERY frame this leg computes (each frame's forward then runs with
+    that frame's Philox masks, generated outside the clock like frame 0's)."""
     import torch
     from oracle import bayes_od, clustering, geometry, network, nms, philox, torch_ref
     tw = torch_ref.prepare(weights)
@@ -171,24 +214,28 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
     threads = best[1]
     torch.set_num_threads(threads)
     P = anchors.shape[0] // 9
-    masks0 = None
-    if device_raw:      # Philox masks of frame 0, generated before the clock starts (the reference draws its masks inside the op)
+    n_cmp = max([len(v) for v in (device_dets or {}).values()] + [1 if device_raw else 0])      # frames with device outputs to compare
+
+    def masks_of(frame):      # Philox masks of one frame, generated before its clock starts (the reference draws its masks inside the op)
         cache = {}
 
-        def masks0(s, lid):
+        def masks(s, lid):
             if (s, lid) not in cache:
-                cache[(s, lid)] = philox.dropout_keep_mask(seed, first_image_id, s, lid, P, 256, 0.3)
+                cache[(s, lid)] = philox.dropout_keep_mask(seed, first_image_id + frame, s, lid, P, 256, 0.3)
             return cache[(s, lid)]
         for s in range(n):
             for lid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11):
-                masks0(s, lid)
+                masks(s, lid)
+        return masks
     done, t_total = 0, 0.0
     parts = {"forward": 0.0, "posterior": 0.0, "nms": 0.0, "cluster": 0.0}
     parity = {}
     cpu_dets0 = None
+    per_frame = {mode: [] for mode in (device_dets or {})}
     while done < len(frames) and (done == 0 or t_total < seconds_budget):
+        masks0 = masks_of(done) if done < n_cmp else None
         t0 = time.perf_counter()
-        out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw, keep_masks=masks0 if done == 0 else None)
+        out = torch_ref.retinanet_forward(None, frames[done:done + 1], n, 8, prepared=tw, keep_masks=masks0)
         t1 = time.perf_counter()
         u = philox.categorical_uniforms(seed, first_image_id + done, anchors.shape[0])
         post = bayes_od.bayes_od_posterior(out, anchors, u, BAYES_CFG, use_full_covar=True, dtype=np.float32)
@@ -210,13 +257,18 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
             for mode, (cls, box, cov) in device_raw.items():
                 errs = [_rel_errs(g, out[k]) for g, k in ((cls, "anchors_class_predictions"), (box, "anchors_box_predictions"),
                                                           (cov, "_covar_params"))]
-                parity[mode] = {"max_rel_err": max(e[0] for e in errs), "rel_rms": max(e[1] for e in errs)}
+                parity[mode] = {"max_rel_err": max(e[0] for e in errs), "rel_rms": max(e[1] for e in errs), "max_rel_err_strict": max(e[2] for e in errs)}
             for mode, dev in (device_dets or {}).items():
-                parity.setdefault(mode, {})["detections"] = detection_parity(dev, cpu_dets0)
+                parity.setdefault(mode, {})["detections"] = detection_parity(dev[0], cpu_dets0)
+        for mode, dev in (device_dets or {}).items():
+            if done < len(dev):
+                per_frame[mode].append(detection_parity(dev[done], dets, arrays=True))
         done += 1
+    for mode, pf in per_frame.items():
+        parity.setdefault(mode, {})["detections_all_frames"] = detection_statistics(pf)
     base = {"value": done / t_total, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "%d frame(s) of %dx%d at N=%d, reference-literal (11*N head convs, no dedup), "
-                      "torch %s fp32 CPU forward + NumPy Bayesian stages; seconds: %s" %
+                      "torch %s fp32 CPU forward + NumPy Bayesian stages (Philox dropout masks of the compared frames generated outside the clock); seconds: %s" %
                       (done, hw[0], hw[1], n, torch.__version__,
                        {k: round(v, 2) for k, v in parts.items()})}
     return base, parity
@@ -837,7 +889,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         # raw head outputs of frame 0 with (seed 0, image id lo) for the parity figures of the CPU leg
         eng.upload_images(frames)
         eng.infer(None, seed=0, first_image_id=lo)
-        device_dets["bf16"] = eng.get_detections(0)
+        device_dets["bf16"] = [eng.get_detections(i) for i in range(min(B, N_CMP_FRAMES))]
         device_raw["bf16"] = raw_of_image0(eng)          # (re-runs the raw flavour of the last tower launches: same Philox streams)
         # ---- what the MC aggregation (a9-a10) costs where it now lives, inside the tower epilogues: the same steps on a handle
         # planned WITHOUT it (raw [B,N,A,.] tensors + the posterior's own loops over the samples), same box, same frames
@@ -886,7 +938,11 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             "towers_ms_per_step": {"fused_aggregation": [round(t_on1, 3), round(t_on2, 3)], "raw_tensors": [round(t_off1, 3), round(t_off2, 3)]},
             # the kernel-quality figure of the stage: the posterior that WALKS the raw [B,N,A,.] tensors (plan without the fusion)
             "unfused_stage_ns": round(post_off * 1e6 / anchors_per_step, 4),
-            "unfused_hbm_frac_of_8TBs": round(algo_bytes / (post_off * 1e-3) / 8e12, 3),
+            # SURVEY 8d's bytes over the unfused stage's time: a RATE, not a roofline fraction -- since the compaction kernel (round 4)
+            # the per-anchor fusion reads box / covariance samples of the ~2 % kept anchors only, so the stage does not move those bytes
+            # (measured FETCH + WRITE of its kernels: profiles/round5_posterior_pmc.json when taken)
+            "unfused_stage_algorithmic_TBps": round(algo_bytes / (post_off * 1e-3) / 1e12, 2),
+            "unfused_stage_measured_hbm_bytes": _posterior_pmc_bytes(B, n, hw),
             "algorithmic_bytes_per_step": int(algo_bytes),
             # (SURVEY 8d's bytes / this stage's time; above 1 by construction once the bytes are not moved: a ratio, not a fraction of peak)
             "algorithmic_bytes_per_second_over_8TBs": round(algo_bytes / ((post_on + bound) * 1e-3) / 8e12, 3)}
@@ -895,40 +951,49 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         del eng
 
     if extras:
-        # ---- parity_mode: the bf16x3 precision mode ((hi, lo) bf16 pairs, three MFMA products per MAC) -- the mode in which the
-        # pipeline meets north_star's 1e-3 end to end -- timed in the same run on the same frames
+        # ---- parity_mode: the precision modes in which the pipeline meets north_star's 1e-3 END TO END, timed in the same run on the same
+        # frames.  f16mx (round 5) = bf16x3 with the head towers -- 80 % of bf16x3's step -- on one f16 product + half a block-scaled e2m3
+        # product per multiplication instead of three bf16 products; bf16x3 (rounds 2-4) beside it as `parity_mode_bf16x3`.
         Bp = min(B, 256)                  # the production data path: fused 1x1 + MC aggregation, no [B,N,A,.] tensors (92 GB of pair planes at 256 frames)
-        engp = make_engine(hw, Bp, n, local_rank, precision="bf16x3", weights=weights, anchors=anchors)
-        engp.upload_images(frames[:Bp])
-        engp.infer(None, seed=0, first_image_id=lo)
-        device_dets["bf16x3"] = engp.get_detections(0)
-        device_raw["bf16x3"] = raw_of_image0(engp)
-        p_steps = 5
-        dt = timed_pipeline(engp, p_steps, 2, False, Bp, first_id=lo)
-        out["parity_mode"] = {"precision": "bf16x3", "images_per_sec": round(Bp * p_steps / dt, 2),
-                              "ms_per_step": round(dt / p_steps * 1e3, 3), "frames_per_step": Bp, "steps": p_steps,
-                              "fraction_of_headline": round(Bp * p_steps / dt / value, 4),
-                              "pipeline_tflops": round(image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
-                              "mfma_issue_tflops": round(3 * image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
-                              "max_rel_err": None, "plan": engp.plan_info()}
-        engp.close()
-        del engp
+        for mode, key in (("f16mx", "parity_mode"), ("bf16x3", "parity_mode_bf16x3")):
+            engp = make_engine(hw, Bp, n, local_rank, precision=mode, weights=weights, anchors=anchors)
+            engp.upload_images(frames[:Bp])
+            engp.infer(None, seed=0, first_image_id=lo)
+            device_dets[mode] = [engp.get_detections(i) for i in range(min(Bp, N_CMP_FRAMES))]
+            device_raw[mode] = raw_of_image0(engp)
+            p_steps = 5
+            dt = timed_pipeline(engp, p_steps, 2, False, Bp, first_id=lo)
+            products = 1.5 if (mode == "f16mx" and engp.plan_info()["tower_mx"]) else 3.0
+            out[key] = {"precision": mode, "images_per_sec": round(Bp * p_steps / dt, 2),
+                        "ms_per_step": round(dt / p_steps * 1e3, 3), "frames_per_step": Bp, "steps": p_steps,
+                        "fraction_of_headline": round(Bp * p_steps / dt / value, 4),
+                        "pipeline_tflops": round(image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
+                        "tower_bf16_product_equivalents_per_multiplication": products,
+                        "max_rel_err": None, "plan": engp.plan_info()}
+            engp.close()
+            del engp
         out["secondary"] = secondary_configs(local_rank, weights, lo)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline(hw, n, frames, weights, anchors, device_raw=device_raw, seed=0, first_image_id=lo, device_dets=device_dets)
         out["cpu_baseline"] = base
         out["config"]["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
-        if "bf16x3" in parity and "parity_mode" in out:
-            out["parity_mode"]["max_rel_err"] = float("%.3g" % parity["bf16x3"]["max_rel_err"])
-            out["parity_mode"]["rel_rms"] = float("%.3g" % parity["bf16x3"]["rel_rms"])
-            out["parity_mode"]["against"] = ("cpu_baseline's fp32 forward of frame 0 with the same Philox dropout masks: raw head outputs "
-                                             "(class logits, box deltas, covariance parameters), max |d| / (|ref| + rms(ref))")
-            out["parity_mode"]["speedup_vs_cpu_baseline"] = round(out["parity_mode"]["images_per_sec"] / base["value"], 1)
-            # the path's OUTPUT (boxes, class scores, 4x4 covariances of the cluster-fused detections of frame 0 at full size)
-            # against the CPU leg's own posterior -> soft-NMS -> cluster-and-fuse, same Philox streams
-            out["parity_mode"]["detections"] = parity["bf16x3"].get("detections")
+        for mode, key in (("f16mx", "parity_mode"), ("bf16x3", "parity_mode_bf16x3")):
+            if mode not in parity or key not in out:
+                continue
+            out[key]["max_rel_err"] = float("%.3g" % parity[mode]["max_rel_err"])
+            out[key]["rel_rms"] = float("%.3g" % parity[mode]["rel_rms"])
+            out[key]["max_rel_err_strict"] = float("%.3g" % parity[mode]["max_rel_err_strict"])
+            out[key]["against"] = ("cpu_baseline's fp32 forward of frame 0 with the same Philox dropout masks: raw head outputs "
+                                   "(class logits, box deltas, covariance parameters), max |d| / (|ref| + rms(ref)); _strict: SURVEY 8d's "
+                                   "max |d| / max(|ref|, 1e-5) over the elements with |ref| >= 1 % of the tensor's rms (a signed output's zero "
+                                   "crossings have no relative error)")
+            out[key]["speedup_vs_cpu_baseline"] = round(out[key]["images_per_sec"] / base["value"], 1)
+            # the path's OUTPUT (boxes, class scores, 4x4 covariances of the cluster-fused detections at full size) against the CPU leg's
+            # own posterior -> soft-NMS -> cluster-and-fuse, same Philox streams: frame 0, and the statistic over every frame of the CPU leg
+            out[key]["detections"] = parity[mode].get("detections")
+            out[key]["detections_all_frames"] = parity[mode].get("detections_all_frames")
         if "bf16" in parity:
-            out["config"]["headline_mode_distance_to_cpu_forward"] = {k: (float("%.3g" % v) if not isinstance(v, dict) else v)
+            out["config"]["headline_mode_distance_to_cpu_forward"] = {k: (float("%.3g" % v) if not isinstance(v, dict) and v is not None else v)
                                                                       for k, v in parity["bf16"].items()}
     if rank == 0:
         print(json.dumps(out), flush=True)

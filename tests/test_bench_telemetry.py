@@ -47,3 +47,32 @@ def test_telemetry_is_optional(tmp_path):
     none.dir, none.samples, none._stop, none._thread = None, [], False, None
     none.start()
     assert none.stop() is None
+
+
+def test_detection_statistics_aggregates_every_frame():
+    """bench.detection_statistics (round 5): the detection-level distance of a precision mode to the CPU leg as a statistic over all
+    frames the CPU leg computed -- match rate, order, median / p95 / max of the per-detection errors -- not one frame's anecdote."""
+    import numpy as np
+    import bench
+    rng = np.random.default_rng(0)
+
+    def frame(k, jitter):
+        means = np.stack([rng.uniform(50, 400, k), rng.uniform(50, 400, k), rng.uniform(20, 60, k), rng.uniform(20, 60, k)], 1)
+        covs = np.tile(np.eye(4) * 4.0, (k, 1, 1))
+        scores = rng.random((k, 8)); counts = rng.integers(0, 30, (k, 8)).astype(np.float64)
+        ref = (scores, means[:, :, None], covs, counts)
+        dev = (scores + jitter * 1e-3, means + jitter, covs * (1 + jitter * 1e-2), counts)
+        return dev, ref
+    per = []
+    for k, j in ((12, 0.0), (9, 0.01), (15, 0.5)):
+        dev, ref = frame(k, j)
+        p = bench.detection_parity(dev, ref, arrays=True)
+        assert p["matched"] == k and p["same_order"]
+        per.append(p)
+    st = bench.detection_statistics(per + [None])
+    assert st["frames"] == 3 and st["matched"] == st["cpu_detections"] == st["device_detections"] == 36 and st["frames_in_same_order"] == 3
+    assert st["abs_dmu_px"]["max"] == 0.5 and st["abs_dmu_px"]["median"] <= 0.5 and st["abs_dmu_px"]["p95"] <= 0.5
+    assert abs(st["dscore"]["max"] - 5e-4) < 1e-9 and st["rel_dSigma"]["max"] < 6e-3
+    assert bench.detection_statistics([]) is None
+    e = bench._rel_errs(np.array([1.0, 2.0, 1e-9]), np.array([1.0, 2.002, 0.0]))
+    assert abs(e[0] - 0.002 / (2.002 + np.sqrt((1 + 2.002 ** 2) / 3))) < 1e-12 and abs(e[2] - 0.002 / 2.002) < 1e-12      # strict: the zero of `ref` is not rated
