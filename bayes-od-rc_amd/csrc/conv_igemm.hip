@@ -1749,6 +1749,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const uint4 vh = *reinterpret_cast<const uint4*>(prow + (((ch ^ lr) & (CPR2 - 1)) << 4));
                 const uint4 vl = *reinterpret_cast<const uint4*>(prow + ((((ch + 4) ^ lr) & (CPR2 - 1)) << 4));
                 const size_t e = ((size_t)off + (size_t)n * a.fan_stride) * a.out_cstride + bc0 * 2 + ch * 8;
+                if (MXK != 0 && (a.flags & CONV_NT_OUT)) {        // f16mx towers, BOD_NT_STORES bits 3 / 4: streaming stores (A/B switch)
+                    __builtin_nontemporal_store(u32x4{vh.x, vh.y, vh.z, vh.w}, reinterpret_cast<u32x4*>(out16 + e));
+                    __builtin_nontemporal_store(u32x4{vl.x, vl.y, vl.z, vl.w}, reinterpret_cast<u32x4*>(out16 + e + 32));
+                    continue;
+                }
                 *reinterpret_cast<uint4*>(out16 + e) = vh;
                 *reinterpret_cast<uint4*>(out16 + e + 32) = vl;
                 if (G.out_relu) {                 // relu(hi + lo): the pair survives iff hi is not negative
@@ -2235,6 +2240,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     }
                 }
             }
+            phase_stamp<ABL>(tstamp, 10);       // (aggregating tiles) fused 1x1 MFMAs
             __syncthreads();
             const int ystride = ((G.cout2 + 31) & ~31) + 4;            // floats per row: = 4 mod 32, conflict-free 16-byte writes
             float* ytile = reinterpret_cast<float*>(smem);
@@ -2253,6 +2259,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 }
             }
             __syncthreads();
+            phase_stamp<ABL>(tstamp, 11);       // barrier + fp32 output tile to LDS + barrier
             if (G.agg_kind == AGG_CLS) {
                 if (G.agg_C == 8) agg_reduce_cls<8>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
                 else agg_reduce_cls<4>(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
@@ -2261,6 +2268,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             } else {
                 agg_reduce_cov(G, ytile, ystride, s_off, s_off2, tid, THREADS, BP);
             }
+            phase_stamp<ABL>(tstamp, 12);       // MC reduction over the samples + statistics stores
+            if constexpr (ABL == 90) { if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[14], __builtin_amdgcn_s_memrealtime() - treal); }
             return;                                   // (fused groups never fan out: one pass, and `pk` dies here)
         }
         if (fuse) {
@@ -2622,22 +2631,24 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // BOD_RES_REGISTER=1: residuals read from global memory in the accumulator layout instead of through the LDS tile (A/B aid)
     static const bool res_register = getenv("BOD_RES_REGISTER") && atoi(getenv("BOD_RES_REGISTER")) == 1;
     if (res_register && a_local.variant == 0 && !a_local.xreuse && !a_local.split && a_local.ksplit <= 1) a_local.variant = 82;
-    // BOD_NT_STORES (default 0 = plain stores): bit 0 = non-temporal output stores in the generic kernel (backbone / FPN), bit 1 = in
+    // BOD_NT_STORES (default 4; 0 = plain stores everywhere): bit 0 = non-temporal output stores in the generic kernel (backbone / FPN), bit 1 = in
     // the row-reuse kernels (head towers, fan-out launch).  Measured on one box, 256 frames: backbone -0.35 ms with bit 0, the tower
     // launches +0.5 ms beside it (net 0); bit 1 costs the towers 1 % and the fan-out launch 4 %: the outputs are re-read by the next
     // launch's neighbouring tiles through L2 after all.  Kept as an A/B switch.
-    static const int nt_stores = getenv("BOD_NT_STORES") ? atoi(getenv("BOD_NT_STORES")) : 0;
+    static const int nt_stores = getenv("BOD_NT_STORES") ? atoi(getenv("BOD_NT_STORES")) : 4;      // (round 5: bit 2 on -- the fan-out launch, 13.5 -> 13.2 ms per 512 frames in two same-box A/B pairs)
     // bit 2 (round 5): the fan-out launch ALONE -- its ten masked copies (42.9 GB per 512 frames) are what pushes the three heads' weights
     // and the shared pyramid rows out of L2 (11.2 GB fetched for 1.4 GB algorithmic, profiles/round4_head_conv_pmc.json launch 0)
     if (!(a_local.flags & CONV_OUT_F32) && !a_local.split && a_local.ksplit <= 1 &&
         (((nt_stores & 1) && !a_local.xreuse) || ((nt_stores & 2) && a_local.xreuse) || ((nt_stores & 4) && a_local.xreuse && a_local.fan_count > 1)))
         a_local.flags |= CONV_NT_OUT;
+    // bits 3 / 4 (f16mx towers): the per-sample tower layers' hx outputs / the first layer's ten-fold hx outputs
+    if (a_local.mx && (((nt_stores & 8) && a_local.fan_count <= 1) || ((nt_stores & 16) && a_local.fan_count > 1))) a_local.flags |= CONV_NT_OUT;
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     if (a.mx) {                                      // f16mx precision: head-tower launches on the row-reuse loop, whatever the tile heuristics say
         if ((a.mx != 1 && a.mx != 2) || !a.split || a.xreuse != 2 || a.cout_pad != 256 || a.cin != 512 || a.taps != 9 || a.KW != 3 || !a.ext || a.M % 256 != 0 ||
-            (a.flags & (CONV_OUT_F32 | CONV_NT_OUT)) || a.ksplit > 1 || (a.variant != 0 && a.variant != 90 && a.variant != 91) || a.groups < 1 || a.groups > 3)
+            (a.flags & CONV_OUT_F32) || a.ksplit > 1 || (a.variant != 0 && a.variant != 90 && a.variant != 91) || a.groups < 1 || a.groups > 3)
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g)
             if (a.g[g].res || a.g[g].out_relu || a.g[g].ch_w2 || a.g[g].ch_w3 || (a.g[g].w2 && (a.g[g].out_hx || a.fan_count > 1))) return hipErrorInvalidValue;

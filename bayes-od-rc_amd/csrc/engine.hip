@@ -2506,7 +2506,11 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
         static const char* names[6] = {"set-up", "main loop", "barrier+bias/relu/pack", "philox+lds writes", "barrier", "store loop"};
         fprintf(stderr, "# phase clock, wave 0, cycles per tile (%.0f tiles):", tiles);
         for (int k = 0; k < 6; ++k) fprintf(stderr, "  %s %.0f", names[k], (double)c[k] / tiles);
+        // (aggregating tiles leave through the fused 1x1 + MC reduction instead of the store loop: slots 10..12)
+        if (c[10] + c[11] + c[12] > 0)
+            fprintf(stderr, "  fused 1x1 MFMAs %.0f  barriers+fp32 tile %.0f  MC reduction+stores %.0f", (double)c[10] / tiles, (double)c[11] / tiles, (double)c[12] / tiles);
         double cyc = 0; for (int k = 0; k < 6; ++k) cyc += (double)c[k];
+        cyc += (double)c[10] + (double)c[11] + (double)c[12];
         fprintf(stderr, "  | shader clock during the tiles %.3f GHz (cycles / 100 MHz real-time ticks); tiles account for %.3f ms of the %.3f ms launch per CU\n",
                 cyc / (double)c[14] * 0.1, (double)c[14] / tiles * 1e-5 * (tiles / (iters + 1)) / 256.0, ms / iters);
     }
