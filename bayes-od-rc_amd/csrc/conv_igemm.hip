@@ -1534,6 +1534,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 uint16_t hb[4];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
+                                    // (f16 range: a tower activation beyond +-65 504 -- none in a trained RetinaNet, whose tower outputs stay below a
+                                    // few hundred -- is clamped instead of becoming an infinity; the bf16x3 mode has no such limit)
+                                    v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
                                     const _Float16 hh = (_Float16)v[r];
                                     hb[r] = __builtin_bit_cast(uint16_t, hh);
                                     const float hf = (float)hh;
