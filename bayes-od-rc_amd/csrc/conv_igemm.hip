@@ -528,7 +528,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     // the f16mx loop; 11 = its phase-clock twin (tests/tools/bench_head_conv.py variant 90), 12 = the same without the loop's LDS-DMA (variant 91)
     constexpr bool MXL = MXK == 1 || MXK == 11 || MXK == 12;
     constexpr bool MXI = MXK == 11 || MXK == 12;
-    unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0;
+    unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0, mx_t_cnt = 0;
     if constexpr (MXI) mx_t0 = __builtin_amdgcn_s_memtime();
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
@@ -1030,8 +1030,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             if (xnext && kxc == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
                             else if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            unsigned long long tm = 0;
+                            if constexpr (MXI) tm = __builtin_amdgcn_s_memtime();
                             __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-                            if constexpr (MXI) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); mx_t_wait += tb - ta; mx_tb += tb - ta; }
+                            if constexpr (MXI) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); mx_t_wait += tb - ta; mx_t_cnt += tm - ta; mx_tb += tb - ta; }
                         },
                         [&](const int k, char* __restrict__ wr) {
                             if (MXK == 12) return;
@@ -1057,7 +1059,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             if constexpr (MXI) {
                 if (threadIdx.x == 0) {
                     const unsigned long long now = __builtin_amdgcn_s_memtime();
-                    atomicAdd(&g_phase_cycles[6], mx_t_wait); atomicAdd(&g_phase_cycles[7], mx_t_body);
+                    atomicAdd(&g_phase_cycles[6], mx_t_wait); atomicAdd(&g_phase_cycles[7], mx_t_body); atomicAdd(&g_phase_cycles[13], mx_t_cnt);
                     atomicAdd(&g_phase_cycles[8], now - mx_t0); atomicAdd(&g_phase_cycles[15], 1ull);
                     mx_t0 = now;
                 }

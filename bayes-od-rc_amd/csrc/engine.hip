@@ -2497,8 +2497,9 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
         conv_igemm_phase_cycles(c, true);
         const double tiles = (double)c[15];
         fprintf(stderr, "# f16mx phase clock, wave 0, cycles per tile (%.0f tiles): whole tile %.0f = set-up %.0f + loop %.0f (of which: waiting for the next K-tile's pieces + barrier %.0f, "
-                        "K-tile bodies %.0f; 72 K-tiles) + epilogue %.0f\n", tiles, (double)c[9] / tiles, ((double)c[8] - (double)c[6] - (double)c[7]) / tiles,
-                ((double)c[6] + (double)c[7]) / tiles, (double)c[6] / tiles, (double)c[7] / tiles, ((double)c[9] - (double)c[8]) / tiles);
+                        "K-tile bodies %.0f; 72 K-tiles) + epilogue %.0f; of the wait: vmcnt / lgkmcnt %.0f, s_barrier %.0f\n", tiles, (double)c[9] / tiles, ((double)c[8] - (double)c[6] - (double)c[7]) / tiles,
+                ((double)c[6] + (double)c[7]) / tiles, (double)c[6] / tiles, (double)c[7] / tiles, ((double)c[9] - (double)c[8]) / tiles,
+                (double)c[13] / tiles, ((double)c[6] - (double)c[13]) / tiles);
     } else if (variant == 90) {
         unsigned long long c[16];
         conv_igemm_phase_cycles(c, true);
