@@ -975,10 +975,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const int ch = kt / 9, tap = kt - ch * 9;
                 return (tap * a.cin + ch * BK) * 2;
             };
+            // Who issues the weight pieces (ConvArgs.mx_loader): 0 = every wave its own eighth of a piece (8 rows); 1 / 2 = the lower / upper four
+            // waves -- one per SIMD -- issue their own rows AND those of the wave they share the SIMD with (rows + 32: 16 KiB further in the
+            // source, 4 KiB in LDS), the other four none.  The two waves of a SIMD share one matrix pipe and a wave parks 60-185 cycles per
+            // piece it issues: with every wave issuing, one wave of each SIMD reaches the K-tile's barrier ~620 cycles before the other
+            // (phase clock: `s_barrier` 44 k of 223 k cycles per tile) and idles there while its partner's parks leave the pipe empty.
+            const int mx_loader = a.mx_loader;
+            const bool w_issuer = mx_loader == 0 || (mx_loader == 1 ? wave < 4 : wave >= 4);
             auto dma_w = [&](const int piece, const int kt_, char* __restrict__ wr) {
+                if (!w_issuer) return;
                 int off = woff_of(kt_) + piece * wrs;
                 asm volatile("" : "+s"(off));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, off, 0, 0);
+                if (mx_loader == 0) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, off, 0, 0);
+                    return;
+                }
+                // (lane offsets of the lower wave of the pair: wave & 3; this wave's own rows are + 0 or + 32 accordingly)
+                const int w3 = wave & 3;
+                const int lane_off = (int)wlane - (wave >= 4 ? 32 * wrow * 2 : 0);
+                int off2 = off + 32 * wrow * 2;
+                asm volatile("" : "+s"(off2));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + w3 * 64) * 16), 16, lane_off, off, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + (w3 + 4) * 64) * 16), 16, lane_off, off2, 0, 0);
             };
             HxCarry<FP> carry;
             // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); piece 0 of K-tile 1 behind them

@@ -977,6 +977,11 @@ bod_status build_plan(bod_context* h) {
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
         a.mx = mx_plan ? (layer == 0 ? 2 : 1) : 0;
+        {   // BOD_MX_LOADER=0|1|2: which waves of the f16mx loop issue the weight pieces (conv_igemm.hip: all / lower four / upper four)
+            // (same-box A/B at 256 frames, two rounds each: towers 198.0 / 196.2 / 199.7 ms with 0 / 1 / 2)
+            static const int mx_loader = getenv("BOD_MX_LOADER") ? atoi(getenv("BOD_MX_LOADER")) : 1;
+            a.mx_loader = mx_loader;
+        }
         if (xreuse0 && layer == 0) { a.rows = d1x; a.M = m1x; a.ext = dext1; a.xreuse = 2; }
         if (xreuse && layer > 0) {
             a.rows = d2x; a.M = m2x; a.ext = dext;

@@ -119,6 +119,7 @@ struct ConvArgs {
     // weights in the hx format, one f16 product + one block-scaled e5m2 product (the two cross terms) per multiplication; 2 = (hi, lo)
     // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer).  0 = off.
     int32_t mx;
+    int32_t mx_loader;     // f16mx loop: which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four)
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
