@@ -836,10 +836,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             // weight offsets of the K-tiles one and two ahead: K-tile t is tap t % 9 of channel chunk t / 9
             int wo1 = a.cin * 2, tap1 = 1, wo2 = 2 * a.cin * 2, tap2 = 2;
             auto w_advance = [&](int& wo, int& tap) { if (++tap == 9) { tap = 0; wo += BK * 2 - 8 * a.cin * 2; } else wo += a.cin * 2; };
+            // ConvArgs.mx_loader == 1 (round 5, A/B switch BOD_TOWER_LOADER): the lower four waves -- one per SIMD -- issue the weight pieces of
+            // both waves of their SIMD (their own 8 rows of a piece and the rows + 32 of wave + 4), the upper four none (f16mx loop: -0.9 %)
+            const bool w_pair = a.mx_loader == 1;
             auto dma_w = [&](int piece, int wo, int stage_) {
                 int so_ = wo + piece * wrs;
                 asm volatile("" : "+s"(so_));
+                if (!w_pair) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + stage_ * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, so_, 0, 0);
+                    return;
+                }
+                if (wave >= 4) return;
+                int so2 = so_ + 32 * wrow * 2;
+                asm volatile("" : "+s"(so2));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + stage_ * WST + (piece * THREADS + wave * 64) * 16), 16, (int)wlane, so_, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(smem + stage_ * WST + (piece * THREADS + (wave + 4) * 64) * 16), 16, (int)wlane, so2, 0, 0);
             };
             // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); add weight piece 0 of K-tile 1, then
             // wait for everything but that piece

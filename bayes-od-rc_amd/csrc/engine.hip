@@ -980,7 +980,9 @@ bod_status build_plan(bod_context* h) {
         {   // BOD_MX_LOADER=0|1|2: which waves of the f16mx loop issue the weight pieces (conv_igemm.hip: all / lower four / upper four)
             // (same-box A/B at 256 frames, two rounds each: towers 198.0 / 196.2 / 199.7 ms with 0 / 1 / 2)
             static const int mx_loader = getenv("BOD_MX_LOADER") ? atoi(getenv("BOD_MX_LOADER")) : 1;
-            a.mx_loader = mx_loader;
+            // BOD_TOWER_LOADER=1: the same pairing in the bf16 tower loop (A/B switch; measured 0.8 % SLOWER there: 211.6 against 209.9 ms per 512 frames)
+            static const int tower_loader = getenv("BOD_TOWER_LOADER") ? atoi(getenv("BOD_TOWER_LOADER")) : 0;
+            a.mx_loader = mx_plan ? mx_loader : ((h->es == 2 && layer > 0) ? tower_loader : 0);
         }
         if (xreuse0 && layer == 0) { a.rows = d1x; a.M = m1x; a.ext = dext1; a.xreuse = 2; }
         if (xreuse && layer > 0) {
