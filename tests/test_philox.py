@@ -80,3 +80,37 @@ def test_categorical_uniforms_contract():
     assert abs(u.mean() - 0.5) < 0.01
     w = philox.philox4x32_10(10, 6, philox.CAT_TAG, 2, 5, 0)
     assert u[10, 25] == np.float32((int(w[1]) >> 8) * 2.0 ** -24)
+
+
+def test_mc_dropout_statistics_under_contract_v3_match_independent_masks():
+    """Round-4 advisor: contract v3 reads sixteen OVERLAPPING 16-bit windows of one Philox call, so the keep decisions of channels that
+    share a byte are only approximately independent (dependence of order 2^-8), while tf.nn.dropout draws independent uniforms
+    (multitask_headers.py:104-116) -- and every parity test uses the same contract on both sides.  What the Bayesian stages consume is the
+    MC SAMPLE MEAN AND COVARIANCE of a layer's outputs (inference_utils.py:220-244): a dropout layer followed by a dense mix of its 256
+    channels, 2 048 MC samples, under v3 masks and under independent Bernoulli masks -- per-output means, variances and the
+    covariance of output pairs must agree within the sampling noise of 2 048 draws (a window dependence at the 2^-8 level moves a
+    variance by < 1e-3 of itself; a broken window scheme -- e.g. neighbours sharing a whole half-word -- moves it by tens of per cent)."""
+    from oracle import philox
+    rng = np.random.default_rng(12)
+    S, P, C, K = 2048, 8, 256, 64
+    x = np.maximum(rng.normal(0, 1, (P, C)), 0)
+    w = rng.normal(0, 1, (C, K)) / np.sqrt(C)
+    # adversarial mix for the window scheme: one output sums NEIGHBOURING channels with equal signs (their keep decisions share bytes)
+    w[:, 0] = 1.0 / np.sqrt(C)
+    w[:, 1] = np.where((np.arange(C) & 3) < 2, 1.0, -1.0) / np.sqrt(C)
+    v3 = np.stack([philox.dropout_keep_mask(77, 3, s, 5, P, C, 0.3) for s in range(S)]).astype(np.float64)      # [S,P,C]
+    ind = (rng.random((S, P, C)) >= 0.3).astype(np.float64)
+    y3 = np.einsum("spc,ck->spk", v3 * x / 0.7, w)
+    yi = np.einsum("spc,ck->spk", ind * x / 0.7, w)
+    # means: standard error sigma / sqrt(S)
+    sd = yi.std(0)
+    assert np.all(np.abs(y3.mean(0) - yi.mean(0)) < 6 * sd * np.sqrt(2.0 / S))
+    # variances: relative standard error sqrt(2 / S) = 3.1 % per output; averaged over the 8 x 64 outputs the two schemes agree to < 1 %
+    ratio = y3.var(0) / yi.var(0)
+    assert np.all(np.abs(ratio - 1) < 6 * np.sqrt(2 * 2.0 / S)), (ratio.min(), ratio.max())
+    assert abs(ratio.mean() - 1) < 1e-2, ratio.mean()
+    assert abs(ratio[:, :2].mean() - 1) < 4 * np.sqrt(2 * 2.0 / S / (2 * P))            # the adversarial outputs
+    # covariance of output pairs (the off-diagonal of the epistemic covariance): correlation coefficients agree within 6 / sqrt(S)
+    c3 = np.stack([np.corrcoef(y3[:, p, :8].T) for p in range(P)])
+    ci = np.stack([np.corrcoef(yi[:, p, :8].T) for p in range(P)])
+    assert np.abs(c3 - ci).max() < 6.0 / np.sqrt(S) * 1.5
