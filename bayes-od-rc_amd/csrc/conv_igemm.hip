@@ -2470,6 +2470,51 @@ static hipError_t launch_mx(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// f16mx: (hi, lo) bf16 pair rows -> hx rows (header of this file), one thread per (pixel, 16-channel slot): the pyramid the generic FPN
+// kernels wrote as pairs becomes the first tower layer's input, so that layer too runs on the f16 + MX-fp6 loop.  The slot's channels
+// 64q + 32m + 8 g4 + 4b + r are four runs of four: four 8-byte reads of hi and of lo, four 8-byte H-chunk writes, two 16-byte slot pieces.
+__global__ __launch_bounds__(256) void pairs_to_hx_kernel(const uint16_t* __restrict__ in, uint8_t* __restrict__ out, const long npix, const int C) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int spp = C / 16;                       // slots per pixel
+    if (t >= npix * spp) return;
+    const long pix = t / spp;
+    const int slot = (int)(t - pix * spp), q = slot >> 2, m = (slot >> 1) & 1, b = slot & 1;
+    const uint16_t* src = in + pix * 2 * C + (2 * q + m) * 64 + 4 * b;      // 32-channel block (2q + m): 32 hi then 32 lo
+    uint8_t* dst = out + pix * 4 * C + q * 256;
+    f32x16v hv, lv;
+    float mx = 6.103515625e-05f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const uint2 h2 = *reinterpret_cast<const uint2*>(src + 8 * g4), l2 = *reinterpret_cast<const uint2*>(src + 32 + 8 * g4);
+        float v[4] = {bf16_to_f32(h2.x & 0xFFFFu) + bf16_to_f32(l2.x & 0xFFFFu), bf16_to_f32(h2.x >> 16) + bf16_to_f32(l2.x >> 16),
+                      bf16_to_f32(h2.y & 0xFFFFu) + bf16_to_f32(l2.y & 0xFFFFu), bf16_to_f32(h2.y >> 16) + bf16_to_f32(l2.y >> 16)};
+        uint16_t hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+            const _Float16 hh = (_Float16)v[r];
+            hb[r] = __builtin_bit_cast(uint16_t, hh);
+            const float hf = (float)hh;
+            hv[g4 * 4 + r] = hf;
+            lv[g4 * 4 + r] = (v[r] - hf) * 2048.0f;
+            mx = fmaxf(mx, fabsf(v[r]));
+        }
+        *reinterpret_cast<uint2*>(dst + 2 * (32 * m + 8 * g4 + 4 * b)) = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+    }
+    const uint32_t eb = (__float_as_uint(mx * 1.0666667f) >> 23) - 2u;
+    const i32x6 pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(hv, lv, __uint_as_float(eb << 23));
+    *reinterpret_cast<uint4*>(dst + 128 + 64 * m + 16 * b) = make_uint4((uint32_t)pk[0], (uint32_t)pk[1], (uint32_t)pk[2], (uint32_t)pk[3]);
+    *reinterpret_cast<uint4*>(dst + 128 + 64 * m + 32 + 16 * b) = make_uint4((uint32_t)pk[4], (uint32_t)pk[5], 0u, eb);
+}
+
+hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s) {
+    if (C % 64 != 0 || npix <= 0) return hipErrorInvalidValue;
+    const long total = npix * (C / 16);
+    hipLaunchKernelGGL(pairs_to_hx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in),
+                       reinterpret_cast<uint8_t*>(out), npix, C);
+    return hipGetLastError();
+}
+
 // Persistent form of the row-reuse kernel: one workgroup per CU walks a contiguous range of (head, pixel tile) work
 // items, XCD x owning a contiguous eighth of them (neighbouring tiles share halo rows in that XCD's L2).  Removes the
 // workgroup retire / dispatch gap between tiles (measured with the phase clock: tiles cover 1.26-1.30 ms of a

@@ -53,6 +53,7 @@ struct Op {
     // samples inside the tile (bod_infer).  0 = the op belongs to both.
     int flavour = 0;
     int head[3] = {-1, -1, -1};          // per group: BOD_HEAD_* whose raw buffer the fused 1x1 writes (raw buffers are allocated lazily)
+    bool hx_pyramid = false;             // f16mx: this launch (the first tower layer) reads the pyramid as hx rows -- converted right in front of it
 };
 enum { FLAVOUR_BOTH = 0, FLAVOUR_RAW = 1, FLAVOUR_AGG = 2 };
 
@@ -203,6 +204,7 @@ struct bod_context {
     char* stem_out = nullptr;
     int es = 2;                                          // bytes per activation / weight CHANNEL (2 = bf16; 4 = fp32, or a (hi, lo) bf16 pair)
     bool split = false;                                  // bf16x3 precision: (hi, lo) bf16 pairs, three MFMA products (conv_igemm.hip)
+    char* pyr_hx = nullptr;                              // f16mx: the pyramid as hx rows [B][Ppad][1 KiB] (pairs_to_hx_kernel in front of the first tower layer)
     bool plan_mx = false;                                // ... and the plan really runs them that way (BOD_TOWER_MX=0 / BOD_CONV_XREUSE=0: bf16x3 towers)
     bool mx = false;                                     // f16mx precision: bf16x3 everywhere but the head towers, which run one f16 + half a block-scaled e2m3 product per multiplication (conv_igemm.hip header)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
@@ -874,6 +876,12 @@ bod_status build_plan(bod_context* h) {
         xreuse0 = xreuse0 && conv_igemm_uses_full_cout_tile(probe);
     }
     if (mx_plan) xreuse0 = true;           // (the first tower layer writes the hx rows the next one reads)
+    // ... and reads hx rows itself: the pyramid, which the FPN's kernels write as (hi, lo) pairs, is converted once per forward (1.5 GB
+    // in, 1.5 GB out per 256 frames: 0.7 ms) so that the three first-layer convs run at 1.5 instead of 3 products too.  Not on overlap
+    // handles (two pyramid buffers).  BOD_MX_LAYER0=0: the bf16x3 loop on the pair rows (conv_igemm_mx_kernel<2>).
+    bool mx_l0 = mx_plan && !c.pipeline_overlap;
+    if (const char* e = getenv("BOD_MX_LAYER0")) mx_l0 = mx_l0 && atoi(e) != 0;
+    if (mx_l0) BODCHK(h->dalloc(&h->pyr_hx, (size_t)B * h->Ppad * 256 * 4));
     if (xreuse0) BODCHK(make_xr_tiles(t1, &d1x, &dext1, &m1x));
 
     const bool mc = train_mode || std::max(N, c.mc_ensemble_size) > 1;    // mc_dropout_enabled (retinanet_model.py:74-77); training: dropout on (:113-129)
@@ -939,12 +947,12 @@ bod_status build_plan(bod_context* h) {
             if (layer >= kHeadConvs[hd]) continue;
             if (split_launch && (part == 1) != (layer == kHeadConvs[hd] - 1)) continue;
             PackedConv pc;
-            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc, mx_plan && layer > 0));
+            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc, mx_plan && (layer > 0 || mx_l0)));
             if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
                 return h->fail(BOD_ERR_INVALID_ARG, "head conv %s_%d must be 3x3 256->256", kHeadPrefix[hd], layer);
             op.wname[g] = std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer);
             ConvGroup cg{};
-            cg.in = layer == 0 ? h->pyramid.d : (train_mode ? h->head_act_t[hd][layer - 1] : h->head_act[hd][(layer + 1) & 1]);
+            cg.in = layer == 0 ? (mx_l0 ? h->pyr_hx : h->pyramid.d) : (train_mode ? h->head_act_t[hd][layer - 1] : h->head_act[hd][(layer + 1) & 1]);
             cg.w = pc.w; cg.bias = pc.bias;
             cg.out = train_mode ? h->head_act_t[hd][layer] : h->head_act[hd][layer & 1];
             cg.layer_id = hd * 4 + layer;
@@ -976,7 +984,8 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
-        a.mx = mx_plan ? (layer == 0 ? 2 : 1) : 0;
+        a.mx = mx_plan ? ((layer == 0 && !mx_l0) ? 2 : 1) : 0;
+        op.hx_pyramid = mx_l0 && layer == 0;
         {   // BOD_MX_LOADER=0|1|2: which waves of the f16mx loop issue the weight pieces (conv_igemm.hip: all / lower four / upper four)
             // (same-box A/B at 256 frames, two rounds each: towers 198.0 / 196.2 / 199.7 ms with 0 / 1 / 2)
             static const int mx_loader = getenv("BOD_MX_LOADER") ? atoi(getenv("BOD_MX_LOADER")) : 1;
@@ -1235,6 +1244,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                                            h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
                 break;
             case Op::CONV: {
+                if (op.hx_pyramid) HIPCHK(h, launch_pairs_to_hx(h->pyramid.d, h->pyr_hx, (long)c.batch * h->Ppad, 256, st));
                 op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
                 op.conv.image_base = first_image;
                 op.conv.sample_base = (uint32_t)c.mc_sample_base;

@@ -137,6 +137,8 @@ bool conv_igemm_uses_full_cout_tile(const ConvArgs& a);   // true => 256-wide co
 bool conv_igemm_uses_big_tile(const ConvArgs& a);         // true => the 256x256 tile (any cout); false => 128-pixel tiles
 void conv_igemm_phase_cycles(unsigned long long* out16, bool reset);   // instrumented build (variant 90)
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
+// f16mx precision: (hi, lo) bf16 pair rows [npix][2C] -> hx rows [npix][4C bytes] (conv_igemm.hip; C a multiple of 64)
+hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Stem + pooling + small elementwise (aux_kernels.hip)
