@@ -217,15 +217,31 @@ __device__ __forceinline__ void mfma_f16_32_inplace(f32x16& c, const bf16x8& a, 
 //    through `wr`, and they never overlap between two barriers (the stage / extended-row buffer being read against the ones being filled)
 //    -- without that the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows an LDS-DMA issue (it cannot tell the
 //    stages apart): a full L2 / HBM round trip with the matrix pipe idle per piece.
+// (f16mx4: the cross terms as ONE block-scaled e2m1 product -- four-register operands, the block's E8M0 scale = byte KS of the lane's
+// scale registers: op_sel / op_sel_hi carry bit 0 / bit 1 of the byte index of A and B)
+template <int KS>
+__device__ __forceinline__ void mfma_mx4_inplace(f32x16& c, const bf16x8& a, const bf16x8& b, int sa, int sb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KS == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else if constexpr (KS == 1) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[1,1,0] op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else if constexpr (KS == 2) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,1,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[1,1,0] op_sel_hi:[1,1,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#endif
+}
 template <int FP>
 struct HxCarry {                 // the first step's operands of a K-tile, requested during the K-tile before
     bf16x8 hA, hB[FP];
     i32x6 xA, xB[FP];
     int xsa, xsb[FP];
+    int sa4[4];                  // f16mx4: the K-tile's A scales (dword i = the four k-steps' bytes of cout fragment i); B scales in xsb
 };
-template <int FC, int FP, int ROWB, bool XT, bool NXT, class SYNC, class SLOT>
+// F4 (f16mx4): X tiles are the cross terms of 128 channels as four e2m1 products of K = 64 -- operands = the 16-byte pieces of k-step ks
+// like an H tile's, scales from the two scale arrays in LDS: `ws` = the lane's dword of cout fragment 0 (fragment i: + 256 i bytes),
+// `xs[j]` = the dword of the lane's pixel row of fragment j; `ws_n` / `xs_n`: the next K-tile's.
+template <int FC, int FP, int ROWB, bool XT, bool NXT, bool F4 = false, class SYNC, class SLOT>
 __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __restrict__ rd, char* __restrict__ wr, const int wa, const int (&xb)[FP],
-                                         const int wa_n, const int (&xb_n)[FP], const bool has_next, HxCarry<FP>& c, SYNC&& sync, SLOT&& slot) {
+                                         const int wa_n, const int (&xb_n)[FP], const bool has_next, HxCarry<FP>& c, SYNC&& sync, SLOT&& slot,
+                                         const int ws_n = 0, const int* xs_n = nullptr) {
     auto ldH = [&](int base, int ks) { return *reinterpret_cast<const bf16x8*>(rd + (base ^ (ks << 5))); };
     // an X operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read straight
     // into a 6-register tuple and one scale register.  The 8- and 4-byte reads run 2- / 4-way bank conflicts (rows r and r + 16 of a
@@ -243,15 +259,34 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
     };
     // X tiles: the A operand double-buffered (requested one step ahead; single-buffered measured 3 % slower on the towers)
     constexpr bool XA2 = true;
-    auto next_A = [&]() { if constexpr (NXT) c.xA = ld6(wa_n, 0, c.xsa); else c.hA = ldH(wa_n, 0); };
-    auto next_B = [&](int j) { if constexpr (NXT) c.xB[j] = ld6(xb_n[j], 0, c.xsb[j]); else c.hB[j] = ldH(xb_n[j], 0); };
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!XT) {
-        constexpr int NIT = 4 * FC;
-        bf16x8 Bf[FP], Af[2];
+    auto ldS = [&](int off) { return *reinterpret_cast<const int*>(rd + off); };
+    auto next_A = [&]() {
+        if constexpr (NXT && !F4) c.xA = ld6(wa_n, 0, c.xsa);
+        else {
+            c.hA = ldH(wa_n, 0);
+            if constexpr (NXT && F4) {
 #pragma unroll
-        for (int j = 0; j < FP; ++j) Bf[j] = c.hB[j];
+                for (int i = 0; i < 4; ++i) c.sa4[i] = ldS(ws_n + i * 256);
+            }
+        }
+    };
+    auto next_B = [&](int j) {
+        if constexpr (NXT && !F4) c.xB[j] = ld6(xb_n[j], 0, c.xsb[j]);
+        else { c.hB[j] = ldH(xb_n[j], 0); if constexpr (NXT && F4) c.xsb[j] = ldS(xs_n[j]); }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!XT || F4) {
+        constexpr int NIT = 4 * FC;
+        static_assert(!F4 || FC == 4, "f16mx4: four cout fragments per wave");
+        bf16x8 Bf[FP], Af[2];
+        int sa[4] = {0, 0, 0, 0}, sb[FP];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) { Bf[j] = c.hB[j]; sb[j] = (XT && F4) ? c.xsb[j] : 0; }
         Af[0] = c.hA;
+        if constexpr (XT && F4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa[i] = c.sa4[i];
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int ks = it / FC, i = it % FC, cur = it & 1;
@@ -260,7 +295,12 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
-                mfma_f16_32_inplace(acc[i][j], Af[cur], Bf[j]);
+                if constexpr (XT && F4) {
+                    if (ks == 0) mfma_mx4_inplace<0>(acc[i][j], Af[cur], Bf[j], sa[i & 3], sb[j]);
+                    else if (ks == 1) mfma_mx4_inplace<1>(acc[i][j], Af[cur], Bf[j], sa[i & 3], sb[j]);
+                    else if (ks == 2) mfma_mx4_inplace<2>(acc[i][j], Af[cur], Bf[j], sa[i & 3], sb[j]);
+                    else mfma_mx4_inplace<3>(acc[i][j], Af[cur], Bf[j], sa[i & 3], sb[j]);
+                } else mfma_f16_32_inplace(acc[i][j], Af[cur], Bf[j]);
                 if (i == FC - 1 && ks + 1 < 4) Bf[j] = ldH(xb[j], ks + 1);
                 if (it == NIT - 1 && has_next) next_B(j);
             }
@@ -526,7 +566,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     static_assert(!(SPLIT && ABL != 0), "the bf16x3 mode exists as production build only");
     static_assert(MXK == 0 || (SPLIT && XR), "f16mx: the row-reuse loop of the (hi, lo) data path only");
     // the f16mx loop; 11 = its phase-clock twin (tests/tools/bench_head_conv.py variant 90), 12 = the same without the loop's LDS-DMA (variant 91)
-    constexpr bool MXL = MXK == 1 || MXK == 11 || MXK == 12;
+    constexpr bool MXL = MXK == 1 || MXK == 11 || MXK == 12 || MXK == 3;
+    constexpr bool MX4 = MXK == 3;          // f16mx4: h4 rows in (4 H chunks + 2 X chunks of e2m1 cross terms + the scale bytes)
     constexpr bool MXI = MXK == 11 || MXK == 12;
     unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0, mx_t_cnt = 0;
     if constexpr (MXI) mx_t0 = __builtin_amdgcn_s_memtime();
@@ -562,7 +603,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     const int bp0 = bx * BP, bc0 = by * BC;
     const int cpt = a.cin / BK / nsplit;         // K-tiles per tap (of this split)
     const int c_begin = kpart * cpt;
-    const int KT = a.taps * cpt;
+    const int KT = MX4 ? a.taps * 6 : a.taps * cpt;          // (h4 rows: six of the eight 128-byte chunks are K-tiles)
     const int wrow = a.taps * a.cin;             // elements per weight row [cout][taps][cin]
 
     // ---- per-thread staging descriptors
@@ -1009,6 +1050,40 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + w3 * 64) * 16), 16, lane_off, off, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + (kt_ & 1) * WST + (piece * THREADS + (w3 + 4) * 64) * 16), 16, lane_off, off2, 0, 0);
             };
+            // f16mx4: the scale bytes of an X K-tile's weights (chunk 6 of the tap's 1 024 bytes: [x][half][ks]) and of an X group's extended
+            // rows (chunk 6 of the row) travel as 4-byte LDS-DMA pieces -- one lane per (row, half): [row][half] dwords in LDS, the dword's
+            // byte ks = the block's E8M0 scale (op_sel of the MFMA).  Weights: with weight piece 1 (older than the extended rows' pieces:
+            // the wait in front of the barrier covers it); rows: in slot 6 of the group's first K-tile, behind the rows' first three pieces.
+            constexpr int OFF_WS = Cfg::LDS, OFF_XS = OFF_WS + 2 * 2048, XSB = XR_EXT_ROWS * 8;
+            uint32_t wslane = 0, xso[2] = {0u, 0u};
+            int xsp[2] = {0, 0};
+            if constexpr (MX4) {
+                wslane = (uint32_t)(tid * 16);
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) {
+                    const int r = p_ * 256 + (tid >> 1);
+                    const int2 e = a.ext[(size_t)bx * XR_EXT_ROWS + (r < XR_EXT_ROWS ? r : 0)];
+                    xso[p_] = ((uint32_t)(e.x - ext_first) * (uint32_t)a.in_cstride) * 2u + 768u + (uint32_t)(tid & 1) * 4u;
+                    xsp[p_] = e.y * a.in_cstride * 2;
+                }
+            }
+            auto dma_ws = [&](const int kt_, char* __restrict__ wr) {          // the scales of X K-tile kt_ (chunk 2 or 5 of its tap)
+                // (a compact copy behind the 256 weight rows: [tap][x][cout][half][ks], 2 KiB per X K-tile = sixteen 128-byte lines; the
+                //  same bytes out of the rows' own scale chunks are 256 lines -- as many L2 requests as the K-tile's weights)
+                if (wave >= 2) return;
+                const int ch = kt_ / 9, tap = kt_ - ch * 9;
+                int off = 256 * wrow * 2 + (tap * 2 + (ch >= 3 ? 1 : 0)) * 2048;
+                asm volatile("" : "+s"(off));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(wr + OFF_WS + (kt_ & 1) * 2048 + wave * 1024), 16, (int)wslane, off, 0, 0);
+            };
+            auto dma_xs = [&](const int g_, const int ky_, const int x_, char* __restrict__ wr) {      // the scales of X group g_'s extended rows
+                const int v0 = (int)xso[0] + ky_ * xsp[0] + x_ * 8;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(wr + OFF_XS + (g_ & 1) * XSB + wave * 256), 4, v0, 0, 0, 0);
+                if (wave < (XR_EXT_ROWS - 256) / 32) {
+                    const int v1 = (int)xso[1] + ky_ * xsp[1] + x_ * 8;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(wr + OFF_XS + (g_ & 1) * XSB + 2048 + wave * 256), 4, v1, 0, 0, 0);
+                }
+            };
             HxCarry<FP> carry;
             // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); piece 0 of K-tile 1 behind them
             if (KT > 1 && MXK != 12) dma_w(0, 1, smem);
@@ -1022,6 +1097,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             auto group = [&](const int g, auto XT, auto LASTB) {
                 constexpr bool xt = decltype(XT)::value;
                 constexpr bool last_of_block = decltype(LASTB)::value;          // the next group has the other flavour
+                constexpr bool xt_next_group = last_of_block ? !xt : xt;
                 const bool xnext = g + 1 < NG && MXK != 12;
                 const bool next_row = ky + 1 < 3;
                 const int xdst = 2 * WST + ((g + 1) & 1) * XBUF;
@@ -1050,13 +1126,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         xb_[j] = xbase + r * ROWB + ((fhalf ^ ((r >> 1) & 7)) << 4);
                         xb_n[j] = xbase_n + rn * ROWB + ((fhalf ^ ((rn >> 1) & 7)) << 4);
                     }
+                    // f16mx4: scale dwords of the NEXT K-tile (weights: stage of kt + 1; rows: the group's array, the tap's row)
+                    int ws_n = 0, xs_n[FP];
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) xs_n[j] = 0;
+                    if constexpr (MX4 && nxt) {
+                        ws_n = OFF_WS + ((kt + 1) & 1) * 2048 + ((wc * WTC + frow) * 2 + fhalf) * 4;
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) {
+                            const int rn = kxc < 2 ? xrow_[j] + kxc + 1 : xrow_[j];
+                            xs_n[j] = OFF_XS + ((kxc < 2 ? g : g + 1) & 1) * XSB + (rn * 2 + fhalf) * 4;
+                        }
+                    }
+                    // the extended rows' scale pieces of the next group leave in this group's first K-tile (slot 6), when it is an X group
+                    constexpr bool xs_here = MX4 && xt_next_group && kxc == 0;
                     unsigned long long mx_tb = 0;
                     if constexpr (MXI) mx_tb = __builtin_amdgcn_s_memtime();
-                    hx_ktile<FC, FP, ROWB, xt, nxt>(acc, smem, smem, wa_, xb_, wa_n, xb_n, has_next, carry,
+                    hx_ktile<FC, FP, ROWB, xt, nxt, MX4>(acc, smem, smem, wa_, xb_, wa_n, xb_n, has_next, carry,
                         [&]() {
                             unsigned long long ta = 0;
                             if constexpr (MXI) ta = __builtin_amdgcn_s_memtime();
-                            if (xnext && kxc == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                            if (xs_here && xnext) {
+                                if (wave < (XR_EXT_ROWS - 256) / 32) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+                                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                            }
+                            else if (xnext && kxc == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
                             else if (xnext && kxc == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                             unsigned long long tm = 0;
@@ -1067,7 +1161,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                         [&](const int k, char* __restrict__ wr) {
                             if (MXK == 12) return;
                             if (k == 7) { if (kt + 2 < KT) dma_w(0, kt + 2, wr); }
-                            else if (k < 3) { if (kt + 1 < KT) dma_w(k + 1, kt + 1, wr); }
+                            else if (k < 3) {
+                                if (kt + 1 < KT) { dma_w(k + 1, kt + 1, wr); if constexpr (MX4 && nxt) { if (k == 0) dma_ws(kt + 1, wr); } }
+                            }
+                            else if (xs_here && k == 6) { if (xnext) dma_xs(g + 1, next_row ? ky + 1 : 0, (next_row ? cc : cc + 1) >= 3 ? 1 : 0, wr); }
                             else if (xnext && k < 6 && kxc < 2) {
                                 const int i = kxc == 0 ? k - 3 : k;          // pieces 0..2 | 3..4
                                 if (i < NXE) {
@@ -1075,12 +1172,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(wr + xdst + (i * THREADS + wave * 64) * 16), 16, (int)xo[i], 0, 0, 0);
                                 }
                             }
-                        });
+                        }, ws_n, xs_n);
                     if constexpr (MXI) mx_t_body += __builtin_amdgcn_s_memtime() - mx_tb;
                 };
                 ktile(std::integral_constant<int, 0>{}); ktile(std::integral_constant<int, 1>{}); ktile(std::integral_constant<int, 2>{});
                 if (++ky == 3) { ky = 0; ++cc; }
             };
+            if constexpr (MX4) {          // per 128 channels: two H chunks, then the X chunk of their cross terms
+                for (int g0 = 0; g0 < NG; g0 += 9) {
+                    group(g0, std::false_type{}, std::false_type{}); group(g0 + 1, std::false_type{}, std::false_type{}); group(g0 + 2, std::false_type{}, std::false_type{});
+                    group(g0 + 3, std::false_type{}, std::false_type{}); group(g0 + 4, std::false_type{}, std::false_type{}); group(g0 + 5, std::false_type{}, std::true_type{});
+                    group(g0 + 6, std::true_type{}, std::false_type{}); group(g0 + 7, std::true_type{}, std::false_type{}); group(g0 + 8, std::true_type{}, std::true_type{});
+                }
+            } else
             for (int g0 = 0; g0 < NG; g0 += 6) {
                 group(g0, std::false_type{}, std::false_type{}); group(g0 + 1, std::false_type{}, std::false_type{}); group(g0 + 2, std::false_type{}, std::true_type{});
                 group(g0 + 3, std::true_type{}, std::false_type{}); group(g0 + 4, std::true_type{}, std::false_type{}); group(g0 + 5, std::true_type{}, std::true_type{});
@@ -1528,6 +1632,76 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 const uint32_t img = rng_image_base + ((uint32_t)rg.y >> 16);
                 const uint32_t sample = a.sample_base + (a.fan_count > 1 ? (uint32_t)n : ((uint32_t)rg.y & 0xFFFFu));
                 if constexpr (MXK != 0) {
+                    if (G.out_hx == 2) {
+                        // ---- f16mx4: the row leaves in the h4 format (header of this file): f16 hi to the H chunks (chunk 3 (q >> 1) + (q & 1) of
+                        // 64-channel group q), the lane's 16 channels of cout fragment i = block (x = wc, ks = i, half = fhalf) of X chunk
+                        // 3 wc + 2: sixteen v_cvt_scalef32_pk_fp4_f32 pack {hi4, lo4'} pairs (byte k = channel k of the block) under the
+                        // block's scale 2^e, e = floor(log2(max * 4/3)) - 2 (the largest |hi| lands in [3, 6], |lo'| <= 4); the four scale
+                        // bytes of the lane's blocks = one dword of the scale chunk (chunk 6, byte 8 wc + 4 fhalf + i).
+                        static_assert(BC == 256 && WC == 2, "h4 epilogue: 256-cout tile, two cout halves");
+                        int fr_i = frow, fh_i = fhalf;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" : "+v"(fr_i), "+v"(fh_i));
+#endif
+                        const int lr = wp * WPP + jj * 32 + fr_i;
+                        char* prow = smem + lr * ROW2;
+                        uint32_t sdw = 0u;
+#pragma unroll
+                        for (int i = 0; i < FC; ++i) {
+                            const int col0 = wc * WTC + i * 32 + fh_i * 4;            // channel of (g4 = 0, r = 0)
+                            Philox4 rr{0u, 0u, 0u, 0u};
+                            if (drop) rr = philox4x32_10((uint32_t)rg.x, dropout_group16(bc0 + col0), sample | ((uint32_t)G.layer_id << 16), img, rng_seed_lo, rng_seed_hi);
+                            float hv[16], lv[16];
+                            float mx = 6.103515625e-05f;                              // 2^-14
+                            const int q = col0 >> 6;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int col = col0 + g4 * 8;
+                                const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
+                                float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
+                                              __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
+                                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                                if (drop) {
+                                    const DropPair dw = dropout_run_windows(rr, g4);
+                                    const uint32_t thr = a.drop_threshold;
+                                    v[0] = (dw.x & 0xFFFFu) >= thr ? v[0] : 0.f; v[1] = (dw.x >> 16) >= thr ? v[1] : 0.f;
+                                    v[2] = (dw.y & 0xFFFFu) >= thr ? v[2] : 0.f; v[3] = (dw.y >> 16) >= thr ? v[3] : 0.f;
+                                }
+                                uint16_t hb[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+                                    const _Float16 hh = (_Float16)v[r];
+                                    hb[r] = __builtin_bit_cast(uint16_t, hh);
+                                    const float hf = (float)hh;
+                                    hv[g4 * 4 + r] = hf;
+                                    lv[g4 * 4 + r] = (v[r] - hf) * 2048.0f;
+                                    mx = fmaxf(mx, fabsf(hf));
+                                }
+                                const int c64 = col & 63, chH = (3 * (q >> 1) + (q & 1)) * 8 + (c64 >> 3);
+                                *reinterpret_cast<uint2*>(prow + (((chH ^ lr) & (CPR2 - 1)) << 4) + (c64 & 7) * 2) =
+                                    make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+                            }
+                            const uint32_t eb = (__float_as_uint(mx * 1.3333334f) >> 23) - 2u;      // biased exponent = the E8M0 byte
+                            const float sc = __uint_as_float(eb << 23);
+                            uint32_t pk[4];
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                uint32_t w_ = 0u;
+                                w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 0], lv[4 * d + 0], sc, 0);
+                                w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 1], lv[4 * d + 1], sc, 1);
+                                w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 2], lv[4 * d + 2], sc, 2);
+                                w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 3], lv[4 * d + 3], sc, 3);
+                                pk[d] = w_;
+                            }
+                            const int chX = (3 * wc + 2) * 8 + 2 * i + fh_i;
+                            *reinterpret_cast<uint4*>(prow + (((chX ^ lr) & (CPR2 - 1)) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                            sdw |= eb << (8 * i);
+                            __builtin_amdgcn_sched_barrier(0);           // one fragment at a time (register pressure)
+                        }
+                        *reinterpret_cast<uint32_t*>(prow + (((48 ^ lr) & (CPR2 - 1)) << 4) + wc * 8 + fh_i * 4) = sdw;
+                        continue;
+                    }
                     if (G.out_hx) {
                         // ---- f16mx: the row leaves in the hx format (header of this file).  A lane's 16 channels of cout fragment i --
                         // 32i + 8*g4 + 4*fhalf + r -- are exactly one MX block: f16 hi to the H chunk (4 x 8 bytes), then ONE
@@ -2458,15 +2632,17 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_mx_kernel(const ConvArgs a)
 template <int MXK>
 static hipError_t launch_mx(const ConvArgs& a, hipStream_t s) {
     using Cfg = ConvCfg<256, 256, 2, 4, true>;
+    constexpr int LDS = Cfg::LDS + (MXK == 3 ? 2 * 2048 + 2 * XR_EXT_ROWS * 8 : 0);          // f16mx4: + the two scale arrays, double-buffered
+    static_assert(LDS <= 160 * 1024, "LDS of a compute unit");
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
     auto kern = conv_igemm_mx_kernel<MXK>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 255) / 256, 1, a.groups), dim3(Cfg::THREADS), Cfg::LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + 255) / 256, 1, a.groups), dim3(Cfg::THREADS), LDS, s, a);
     return hipGetLastError();
 }
 
@@ -2507,8 +2683,62 @@ __global__ __launch_bounds__(256) void pairs_to_hx_kernel(const uint16_t* __rest
     *reinterpret_cast<uint4*>(dst + 128 + 64 * m + 32 + 16 * b) = make_uint4((uint32_t)pk[4], (uint32_t)pk[5], 0u, eb);
 }
 
-hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s) {
+// f16mx4: (hi, lo) bf16 pair rows -> h4 rows (engine.hip, pack_h4_row), one thread per (pixel, MX block): block (x, ks, b) = channels
+// 128x + 32 ks + 8 g4 + 4b + r -- the same four runs of four as above.
+__global__ __launch_bounds__(256) void pairs_to_h4_kernel(const uint16_t* __restrict__ in, uint8_t* __restrict__ out, const long npix) {
+    constexpr int C = 256;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= npix * 16) return;
+    const long pix = t >> 4;
+    const int slot = (int)(t & 15), x = slot >> 3, ks = (slot >> 1) & 3, b = slot & 1;
+    const uint16_t* src = in + pix * 2 * C + (4 * x + ks) * 64 + 4 * b;      // 32-channel block 4x + ks: 32 hi then 32 lo
+    uint8_t* dst = out + pix * 4 * C;
+    const int q = 2 * x + (ks >> 1);
+    uint8_t* H = dst + (3 * (q >> 1) + (q & 1)) * 128 + 2 * ((32 * ks) & 63);
+    float hv[16], lv[16];
+    float mx = 6.103515625e-05f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const uint2 h2 = *reinterpret_cast<const uint2*>(src + 8 * g4), l2 = *reinterpret_cast<const uint2*>(src + 32 + 8 * g4);
+        float v[4] = {bf16_to_f32(h2.x & 0xFFFFu) + bf16_to_f32(l2.x & 0xFFFFu), bf16_to_f32(h2.x >> 16) + bf16_to_f32(l2.x >> 16),
+                      bf16_to_f32(h2.y & 0xFFFFu) + bf16_to_f32(l2.y & 0xFFFFu), bf16_to_f32(h2.y >> 16) + bf16_to_f32(l2.y >> 16)};
+        uint16_t hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
+            const _Float16 hh = (_Float16)v[r];
+            hb[r] = __builtin_bit_cast(uint16_t, hh);
+            const float hf = (float)hh;
+            hv[g4 * 4 + r] = hf;
+            lv[g4 * 4 + r] = (v[r] - hf) * 2048.0f;
+            mx = fmaxf(mx, fabsf(hf));
+        }
+        *reinterpret_cast<uint2*>(H + 2 * (8 * g4 + 4 * b)) = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+    }
+    const uint32_t eb = (__float_as_uint(mx * 1.3333334f) >> 23) - 2u;
+    const float sc = __uint_as_float(eb << 23);
+    uint32_t pk[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t w_ = 0u;
+        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 0], lv[4 * d + 0], sc, 0);
+        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 1], lv[4 * d + 1], sc, 1);
+        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 2], lv[4 * d + 2], sc, 2);
+        w_ = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w_, hv[4 * d + 3], lv[4 * d + 3], sc, 3);
+        pk[d] = w_;
+    }
+    *reinterpret_cast<uint4*>(dst + (3 * x + 2) * 128 + (2 * ks + b) * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    dst[6 * 128 + 8 * x + 4 * b + ks] = (uint8_t)eb;
+}
+
+hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s, int fmt) {
     if (C % 64 != 0 || npix <= 0) return hipErrorInvalidValue;
+    if (fmt == 2) {
+        if (C != 256) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(pairs_to_h4_kernel, dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in),
+                           reinterpret_cast<uint8_t*>(out), npix);
+        return hipGetLastError();
+    }
     const long total = npix * (C / 16);
     hipLaunchKernelGGL(pairs_to_hx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(in),
                        reinterpret_cast<uint8_t*>(out), npix, C);
@@ -2726,13 +2956,14 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;
     if (a.mx) {                                      // f16mx precision: head-tower launches on the row-reuse loop, whatever the tile heuristics say
-        if ((a.mx != 1 && a.mx != 2) || !a.split || a.xreuse != 2 || a.cout_pad != 256 || a.cin != 512 || a.taps != 9 || a.KW != 3 || !a.ext || a.M % 256 != 0 ||
+        if ((a.mx < 1 || a.mx > 3) || !a.split || a.xreuse != 2 || a.cout_pad != 256 || a.cin != 512 || a.taps != 9 || a.KW != 3 || !a.ext || a.M % 256 != 0 ||
             (a.flags & CONV_OUT_F32) || a.ksplit > 1 || (a.variant != 0 && a.variant != 90 && a.variant != 91) || a.groups < 1 || a.groups > 3)
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g)
             if (a.g[g].res || a.g[g].out_relu || a.g[g].ch_w2 || a.g[g].ch_w3 || (a.g[g].w2 && (a.g[g].out_hx || a.fan_count > 1))) return hipErrorInvalidValue;
         if (a.variant == 90 && a.mx == 1) return launch_mx<11>(a, s);          // phase clock (tests/tools/bench_head_conv.py)
         if (a.variant == 91 && a.mx == 1) return launch_mx<12>(a, s);          // ... without the loop's LDS-DMA
+        if (a.mx == 3) return a.variant == 0 ? launch_mx<3>(a, s) : hipErrorInvalidValue;          // f16mx4: h4 rows in
         return a.mx == 1 ? launch_mx<1>(a, s) : launch_mx<2>(a, s);
     }
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();

@@ -163,6 +163,71 @@ void unpack_hx_row(const uint8_t* src, int C, float* v) {
     }
 }
 
+// e2m1 (OCP MX fp4): round to nearest even, saturating at 6; code = sign(1) exp(2) mant(1), bias 1, subnormal step 0.5
+uint32_t f2e2m1(float x) {
+    const uint32_t s = std::signbit(x) ? 8u : 0u;
+    float a = std::fabs(x);
+    if (!(a == a)) return s;
+    if (a >= 6.0f) return s | 7u;
+    static const float grid[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    uint32_t best = 0;
+    for (uint32_t c = 0; c < 7; ++c) {
+        const float mid = 0.5f * (grid[c] + grid[c + 1]);
+        if (a > mid || (a == mid && (c & 1u))) best = c + 1;          // ties to the even code
+    }
+    return s | best;
+}
+float e2m1_to_f(uint32_t c) {
+    static const float grid[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    return (c & 8u) ? -grid[c & 7u] : grid[c & 7u];
+}
+// One h4 row (f16mx4): C = 256 channels -> 1 024 bytes in eight 128-byte chunks: [H0 H1 X0 H2 H3 X1 S -].  Hq = the 64 f16 hi of channels
+// 64q..; Xx = the cross-term elements of channels 128x..: piece 2 ks + half (16 bytes) = the MX block of the 16 channels
+// 128x + 32 ks + 8 g4 + 4 half + r as 32 e2m1 nibbles, nibble 2k = hi4 (weights: lo4'), 2k + 1 = lo4' (weights: hi4), k = 4 g4 + r,
+// lo' = (v - hi) * 2^11, under the block's scale 2^(eb - 127), eb = biased exponent of (max(|hi|, 2^-14) * 4/3) - 2; S: byte
+// 8x + 4 half + ks = eb (weights: eb - 11).
+void pack_h4_row(const float* v, int C, uint8_t* dst, bool weights) {
+    std::memset(dst, 0, (size_t)C * 4);
+    for (int q = 0; q < C / 64; ++q) {
+        uint8_t* H = dst + (size_t)(3 * (q >> 1) + (q & 1)) * 128;
+        for (int c = 0; c < 64; ++c) { const uint16_t hb = f2h(v[q * 64 + c]); std::memcpy(H + 2 * c, &hb, 2); }
+    }
+    for (int x = 0; x < C / 128; ++x)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int b = 0; b < 2; ++b) {
+                float hi[16], lo[16], mx = 6.103515625e-05f;
+                for (int k = 0; k < 16; ++k) {
+                    const float xv = v[128 * x + 32 * ks + 8 * (k >> 2) + 4 * b + (k & 3)];
+                    hi[k] = h2f(f2h(xv)); lo[k] = (xv - hi[k]) * 2048.0f;
+                    mx = std::max(mx, std::fabs(hi[k]));
+                }
+                const float mxs = mx * 1.3333334f;
+                uint32_t ub; std::memcpy(&ub, &mxs, 4);
+                const uint32_t eb = (ub >> 23) - 2u;
+                const float inv = std::ldexp(1.0f, 127 - (int)eb);
+                uint8_t* piece = dst + (size_t)(3 * x + 2) * 128 + (2 * ks + b) * 16;
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t h4 = f2e2m1(hi[k] * inv), l4 = f2e2m1(lo[k] * inv);
+                    piece[k] = (uint8_t)(weights ? (l4 | (h4 << 4)) : (h4 | (l4 << 4)));
+                }
+                dst[6 * 128 + 8 * x + 4 * b + ks] = (uint8_t)(weights ? eb - 11u : eb);
+            }
+}
+void unpack_h4_row(const uint8_t* src, int C, float* v) {
+    for (int x = 0; x < C / 128; ++x)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int b = 0; b < 2; ++b) {
+                const uint8_t* piece = src + (size_t)(3 * x + 2) * 128 + (2 * ks + b) * 16;
+                const float sc = std::ldexp(1.0f, (int)src[6 * 128 + 8 * x + 4 * b + ks] - 127);
+                for (int k = 0; k < 16; ++k) {
+                    const int c = 128 * x + 32 * ks + 8 * (k >> 2) + 4 * b + (k & 3);
+                    const int q = c >> 6;
+                    uint16_t hb; std::memcpy(&hb, src + (size_t)(3 * (q >> 1) + (q & 1)) * 128 + 2 * (c & 63), 2);
+                    v[c] = h2f(hb) + e2m1_to_f((uint32_t)piece[k] >> 4) * sc * (1.0f / 2048.0f);
+                }
+            }
+}
+
 }  // namespace
 
 struct bod_context {
@@ -205,8 +270,9 @@ struct bod_context {
     int es = 2;                                          // bytes per activation / weight CHANNEL (2 = bf16; 4 = fp32, or a (hi, lo) bf16 pair)
     bool split = false;                                  // bf16x3 precision: (hi, lo) bf16 pairs, three MFMA products (conv_igemm.hip)
     char* pyr_hx = nullptr;                              // f16mx: the pyramid as hx rows [B][Ppad][1 KiB] (pairs_to_hx_kernel in front of the first tower layer)
-    bool plan_mx = false;                                // ... and the plan really runs them that way (BOD_TOWER_MX=0 / BOD_CONV_XREUSE=0: bf16x3 towers)
-    bool mx = false;                                     // f16mx precision: bf16x3 everywhere but the head towers, which run one f16 + half a block-scaled e2m3 product per multiplication (conv_igemm.hip header)
+    int pyr_fmt = 1;                                     // format of `pyr_hx` (1 hx, 2 h4)
+    int plan_mx = 0;                                     // ... and the plan really runs them that way (BOD_TOWER_MX=0 / BOD_CONV_XREUSE=0: bf16x3 towers)
+    int mx = 0;                                          // 1 = f16mx, 2 = f16mx4 (the cross terms as ONE e2m1 product of twice the channels; h4 rows).  f16mx precision: bf16x3 everywhere but the head towers, which run one f16 + half a block-scaled e2m3 product per multiplication (conv_igemm.hip header)
     Plane pyramid;                                       // all levels, [B][Ppad][256]
     char* head_act[3][2] = {{nullptr}};              // [B][N][Ppad][256]
     char* head_act_t[3][4] = {{nullptr}};            // training: one buffer per tower layer
@@ -371,8 +437,8 @@ const HostTensor* find_w(bod_context* h, const std::string& name, int kind) {
 
 // Fold BN (double), pack OHWI bf16 padded to cout_pad, upload.
 bod_status pack_conv(bod_context* h, const std::string& name, const std::string& bn, int cout_pad_to,
-                     PackedConv* out, bool hx = false) {
-    const std::string ckey = hx ? name + ":hx" : name;             // (f16mx: tower layers 1.. are packed as hx rows, everything else as pairs)
+                     PackedConv* out, int hx = 0) {          // hx: 0 = the data path's own form, 1 = hx rows (f16mx), 2 = h4 rows (f16mx4)
+    const std::string ckey = hx == 2 ? name + ":h4" : hx ? name + ":hx" : name;             // (f16mx: tower layers 1.. are packed as hx rows, everything else as pairs)
     auto it = h->packed.find(ckey);
     if (it != h->packed.end()) { *out = it->second; return BOD_OK; }
     const HostTensor* k = find_w(h, name, 0);
@@ -420,12 +486,27 @@ bod_status pack_conv(bod_context* h, const std::string& name, const std::string&
         for (int o = 0; o < cout; ++o)
             for (int t = 0; t < pc.taps; ++t) {
                 for (int c = 0; c < cin; ++c) row[c] = (float)((double)k->data[((size_t)t * cin + c) * cout + o] * scale[o]);
-                pack_hx_row(row.data(), cin, wb + ((size_t)o * pc.taps + t) * cin * 4, true);
+                if (hx == 2) {
+                    if (cin != 256) return h->fail(BOD_ERR_INVALID_ARG, "h4 weights: 256 input channels");
+                    pack_h4_row(row.data(), cin, wb + ((size_t)o * pc.taps + t) * cin * 4, true);
+                } else pack_hx_row(row.data(), cin, wb + ((size_t)o * pc.taps + t) * cin * 4, true);
             }
     }
-    BODCHK(h->dalloc(&pc.w, nw * h->es, false));
+    size_t w_extra = 0;
+    if (hx == 2) {          // ... + a compact copy of the scale bytes behind the rows: [tap][x][cout][half][ks], what the kernel's scale pieces read
+        if (pc.cout_pad != 256) return h->fail(BOD_ERR_INVALID_ARG, "h4 weights: one 256-cout tile");
+        w_extra = (size_t)pc.taps * 2 * 2048;
+        w.resize(w.size() + w_extra / 2, 0);
+        uint8_t* wb = reinterpret_cast<uint8_t*>(w.data());
+        uint8_t* sc = wb + nw * h->es;
+        for (int t = 0; t < pc.taps; ++t)
+            for (int x = 0; x < 2; ++x)
+                for (int o = 0; o < 256; ++o)
+                    std::memcpy(sc + ((size_t)(t * 2 + x) * 256 + o) * 8, wb + ((size_t)o * pc.taps + t) * cin * 4 + 768 + 8 * x, 8);
+    }
+    BODCHK(h->dalloc(&pc.w, nw * h->es + w_extra, false));
     BODCHK(h->dalloc(&pc.bias, bias.size(), false));
-    HIPCHK(h, hipMemcpyAsync(pc.w, as_f32 ? (const void*)w32.data() : (const void*)w.data(), nw * h->es,
+    HIPCHK(h, hipMemcpyAsync(pc.w, as_f32 ? (const void*)w32.data() : (const void*)w.data(), nw * h->es + w_extra,
                              hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -842,7 +923,8 @@ bod_status build_plan(bod_context* h) {
     if (const char* e = getenv("BOD_CONV_XREUSE")) xreuse = xreuse && atoi(e) != 0;
     // f16mx precision: the towers' arithmetic exists in the row-reuse kernel only, which therefore runs them at every size (the tile
     // heuristics below choose between kernels of equal results; here the kernel IS the arithmetic).  BOD_TOWER_MX=0: plain bf16x3 towers.
-    bool mx_plan = h->mx && xreuse;
+    bool mx_plan = h->mx != 0 && xreuse;
+    const int mxf = h->mx;                 // tower row format: 1 = hx, 2 = h4
     if (const char* e = getenv("BOD_TOWER_MX")) mx_plan = mx_plan && atoi(e) != 0;
     {
         ConvArgs probe{};
@@ -927,16 +1009,28 @@ bod_status build_plan(bod_context* h) {
     } else {
         BODCHK(ensure_raw(h));                 // the ops below reference the raw tensors directly
     }
-    h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0; h->plan_mx = mx_plan;
+    h->agg_plan = agg; h->plan_fused_out = fuse_out; h->plan_xreuse = xreuse; h->plan_xreuse0 = xreuse0; h->plan_mx = mx_plan ? mxf : 0;
     // A layer's launch takes the sample-complete ("aggregated") tiling only for the heads that END there (fused 1x1 + MC aggregation): such
     // a tile holds 25 pixels x 10 samples = 250 of its 256 rows (240 at N = 30), so every other head's conv of that layer -- the
     // classification and covariance towers at layer 2 -- would pay 2.8 % (6 %) more MFMA work for nothing.  Round 4: those heads run the
     // layer as their own launch on the plain tiling (part 0); the ending heads' launch (part 1) exists in the two flavours.
+    // f16mx4: all towers on h4 rows (e2m1 cross terms).  BOD_MX4_BOX_HX=1 keeps the box-regression tower on hx rows (e2m3) -- the epistemic
+    // covariance is a sample variance of N nearly equal boxes and amplifies the box outputs' rounding error; measured on the BASELINE-size
+    // frames: fused covariance entries 2.5e-3 -> 1.8e-3 (f16mx: 5e-4), 1 024 -> 1 000 frames/s (f16mx: 944) -- as separate launches from
+    // layer 1 on; layer 0 then reads ONE pyramid (hx) and writes each head's format.
+    int hfmt[3] = {mxf, mxf, mxf};
+    if (mxf == 2) { const char* e = getenv("BOD_MX4_BOX_HX"); if (e && atoi(e) != 0) hfmt[1] = 1; }
+    const bool mixed = mx_plan && hfmt[0] != hfmt[1];
+    const int pyr_fmt = mixed ? 1 : mxf;
+    h->pyr_fmt = pyr_fmt;
     for (int layer = 0; layer < 4; ++layer)
+    for (int fpass = 0; fpass < 2; ++fpass)
     for (int part = 0; part < 2; ++part)
     for (int flav = (agg && layer >= 2) ? FLAVOUR_RAW : FLAVOUR_BOTH; flav <= ((agg && layer >= 2) ? FLAVOUR_AGG : FLAVOUR_BOTH); ++flav) {
         static const bool split_on = [] { const char* e = getenv("BOD_SPLIT_AGG_LAUNCH"); return !e || atoi(e) != 0; }();     // (=0: one launch per layer on the aggregated tiling, A/B aid)
         const bool split_launch = agg && layer >= 2 && split_on;       // part 0: heads that continue, part 1: heads that end at this layer
+        if (fpass == 1 && (!mixed || layer == 0)) continue;
+        const int lfmt = !mx_plan ? 0 : layer == 0 ? pyr_fmt : mixed ? (fpass == 0 ? 2 : 1) : mxf;       // row format this launch READS
         if (!split_launch && part == 1) continue;
         if (split_launch && part == 0 && flav == FLAVOUR_AGG) continue;      // the continuing heads' launch is the same in both flavours: planned once
         const bool both = split_launch && part == 0;
@@ -946,8 +1040,9 @@ bod_status build_plan(bod_context* h) {
         for (int hd = 0; hd < nheads; ++hd) {
             if (layer >= kHeadConvs[hd]) continue;
             if (split_launch && (part == 1) != (layer == kHeadConvs[hd] - 1)) continue;
+            if (mixed && layer > 0 && hfmt[hd] != lfmt) continue;
             PackedConv pc;
-            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc, mx_plan && (layer > 0 || mx_l0)));
+            BODCHK(pack_conv(h, std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer), "", 128, &pc, (mx_plan && (layer > 0 || mx_l0)) ? lfmt : 0));
             if (pc.cin != 256 || pc.cout != 256 || pc.taps != 9)
                 return h->fail(BOD_ERR_INVALID_ARG, "head conv %s_%d must be 3x3 256->256", kHeadPrefix[hd], layer);
             op.wname[g] = std::string(kHeadPrefix[hd]) + "_" + std::to_string(layer);
@@ -956,7 +1051,7 @@ bod_status build_plan(bod_context* h) {
             cg.w = pc.w; cg.bias = pc.bias;
             cg.out = train_mode ? h->head_act_t[hd][layer] : h->head_act[hd][layer & 1];
             cg.layer_id = hd * 4 + layer;
-            cg.out_hx = (mx_plan && layer < kHeadConvs[hd] - 1) ? 1 : 0;      // read by the head's next tower layer: hx rows; a last layer feeds the 1x1: pairs
+            cg.out_hx = (mx_plan && layer < kHeadConvs[hd] - 1) ? hfmt[hd] : 0;      // read by the head's next tower layer: hx rows; a last layer feeds the 1x1: pairs
             if (fuse_out && layer == kHeadConvs[hd] - 1) {
                 PackedConv po;
                 BODCHK(pack_conv(h, kHeadPrefix[hd], "", 32, &po));
@@ -984,7 +1079,7 @@ bod_status build_plan(bod_context* h) {
         a.fan_count = layer == 0 ? N : 1;
         a.fan_stride = (int32_t)h->Ppad;
         a.drop_threshold = thr; a.drop_scale = dscale;
-        a.mx = mx_plan ? ((layer == 0 && !mx_l0) ? 2 : 1) : 0;
+        a.mx = mx_plan ? ((layer == 0 && !mx_l0) ? 2 : (lfmt == 2 ? 3 : 1)) : 0;
         op.hx_pyramid = mx_l0 && layer == 0;
         {   // BOD_MX_LOADER=0|1|2: which waves of the f16mx loop issue the weight pieces (conv_igemm.hip: all / lower four / upper four)
             // (same-box A/B at 256 frames, two rounds each: towers 198.0 / 196.2 / 199.7 ms with 0 / 1 / 2)
@@ -1244,7 +1339,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                                            h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
                 break;
             case Op::CONV: {
-                if (op.hx_pyramid) HIPCHK(h, launch_pairs_to_hx(h->pyramid.d, h->pyr_hx, (long)c.batch * h->Ppad, 256, st));
+                if (op.hx_pyramid) HIPCHK(h, launch_pairs_to_hx(h->pyramid.d, h->pyr_hx, (long)c.batch * h->Ppad, 256, st, h->pyr_fmt));
                 op.conv.seed_lo = (uint32_t)seed; op.conv.seed_hi = (uint32_t)(seed >> 32);
                 op.conv.image_base = first_image;
                 op.conv.sample_base = (uint32_t)c.mc_sample_base;
@@ -1448,11 +1543,11 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     if (!(c.dropout_rate >= 0.f && c.dropout_rate < 1.f)) return bail(h->fail(BOD_ERR_INVALID_ARG, "dropout_rate must be in [0,1)"));
     if (c.num_categorical_draws < 1 || c.num_categorical_draws > 1024) return bail(h->fail(BOD_ERR_INVALID_ARG, "num_categorical_draws out of range"));
     if (c.nms_max_output_size < 1 || c.nms_max_output_size > 512) return bail(h->fail(BOD_ERR_INVALID_ARG, "nms_max_output_size must be in [1,512]"));
-    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32 && c.precision != BOD_PRECISION_BF16X3 && c.precision != BOD_PRECISION_F16MX)
-        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0), BOD_PRECISION_FP32 (1), BOD_PRECISION_BF16X3 (2) or BOD_PRECISION_F16MX (3)"));
+    if (c.precision != BOD_PRECISION_BF16 && c.precision != BOD_PRECISION_FP32 && c.precision != BOD_PRECISION_BF16X3 && c.precision != BOD_PRECISION_F16MX && c.precision != BOD_PRECISION_F16MX4)
+        return bail(h->fail(BOD_ERR_INVALID_ARG, "precision must be BOD_PRECISION_BF16 (0), BOD_PRECISION_FP32 (1), BOD_PRECISION_BF16X3 (2), BOD_PRECISION_F16MX (3) or BOD_PRECISION_F16MX4 (4)"));
     h->es = c.precision == BOD_PRECISION_BF16 ? 2 : 4;
-    h->split = c.precision == BOD_PRECISION_BF16X3 || c.precision == BOD_PRECISION_F16MX;
-    h->mx = c.precision == BOD_PRECISION_F16MX;
+    h->split = c.precision == BOD_PRECISION_BF16X3 || c.precision == BOD_PRECISION_F16MX || c.precision == BOD_PRECISION_F16MX4;
+    h->mx = c.precision == BOD_PRECISION_F16MX ? 1 : c.precision == BOD_PRECISION_F16MX4 ? 2 : 0;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
     // BOD_MAIN_CUS_PER_XCD=k (development aid, tests/tools): the main stream owns only CU slots [0, k) of each of the 8 XCDs
     // (mask bit i = slot i / 8 of XCD i % 8: tests/tools/cu_mask_probe.hip)
@@ -2113,12 +2208,13 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
                           int32_t round_output_bf16, int32_t precision, float* out) {
     bod_context ctx;                      // scratch context: owns the temporary device buffers
     bod_context* h = &ctx;
-    const bool mxp = precision == BOD_PRECISION_F16MX;                 // f16mx tower kernel; round_output_bf16 = data path under test (bayesod.h)
+    const int mxfmt = precision == BOD_PRECISION_F16MX ? 1 : precision == BOD_PRECISION_F16MX4 ? 2 : 0;
+    const bool mxp = mxfmt != 0;                 // f16mx tower kernel; round_output_bf16 = data path under test (bayesod.h)
     const int mx_mode = mxp ? round_output_bf16 : 0;
     const bool f32 = precision == BOD_PRECISION_FP32, x3 = precision == BOD_PRECISION_BF16X3 || mxp;
     if (mxp) round_output_bf16 = 1;
     h->es = (f32 || x3) ? 4 : 2;
-    h->split = x3; h->mx = mxp;
+    h->split = x3; h->mx = mxfmt;
     auto done = [&](bod_status s) {
         if (s != BOD_OK) g_create_error = h->err;
         if (h->stream) hipStreamSynchronize(h->stream);
@@ -2131,7 +2227,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad argument"));
     if (precision != BOD_PRECISION_BF16 && !f32 && !x3) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: bad precision"));
     if (mxp && (KH != 3 || KW != 3 || stride != 1 || !same_padding || Cin != 256 || Cout != 256 || residual || mx_mode < 0 || mx_mode > 2))
-        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: BOD_PRECISION_F16MX runs a head-tower layer (3x3, stride 1, SAME, 256 -> 256, no residual), round_output_bf16 in 0..2"));
+        return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: BOD_PRECISION_F16MX / F16MX4 run a head-tower layer (3x3, stride 1, SAME, 256 -> 256, no residual), round_output_bf16 in 0..2"));
     if (f32 && round_output_bf16) return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: round_output_bf16 is meaningless in fp32 precision"));
     if (Cin % 64 != 0 || ((round_output_bf16 || (dropout_rate > 0.f && !f32)) && Cout % 4 != 0))
         return done(h->fail(BOD_ERR_INVALID_ARG, "bod_stage_conv: Cin must be a multiple of 64 (and Cout of 4 for bf16 output); got %d, %d", Cin, Cout));
@@ -2166,7 +2262,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
             for (int y = 0; y < H; ++y)
                 for (int xx = 0; xx < W; ++xx) {
                     const size_t pix = (size_t)b * in.bstride + (size_t)(y + 1) * in.pitch + (xx + 1);
-                    pack_hx_row(x + (((size_t)b * H + y) * W + xx) * Cin, Cin, reinterpret_cast<uint8_t*>(hx.data()) + pix * Cin * 4, false);
+                    (mxfmt == 2 ? pack_h4_row : pack_hx_row)(x + (((size_t)b * H + y) * W + xx) * Cin, Cin, reinterpret_cast<uint8_t*>(hx.data()) + pix * Cin * 4, false);
                 }
         for (int b = 0; b < B && !hx_in; ++b)
             for (int y = 0; y < H; ++y)
@@ -2201,7 +2297,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
         h->host_w["stage/0"] = std::move(k);
         if (bias) { HostTensor bt; bt.shape = {Cout}; bt.data.assign(bias, bias + Cout); h->host_w["stage/1"] = std::move(bt); }
         PackedConv pc;
-        BODCHK(pack_conv(h, "stage", "", 64, &pc, hx_in));
+        BODCHK(pack_conv(h, "stage", "", 64, &pc, hx_in ? mxfmt : 0));
         // dense fp32 / bf16 output [B,OH,OW,Cout]
         const bool drop = dropout_rate > 0.f;
         const size_t n_out = (size_t)B * OH * OW * Cout;
@@ -2238,8 +2334,8 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
             HIPCHK(h, hipMemcpyAsync(d_ext, ext.data(), ext.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             a.rows = d_tiled; a.M = (int)tiled.size(); a.ext = d_ext; a.xreuse = 2;
-            a.mx = mx_mode == 2 ? 2 : 1;
-            a.g[0].out_hx = mx_mode != 0;
+            a.mx = mx_mode == 2 ? 2 : (mxfmt == 2 ? 3 : 1);
+            a.g[0].out_hx = mx_mode != 0 ? mxfmt : 0;
         }
         a.flags = (relu ? CONV_RELU : 0) | (drop ? CONV_DROPOUT : 0) | ((f32_out && !f32) ? CONV_OUT_F32 : 0);
         if (stride == 1 && same_padding && KH == 3 && KW == 3) { a.plane_h = OH; a.plane_w = OW; }      // (the sliding-window kernels walk planes)
@@ -2263,7 +2359,7 @@ bod_status bod_stage_conv(int32_t device, const float* x, int32_t B, int32_t H, 
             HIPCHK(h, hipMemcpyAsync(ho.data(), d_out16, ho.size() * 2, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (mxp && mx_mode != 0) {
-                for (size_t px = 0; px < n_out / Cout; ++px) unpack_hx_row(reinterpret_cast<const uint8_t*>(ho.data()) + px * Cout * 4, Cout, out + px * Cout);
+                for (size_t px = 0; px < n_out / Cout; ++px) (mxfmt == 2 ? unpack_h4_row : unpack_hx_row)(reinterpret_cast<const uint8_t*>(ho.data()) + px * Cout * 4, Cout, out + px * Cout);
             } else if (x3) {
                 for (size_t px = 0; px < n_out / Cout; ++px)
                     for (int c = 0; c < Cout; ++c) {

@@ -138,7 +138,7 @@ bool conv_igemm_uses_big_tile(const ConvArgs& a);         // true => the 256x256
 void conv_igemm_phase_cycles(unsigned long long* out16, bool reset);   // instrumented build (variant 90)
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);      // conv_igemm_f32.hip (fp32 planes / weights)
 // f16mx precision: (hi, lo) bf16 pair rows [npix][2C] -> hx rows [npix][4C bytes] (conv_igemm.hip; C a multiple of 64)
-hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s);
+hipError_t launch_pairs_to_hx(const void* in, void* out, long npix, int C, hipStream_t s, int fmt = 1);          // fmt 1: hx rows, 2: h4 rows (f16mx4)
 
 // ------------------------------------------------------------------------------------------------
 // Stem + pooling + small elementwise (aux_kernels.hip)

@@ -12,7 +12,7 @@ from ._lib import BodConfig, BodSizes, as_f32, fptr, iptr
 _KINDS = {"kernel": 0, "bias": 1, "gamma": 2, "beta": 3, "mean": 4, "var": 5}
 # bod_config.precision (include/bayesod.h): bf16 = throughput path; fp32 = exact-fp32 MFMA; bf16x3 = (hi, lo) bf16 pairs with
 # three MFMA products, the 1e-3 end-to-end parity mode on the bf16 matrix pipe
-PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2, "f16mx": 3}
+PRECISIONS = {"bf16": 0, "fp32": 1, "bf16x3": 2, "f16mx": 3, "f16mx4": 4}
 
 
 def make_config(image_hw, batch=1, mc_samples=10, num_classes=8, anchors_per_location=9, device=0,
@@ -427,7 +427,7 @@ class Engine(object):
         info = (C.c_int32 * 8)()
         self._chk(self.lib.bod_plan_info(self.h, info))
         return {"aggregating": bool(info[0]), "fused_head_outputs": bool(info[1]), "row_reuse": bool(info[2]),
-                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4]), "plane_row_reuse_layers": int(info[5]), "tower_mx": bool(info[6])}
+                "fan_out_row_reuse": bool(info[3]), "ops": int(info[4]), "plane_row_reuse_layers": int(info[5]), "tower_mx": bool(info[6]), "tower_mx_format": int(info[6])}
 
     @property
     def aggregating(self):

@@ -54,8 +54,9 @@ PRODUCTION = [     # <BC, BP, WC, WP, ABL, XR, SPLIT>
     "conv_igemm_kernelILi256ELi256ELi2ELi4ELi9ELb1ELb0EE",     # head towers on the round-2 loop (top-of-K-tile barrier): A/B twin, BOD_TOWER_MIDBAR=0
     "conv_igemm_mx_kernelILi1EE",                              # f16mx precision: head towers, hx rows in (f16 + block-scaled e2m3 products, tied inline asm)
     "conv_igemm_mx_kernelILi2EE",                              # f16mx precision: first tower layer ((hi, lo) pairs in, hx rows out)
+    "conv_igemm_mx_kernelILi3EE",                              # f16mx4 precision: head towers, h4 rows in (f16 + block-scaled e2m1 products)
 ]
-MX_ASM_MFMA = ["conv_igemm_mx_kernelILi1EE"]                   # ... whose two MFMA flavours are tied inline asm on the 32x32 accumulators
+MX_ASM_MFMA = ["conv_igemm_mx_kernelILi1EE", "conv_igemm_mx_kernelILi3EE"]                   # ... whose two MFMA flavours are tied inline asm on the 32x32 accumulators
 MX_MFMA_RE = r"(?:v_mfma_scale_f32_32x32x64_f8f6f4|v_mfma_f32_32x32x16_f16)"
 INLINE_ASM_MFMA = PRODUCTION[:3] + PRODUCTION[12:13]           # the kernels on the 16x16x32 inline-asm loop
 INLINE_ASM_LDS = PRODUCTION[:3]                                # ... whose fragment reads and lgkmcnt waits are hand-written too (mid-tile barrier)

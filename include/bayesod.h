@@ -33,7 +33,7 @@ typedef enum {
 enum { BOD_RANK_SCORE = 0, BOD_RANK_JOINT_ENTROPY = 1 };
 enum { BOD_NMS_VARIANT_A = 0, BOD_NMS_VARIANT_B = 1 };      /* SURVEY.md App. A.8 */
 enum { BOD_HEAD_CLS = 0, BOD_HEAD_REG = 1, BOD_HEAD_COV = 2 };
-enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1, BOD_PRECISION_BF16X3 = 2, BOD_PRECISION_F16MX = 3 };
+enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1, BOD_PRECISION_BF16X3 = 2, BOD_PRECISION_F16MX = 3, BOD_PRECISION_F16MX4 = 4 };
 
 /* Mirrors model_config / testing_config of src/retina_net/configs/retinanet_bdd_covar.yaml
  * (:61-143) plus the geometry the reference derives at run time. */
@@ -69,7 +69,10 @@ typedef struct {
                                     BOD_PRECISION_F16MX (the parity mode with the head towers -- 80 % of its time --
                                     on one f16 product + half a block-scaled e2m3 product per multiplication instead of
                                     three bf16 products: x = f16 hi + lo, hi*hi exact, the two cross terms on the MX
-                                    pipe; everything else as in BF16X3; still within 1e-3 END TO END)            */
+                                    pipe; everything else as in BF16X3; still within 1e-3 END TO END) or
+                                    BOD_PRECISION_F16MX4 (F16MX with the cross terms as block-scaled e2m1 (fp4) products of
+                                    twice the channels: three quarters of the tower bytes and K-tiles, ~4x F16MX's
+                                    rounding error -- still inside 1e-3 END TO END, with less margin)             */
     int32_t mc_sample_base;      /* index of this handle's first MC sample in the dropout RNG streams (default 0).
                                     A handle with mc_samples = n and base = r*n computes samples r*n .. r*n+n-1 of
                                     a larger ensemble bit-identically: the MC-sample-sharded multi-GPU mode
@@ -254,7 +257,7 @@ bod_status bod_synchronize(bod_handle h);
  * (multitask_headers.py:102-116): batch item b plays MC sample b, pixel index = y*OW+x.
  * out [B,OH,OW,Cout] fp32; round_output_bf16 != 0 rounds it like a stored activation.
  * precision = BOD_PRECISION_FP32 runs the fp32 twin of the kernel on unrounded fp32 operands.
- * precision = BOD_PRECISION_F16MX (3x3, stride 1, SAME, 256 -> 256 only: a head-tower layer) runs the f16mx tower kernel on the
+ * precision = BOD_PRECISION_F16MX / BOD_PRECISION_F16MX4 (3x3, stride 1, SAME, 256 -> 256 only: a head-tower layer) runs that tower kernel on the
  * row-reuse loop; round_output_bf16 then selects the data path under test: 0 = hx rows in, (hi, lo) pairs out (a head's last
  * layer); 1 = hx rows in, hx rows out (a middle layer; `out` is the decoded hx row: f16 hi + e2m3 lo); 2 = (hi, lo) pairs in,
  * hx rows out (the first layer).
@@ -375,8 +378,8 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
  * statistics are reduced inside the last tower layers' tiles (no [B,N,A,.] tensors on the bod_infer path), [1] = 1 when the 1x1
  * head output convs are fused into the last tower layers' epilogues, [2] = 1 when the per-sample tower layers run on the
  * activation-row-reuse kernel, [3] = 1 when the fan-out layer does, [4] = number of ops of the forward plan, [5] = number of
- * backbone / FPN 3x3 layers planned on the row-reuse kernel, [6] = 1 when the head towers run the f16mx arithmetic
- * (BOD_PRECISION_F16MX), [7] = 0. */
+ * backbone / FPN 3x3 layers planned on the row-reuse kernel, [6] = 1 / 2 when the head towers run the f16mx / f16mx4 arithmetic
+ * (BOD_PRECISION_F16MX / BOD_PRECISION_F16MX4), [7] = 0. */
 bod_status bod_plan_info(bod_handle h, int32_t* info8);
 
 #ifdef __cplusplus

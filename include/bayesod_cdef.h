@@ -12,7 +12,7 @@ typedef enum {
 enum { BOD_RANK_SCORE = 0, BOD_RANK_JOINT_ENTROPY = 1 };
 enum { BOD_NMS_VARIANT_A = 0, BOD_NMS_VARIANT_B = 1 };
 enum { BOD_HEAD_CLS = 0, BOD_HEAD_REG = 1, BOD_HEAD_COV = 2 };
-enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1, BOD_PRECISION_BF16X3 = 2, BOD_PRECISION_F16MX = 3 };
+enum { BOD_PRECISION_BF16 = 0, BOD_PRECISION_FP32 = 1, BOD_PRECISION_BF16X3 = 2, BOD_PRECISION_F16MX = 3, BOD_PRECISION_F16MX4 = 4 };
 typedef struct {
     int32_t device;
     int32_t image_h, image_w;

@@ -38,11 +38,11 @@ def test_baseline_config_frame_against_the_cpu_pipeline(hw, n):
     anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
     frame = synthetic.make_frames(1, hw[0], hw[1], seed=77)
     got = {}
-    for precision in ("f16mx", "bf16x3", "bf16"):
+    for precision in ("f16mx4", "f16mx", "bf16x3", "bf16"):
         eng = Engine(make_config(hw, batch=1, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True, precision=precision))
         eng.load_weights(weights)
         eng.set_anchors(anchors)
-        assert eng.plan_info()["tower_mx"] == (precision == "f16mx")
+        assert eng.plan_info()["tower_mx"] == (precision in ("f16mx", "f16mx4"))
         eng.upload_images(frame)
         eng.infer(None, seed=seed, first_image_id=first)
         dets = eng.get_detections(0)
@@ -60,7 +60,8 @@ def test_baseline_config_frame_against_the_cpu_pipeline(hw, n):
     assert len(idx) > 10
     cpu_dets = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, geometry.bbox_iou_vuvu(corners, corners), 0.5)
     keys = (("cls", "anchors_class_predictions"), ("box", "anchors_box_predictions"), ("cov", "_covar_params"))
-    for precision in ("f16mx", "bf16x3"):
+    for precision in ("f16mx4", "f16mx", "bf16x3"):
+        loose = precision == "f16mx4"          # e2m1 cross terms: ~4x f16mx's rounding error, still inside 1e-3
         worst, strict = 0.0, 0.0
         for k, rk in keys:
             a, t = got[precision][k].astype(np.float64), np.asarray(ref[rk], np.float64)
@@ -68,12 +69,12 @@ def test_baseline_config_frame_against_the_cpu_pipeline(hw, n):
             rms = _rms(t)
             d = np.abs(a - t)
             worst = max(worst, float((d / (np.abs(t) + rms)).max()))
-            assert _rms(a - t) / rms < 2e-4, (precision, k)
+            assert _rms(a - t) / rms < (4e-4 if loose else 2e-4), (precision, k)
             # SURVEY 8d's strict form: relative to the element itself, abs floor 1e-5 -- unbounded at the zero crossings of a signed
             # output, so it is asserted where |ref| is at least 1 % of the tensor's RMS and reported everywhere
             strict = max(strict, float((d / np.maximum(np.abs(t), 1e-5)).max()))
             big = np.abs(t) >= 1e-2 * rms
-            assert float((d[big] / np.abs(t[big])).max()) < 2e-2, (precision, k)
+            assert float((d[big] / np.abs(t[big])).max()) < (6e-2 if loose else 2e-2), (precision, k)
         assert worst < 1e-3, (precision, worst)
         par = bench.detection_parity(got[precision]["dets"], cpu_dets, arrays=True)
         dmu, dsig, dsc = par.pop("_dmu_px"), par.pop("_rel_dsigma"), par.pop("_dscore")
@@ -85,8 +86,8 @@ def test_baseline_config_frame_against_the_cpu_pipeline(hw, n):
         # (boxes: pixels against boxes tens of pixels wide; covariance entries against |entry| + 1 % of the matrix's largest: the epistemic
         # part is a sample variance of N nearly equal boxes)
         bad = (dmu > 2e-2) | (dsig > 3e-3) | (dsc > 1e-3)
-        assert bad.sum() <= 1, (int(bad.sum()), par)
-        assert np.median(dmu) < 1e-3 and np.median(dsig) < 1e-3, par
+        assert bad.sum() <= (3 if loose else 1), (int(bad.sum()), par)
+        assert np.median(dmu) < (3e-3 if loose else 1e-3) and np.median(dsig) < 1e-3, par
     for k, rk in keys:                                        # the throughput mode: storage noise, not a wiring error
         assert _rms(got["bf16"][k] - ref[rk]) / _rms(ref[rk]) < 2e-2, k
     par16 = bench.detection_parity(got["bf16"]["dets"], cpu_dets)

@@ -248,29 +248,38 @@ def _tower_case(rng, b, h, w):
     return x, wt, bias
 
 
+# per-layer bounds of the two tower formats, max |d| / (|ref| + rms): [mode 0, modes 1 / 2] (CPU model of the arithmetic, tests/tools/
+# tower_numerics.py: e2m3 cross terms 1.3e-5 rms / 7e-5 max of the output RMS, e2m1 5.7e-5 / 2.9e-4)
+MX_TOL = {"f16mx": (1e-4, 2e-4), "f16mx4": (4.5e-4, 5e-4)}
+
+
+@pytest.mark.parametrize("precision", ["f16mx", "f16mx4"])
 @pytest.mark.parametrize("mode,b,h,w", [(0, 2, 16, 16), (0, 1, 21, 37), (1, 2, 16, 16), (1, 3, 9, 13), (2, 2, 16, 16), (2, 1, 30, 7)])
-def test_f16mx_tower_layer_matches_oracle(mode, b, h, w):
+def test_f16mx_tower_layer_matches_oracle(mode, b, h, w, precision):
     """f16mx precision, one head-tower layer (multitask_headers.py:98-123: 3x3, 256 -> 256) on the f16mx kernel of the row-reuse loop
     against float64 on the UNROUNDED fp32 operands: x = f16 hi + lo, hi*hi on v_mfma_f32_32x32x16_f16 (exact products), the cross
     terms hi*lo + lo*hi as ONE block-scaled e2m3 product (v_mfma_scale_f32_32x32x64_f8f6f4; conv_igemm.hip header).  Per-layer
     error 1.3e-5 rms / 7e-5 max of the output RMS on the CPU model of the arithmetic (tests/tools/tower_numerics.py): 1e-4 here,
     the bf16x3 kernel's own gate.  mode 0: hx rows in, (hi, lo) pairs out (a head's last layer: exact to 2^-17); 1: hx in, hx out
     (the decoded hx row carries f16 hi + e2m3 lo: 2^-14); 2: pairs in -- the bf16x3 loop -- hx out (the first layer).  Ragged
-    sizes: tiles with invalid slots, runs of x-adjacent pixels shorter than a tile."""
+    sizes: tiles with invalid slots, runs of x-adjacent pixels shorter than a tile.
+    precision 'f16mx4': the same layer with h4 rows -- the cross terms as block-scaled e2m1 products of twice the channels (54 K-tiles
+    instead of 72; scale bytes staged as their own LDS-DMA pieces, byte ks of a scale dword chosen by the MFMA's op_sel)."""
     from bayes_od_rc_amd.engine import stage_conv
     from oracle import network
     rng = np.random.default_rng(100 * mode + h + w)
     x, wt, bias = _tower_case(rng, b, h, w)
-    got = stage_conv(x, wt, bias, padding="same", relu=True, precision="f16mx", round_output_bf16=mode)
+    got = stage_conv(x, wt, bias, padding="same", relu=True, precision=precision, round_output_bf16=mode)
     ref = np.maximum(network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same"), 0)
     rms = float(np.sqrt((ref ** 2).mean()))
     err = rel_err(got, ref, floor=rms)
-    print("f16mx mode %d %dx%dx%d: max |d| / (|ref| + rms) = %.2e" % (mode, b, h, w, err))
+    print("%s mode %d %dx%dx%d: max |d| / (|ref| + rms) = %.2e" % (precision, mode, b, h, w, err))
     assert got.shape == ref.shape and np.all(got >= 0)
-    assert err < (1e-4 if mode == 0 else 2e-4)
+    assert err < MX_TOL[precision][0 if mode == 0 else 1]
 
 
-def test_f16mx_tower_layer_dropout_and_bf16x3_agreement():
+@pytest.mark.parametrize("precision", ["f16mx", "f16mx4"])
+def test_f16mx_tower_layer_dropout_and_bf16x3_agreement(precision):
     """The head-tower dropout in the hx epilogue (values are zeroed before the split: the Philox contract's decisions, exact
     zeros) and, on the same layer, agreement with the bf16x3 kernel (both within 1e-4 of float64, hence 2e-4 of each other)."""
     from bayes_od_rc_amd.engine import stage_conv
@@ -283,15 +292,16 @@ def test_f16mx_tower_layer_dropout_and_bf16x3_agreement():
     ref = np.maximum(conv, 0) * np.float64(np.float32(1.0 / 0.7)) * keep
     rms = float(np.sqrt((ref ** 2).mean()))
     for mode in (0, 1, 2):
-        got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=0.3, seed=11, layer_id=6, image_id=5, precision="f16mx", round_output_bf16=mode)
+        got = stage_conv(x, wt, bias, padding="same", relu=True, dropout_rate=0.3, seed=11, layer_id=6, image_id=5, precision=precision, round_output_bf16=mode)
         assert np.all(got[~keep] == 0), mode
-        assert rel_err(got, ref, floor=rms) < (1e-4 if mode == 0 else 2e-4), mode
-    a = stage_conv(x, wt, bias, padding="same", relu=True, precision="f16mx", round_output_bf16=0)
+        assert rel_err(got, ref, floor=rms) < MX_TOL[precision][0 if mode == 0 else 1], mode
+    a = stage_conv(x, wt, bias, padding="same", relu=True, precision=precision, round_output_bf16=0)
     c = stage_conv(x, wt, bias, padding="same", relu=True, precision="bf16x3", round_output_bf16=True)
-    assert rel_err(a, c, floor=float(np.sqrt((c.astype(np.float64) ** 2).mean()))) < 2e-4
+    assert rel_err(a, c, floor=float(np.sqrt((c.astype(np.float64) ** 2).mean()))) < 2 * MX_TOL[precision][0]
 
 
-def test_f16mx_extreme_magnitudes():
+@pytest.mark.parametrize("precision", ["f16mx", "f16mx4"])
+def test_f16mx_extreme_magnitudes(precision):
     """Blocks of tiny values (f16-subnormal range: the lo part carries them), of large ones, all-zero blocks and mixed signs in the
     weights: the block scale follows the block's maximum, nothing saturates, zeros stay zeros."""
     from bayes_od_rc_amd.engine import stage_conv
@@ -306,8 +316,8 @@ def test_f16mx_extreme_magnitudes():
     ref = network.conv2d(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, "same")
     rms = float(np.sqrt((ref ** 2).mean()))
     for mode in (0, 1):
-        got = stage_conv(x, wt, bias, padding="same", precision="f16mx", round_output_bf16=mode)
-        assert rel_err(got, ref, floor=rms) < 2e-4, mode
+        got = stage_conv(x, wt, bias, padding="same", precision=precision, round_output_bf16=mode)
+        assert rel_err(got, ref, floor=rms) < (2e-4 if precision == "f16mx" else 6e-4), mode
 
 
 @pytest.mark.parametrize("ch", [64, 128])

@@ -150,12 +150,12 @@ def test_geometry_mismatch_is_rejected():
         Engine(make_config((100, 100), batch=1, mc_samples=2))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx", "f16mx4"])
 @pytest.mark.parametrize("hw,batch,n,depth", [((128, 128), 2, 3, 50), ((96, 160), 1, 1, 50), ((96, 96), 1, 2, 101)])
 def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
     """precision='fp32' (fp32 storage + exact-fp32 MFMA), precision='bf16x3' ((hi, lo) bf16 pairs, three products on the
     bf16 MFMA: the parity mode of the throughput path) and precision='f16mx' (round 5: bf16x3 with the head towers on one f16 +
-    half a block-scaled e2m3 product per multiplication): the whole forward pass -- stem, 53 backbone
+    half a block-scaled e2m3 product per multiplication; 'f16mx4': the cross terms as e2m1 products, ~4x the rounding error): the whole forward pass -- stem, 53 backbone
     convs, FPN, MC-dropout heads -- agrees with the float64 oracle element-wise within the 1e-3 bar of
     BASELINE.json's north_star (observed ~1e-5, fp32 summation noise through ~50 layers)."""
     from bayes_od_rc_amd import synthetic
@@ -165,7 +165,7 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
     frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
     eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision=precision, backbone_depth=depth))
     eng.load_weights(w)
-    assert eng.plan_info()["tower_mx"] == (precision == "f16mx")      # (the f16mx towers run at every size: the kernel IS the arithmetic)
+    assert eng.plan_info()["tower_mx"] == (precision in ("f16mx", "f16mx4"))      # (the f16mx towers run at every size: the kernel IS the arithmetic)
     eng.forward(frames, seed=seed, first_image_id=first)
     cls, box, cov = eng.get_raw()
     pyr = [eng.get_pyramid(l) for l in range(5)]
@@ -180,11 +180,11 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
             err = float(np.max(np.abs(got - t) / (np.abs(t) + rms)))
             worst = max(worst, err)
             assert err < 1e-3, (name, err)
-            assert _rms(got - t) / rms < 1e-4, (name, _rms(got - t) / rms)
+            assert _rms(got - t) / rms < (3e-4 if precision == "f16mx4" else 1e-4), (name, _rms(got - t) / rms)
     print("end-to-end forward, precision %s, %dx%d depth %d: max rel err %.2e" % (precision, hw[0], hw[1], depth, worst))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx", "f16mx4"])
 @pytest.mark.parametrize("hw", [(192, 624), (360, 640)])
 def test_non_square_and_odd_pyramids(hw, precision):
     """Half-scale versions of BASELINE config 4 (KITTI 384x1248 -> 192x624: odd level widths 78/39/20/10/5)

@@ -526,7 +526,7 @@ def test_engine_loads_a_converted_checkpoint_without_the_unbuilt_reg_layer():
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("parts,batch,precision", [(2, 1, "bf16"), (3, 2, "bf16"), (6, 1, "bf16"), (3, 2, "f16mx")])
+@pytest.mark.parametrize("parts,batch,precision", [(2, 1, "bf16"), (3, 2, "bf16"), (6, 1, "bf16"), (3, 2, "f16mx"), (3, 1, "f16mx4")])
 def test_sample_sharded_ensemble_is_bit_identical(parts, batch, precision):
     """SURVEY 8e second mode on one GPU: `parts` handles, each computing n = N/parts MC samples with
     mc_sample_base = r*n, reproduce the N-sample handle's raw head outputs bit for bit (the RNG is keyed by the
@@ -743,7 +743,7 @@ def test_sample_sharded_two_ranks_on_one_gpu():
     assert "SAMPLE_SHARD_OK" in out.stdout
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f16mx"])
+@pytest.mark.parametrize("precision", ["bf16", "f16mx", "f16mx4"])
 def test_model_without_covariance_head(precision):
     """output_names = ['classification', 'regression'] (retinanet_model.py:50-66: no CovHeader): two towers on the device,
     aleatoric term absent, likelihood covariance = epistemic / 11 (inference_utils.py:62-87 with the covar branch off)."""
@@ -761,7 +761,7 @@ def test_model_without_covariance_head(precision):
     pipe = BayesOdPipeline(model, hw, 1, BAYES_CFG, NMS_CFG, use_full_covar=True, anchors=anchors)
     frames = synthetic.make_frames(1, hw[0], hw[1], seed=4)
     dets = pipe(frames, seed=21, first_image_id=5)
-    assert pipe.engine.plan_info()["tower_mx"] == (precision == "f16mx")
+    assert pipe.engine.plan_info()["tower_mx"] == (precision in ("f16mx", "f16mx4"))
     eng = pipe.engine
     cls, box, cov = eng.get_raw()
     assert cov is None or cov.size == 0 or not np.any(cov)
@@ -775,7 +775,7 @@ def test_model_without_covariance_head(precision):
 
 
 @pytest.mark.parametrize("hw,n,batch,precision", [((512, 512), 10, 16, "bf16"), ((384, 1248), 30, 4, "bf16"), ((720, 1280), 10, 4, "bf16"), ((512, 1696), 10, 4, "bf16"),
-                                                  ((384, 1248), 30, 4, "f16mx")])
+                                                  ((384, 1248), 30, 4, "f16mx"), ((384, 1248), 30, 2, "f16mx4")])
 def test_full_size_properties(hw, n, batch, precision):
     """BASELINE.json's metric configuration (512x512, N=10; 16 frames per step here: the row-reuse tower kernel, fused
     1x1 outputs and the 256x256 fan-out tile are all in play) and its KITTI configuration (384x1248, N=30), where the

@@ -176,6 +176,30 @@ def c_f16_fp6_paired(x, w):
     return conv(xh, wh) + conv(xh6, wl6) + conv(xl6, wh6)
 
 
+def make_fp4_paired(lo_shift, blk=16):
+    """The fp4 form (conv_igemm.hip, f16mx4): an MX block = `blk` channels x {hi, lo * 2^lo_shift} in e2m1 under ONE shared scale
+    2^(floor(log2(max|hi| * 4/3)) - 2) (the largest hi lands in [3, 6]; lo' beyond 6 saturates); activations [hi4, lo4'] against
+    weights [lo4', hi4]."""
+    f = 2.0 ** lo_shift
+
+    def q(hi, lo, axis):
+        hi = np.moveaxis(hi, axis, -1); lo = np.moveaxis(lo, axis, -1)
+        sh = hi.shape
+        hb = hi.reshape(sh[:-1] + (sh[-1] // blk, blk)); lb = lo.reshape(hb.shape)
+        mx = np.abs(hb).max(-1, keepdims=True)
+        sc = 2.0 ** (np.floor(np.log2(np.maximum(mx * (4.0 / 3.0), 2.0 ** -120))) - 2)
+        qh = minifloat(hb / sc, 2, 1, 1, 6.0) * sc; ql = minifloat(lb / sc, 2, 1, 1, 6.0) * sc
+        return np.moveaxis(qh.reshape(sh), -1, axis), np.moveaxis(ql.reshape(sh), -1, axis) / f
+
+    def layer(x, w):
+        xh = f16(x).astype(np.float64); wh = f16(w).astype(np.float64)
+        xl = (x.astype(np.float64) - xh) * f; wl = (w.astype(np.float64) - wh) * f
+        xh4, xl4 = q(xh, xl, 0)
+        wh4, wl4 = q(wh, wl, 1)
+        return conv(xh, wh) + conv(xh4, wl4) + conv(xl4, wh4)
+    return layer
+
+
 def make_wino(rnd, pairs):
     def split(U, V):
         if not pairs:
@@ -195,6 +219,9 @@ CANDIDATES = [
     ("f16 hi*hi + MX-fp6 (e2m3) cross, block scales", 1.5, make_cross("fp6", False), None),
     ("f16 hi*hi + MX-fp4 (e2m1) cross, block scales", 1.5, make_cross("fp4", False), None),
     ("f16 hi*hi + MX-fp6 cross, {hi, lo*2^11} x 16 ch blocks [built]", 1.5, c_f16_fp6_paired, None),
+    ("f16 hi*hi + MX-fp4 cross, {hi, lo*2^11} x 16 ch blocks", 1.5, make_fp4_paired(11), None),
+    ("f16 hi*hi + MX-fp4 cross, {hi, lo*2^12} x 16 ch blocks", 1.5, make_fp4_paired(12), None),
+    ("f16 hi*hi + MX-fp4 cross, {hi, lo*2^13} x 16 ch blocks", 1.5, make_fp4_paired(13), None),
     ("Winograd F(2x2,3x3), bf16 operands", 16 / 36, make_wino(bf16, False), bf16),
     ("Winograd F(2x2,3x3), f16 operands", 16 / 36, make_wino(f16, False), f16),
     ("Winograd F(2x2,3x3), (hi,lo) bf16 operands", 3 * 16 / 36, make_wino(bf16, True), None),
