@@ -2160,22 +2160,34 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
     BODCHK(run_posterior(h, seed, first_image_id));           // waits for the side stream's previous readers
     HIPCHK(h, hipEventRecord(h->ev_posterior, h->stream));
     h->select_slot(sidx);
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
-    BODCHK(run_nms(h, h->side));
-    BODCHK(run_cluster(h, h->side));
+    // Round 5: soft-NMS + cluster-and-fuse (and the copies of the records) run on the MAIN stream, behind the posterior, not on the side
+    // stream beside the next call's stem.  With them on the side stream a call's detections were not reproducible: one detection in ~60
+    // frames with its fused mean moved by up to 0.4 px (same counts and scores: one cluster member more or less) -- in 3-14 of 12 runs of
+    // tests/tools/overlap_race.py on overlap handles (64 frames, two calls in flight), and in 5 of 12 fresh processes whose FIRST work is a
+    // pipelined pair on a serial handle (tests/tools/pipelined_vs_sync.py, 128 x 128 x 128 frames); with them on the main stream: 0 of 12
+    // and 0 of 12.  The mechanism is not found (every buffer the two streams share is ordered by events; tests/tools/side_race.py: the
+    // posterior re-run on unchanged inputs differs while ANOTHER handle keeps the GPU busy, never alone; no LDS overrun:
+    // tests/tools/lds_canary.py) -- so the contract ("pipelined == synchronous, bit for bit") is kept by not overlapping them.  Cost:
+    // the side work no longer hides under the next stem, where it collided for 2.4 ms per 512-frame step anyway (History A.1):
+    // measured below.  BOD_SIDE_STREAM=1: the side stream again (A/B).
+    static const bool side_on = [] { const char* e = getenv("BOD_SIDE_STREAM"); return e && atoi(e) != 0; }();
+    hipStream_t sd = side_on ? h->side : h->stream;
+    if (side_on) HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_posterior, 0));
+    BODCHK(run_nms(h, sd));
+    BODCHK(run_cluster(h, sd));
     // The records follow the kernels on the side stream into pinned host memory, so bod_collect only waits for
     // this slot's event: it must never queue work behind the NEXT batch's side-stream kernels (that would
     // stall the host until the next batch has finished and drain the pipeline).
     {
         const size_t B = (size_t)h->cfg.batch, BK = B * h->cfg.nms_max_output_size, C = h->cfg.num_classes;
         char* hs = h->host_stage[sidx];
-        HIPCHK(h, hipMemcpyAsync(hs, h->nms_nsel_s[sidx], B * 4, hipMemcpyDeviceToHost, h->side)); hs += B * 4;
-        HIPCHK(h, hipMemcpyAsync(hs, h->out_scores_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, h->side)); hs += BK * C * 4;
-        HIPCHK(h, hipMemcpyAsync(hs, h->out_means_s[sidx], BK * 16, hipMemcpyDeviceToHost, h->side)); hs += BK * 16;
-        HIPCHK(h, hipMemcpyAsync(hs, h->out_covs_s[sidx], BK * 64, hipMemcpyDeviceToHost, h->side)); hs += BK * 64;
-        HIPCHK(h, hipMemcpyAsync(hs, h->out_counts_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, h->side));
+        HIPCHK(h, hipMemcpyAsync(hs, h->nms_nsel_s[sidx], B * 4, hipMemcpyDeviceToHost, sd)); hs += B * 4;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_scores_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, sd)); hs += BK * C * 4;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_means_s[sidx], BK * 16, hipMemcpyDeviceToHost, sd)); hs += BK * 16;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_covs_s[sidx], BK * 64, hipMemcpyDeviceToHost, sd)); hs += BK * 64;
+        HIPCHK(h, hipMemcpyAsync(hs, h->out_counts_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, sd));
     }
-    HIPCHK(h, hipEventRecord(h->ev_done[sidx], h->side));
+    HIPCHK(h, hipEventRecord(h->ev_done[sidx], sd));
     h->side_pending[sidx] = true;
     *slot_out = sidx;
     return BOD_OK;
@@ -2697,6 +2709,8 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     // rec_send / rec_recv are shared by the ticket gathers (side stream) and the synchronous form (main stream): a gather that goes to
     // the other stream than the previous one waits for it -- nothing else orders the two streams against each other (round-4 advisor finding)
     if (h->ev_gather && h->gather_stream && h->gather_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_gather, 0));
+    // a ticket's records are finished on the main stream since round 5 (bod_infer_async): the side stream waits for the slot's event
+    if (slot >= 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_done[slot], 0));
     HIPCHK(h, launch_pack_records(h->nms_nsel_s[sidx], h->out_scores_s[sidx], h->out_means_s[sidx], h->out_covs_s[sidx],
                                   h->out_counts_s[sidx], h->rec_send, B, K, C, st));
     float* recv = nullptr;

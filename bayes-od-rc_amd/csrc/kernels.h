@@ -54,7 +54,7 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     int32_t ch_dual;
     // f16mx precision (ConvArgs.mx != 0): 1 = this group's output rows leave in the tower format "hx" (conv_igemm.hip: per 64 channels
     // 64 f16 hi + 128 bytes of e5m2 copies of hi and of lo * 2^12) for the next tower layer; 0 = (hi, lo) bf16 pairs (what the fused
-    // 1x1 + aggregation and every other consumer read)
+    // 1x1 + aggregation and every other consumer read); 2 = "h4" rows (f16mx4)
     int32_t out_hx;
 };
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
@@ -117,7 +117,9 @@ struct ConvArgs {
     int32_t stagger_ticks;
     // f16mx precision, head towers on the row-reuse loop (with `split`: same slot counts, same 1 KiB pixel rows): 1 = activations and
     // weights in the hx format, one f16 product + one block-scaled e5m2 product (the two cross terms) per multiplication; 2 = (hi, lo)
-    // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer).  0 = off.
+    // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer); 3 = activations and weights in the h4 format
+    // (f16mx4: the cross terms as e2m1 products of twice the channels; the weight buffer carries a compact copy of its scale bytes behind
+    // the 256 rows).  0 = off.
     int32_t mx;
     int32_t mx_loader;     // f16mx loop: which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four)
 };

@@ -47,7 +47,7 @@ class RetinaNetModel(object):
         self.device = device
         self.batch = batch
         self.seed = seed
-        self.precision = precision        # 'bf16' (throughput), 'f16mx' / 'bf16x3' (the 1e-3 end-to-end parity modes: f16 + MX-fp6 towers / (hi, lo) bf16 pairs) or 'fp32' (exact fp32)
+        self.precision = precision        # 'bf16' (throughput), 'f16mx' / 'bf16x3' (the 1e-3 end-to-end parity modes: f16 + MX-fp6 towers / (hi, lo) bf16 pairs), 'f16mx4' (f16mx with fp4 cross terms: faster, covariances at 2.5e-3) or 'fp32' (exact fp32)
         self.backbone_depth = 101 if '101' in str(model_config.get('feature_extractor', {}).get('name', '')) else 50
         self.image_counter = 0
         self.prediction_dict = None

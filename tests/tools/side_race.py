@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Which stage of posterior -> soft-NMS -> cluster-and-fuse is not reproducible while another handle keeps the GPU busy?  (development check)"""
+import os, sys, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from conftest import ANCHOR_CFG
+from bayes_od_rc_amd import synthetic
+from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+from bayes_od_rc_amd.engine import Engine, make_config
+
+BAYES_CFG = {"ranking_method": "score", "dirichlet_prior": {"type": "non_informative"}, "gaussian_prior": {"type": "isotropic", "isotropic_variance": 100000.0}}
+NMS_CFG = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
+hw, n, batch = (512, 512), 2, 64
+weights = synthetic.make_weights(cls_fg_bias=-1.0)
+anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+frames = synthetic.make_frames(batch, hw[0], hw[1], seed=12)
+mk = lambda: Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+e = mk(); e.load_weights(weights); e.set_anchors(anchors); e.upload_images(frames)
+b = mk(); b.load_weights(weights); b.set_anchors(anchors); b.upload_images(frames)
+e.infer(None, seed=3, first_image_id=0)
+ref = {k: v.copy() for k, v in e.get_detections_batch().items()}
+ref_post = [e.get_posterior(i) for i in range(batch)]
+ref_nms = [e.get_nms(i) for i in range(batch)]
+stop = False
+def noise():
+    while not stop:
+        b.forward(None, seed=1, first_image_id=0)
+NOISE = os.environ.get("NOISE", "1") != "0"
+t = threading.Thread(target=noise if NOISE else (lambda: None)); t.start()
+def cmp_dets(tag):
+    d = e.get_detections_batch()
+    bad = 0
+    for img in range(batch):
+        k = ref["num"][img]
+        for key in ("scores", "means", "covs", "counts"):
+            if d["num"][img] != k or not np.array_equal(d[key][img, :k], ref[key][img, :k]):
+                bad += 1
+                print("%s: img %d %s differs (max |d| %.3g)" % (tag, img, key, float(np.abs(d[key][img, :k] - ref[key][img, :k]).max())), flush=True)
+    return bad
+try:
+    tot = {"cluster": 0, "nms+cluster": 0, "posterior+nms+cluster": 0, "posterior_arrays": 0, "nms_lists": 0}
+    for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
+        e.cluster_fuse(); tot["cluster"] += cmp_dets("iter %d cluster only" % it)
+        e.nms(); e.cluster_fuse(); tot["nms+cluster"] += cmp_dets("iter %d nms+cluster" % it)
+        for i in range(batch):
+            a, r = e.get_nms(i), ref_nms[i]
+            if not all(np.array_equal(x, y) for x, y in zip(a, r)): tot["nms_lists"] += 1
+        e.posterior(seed=3, first_image_id=0)
+        for i in range(0, batch, 1):
+            a, r = e.get_posterior(i), ref_post[i]
+            for k in r:
+                if not np.array_equal(a[k], r[k]): tot["posterior_arrays"] += 1; print("iter %d posterior img %d %s differs" % (it, i, k), flush=True)
+        e.nms(); e.cluster_fuse(); tot["posterior+nms+cluster"] += cmp_dets("iter %d posterior+nms+cluster" % it)
+    print("mismatches:", tot, flush=True)
+finally:
+    stop = True; t.join()
