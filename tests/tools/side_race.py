@@ -24,6 +24,13 @@ ref_post = [e.get_posterior(i) for i in range(batch)]
 ref_nms = [e.get_nms(i) for i in range(batch)]
 stop = False
 def noise():
+    kind = os.environ.get("NOISE_KIND", "forward")
+    if kind == "torch":                       # someone else's kernels: rocBLAS GEMMs + elementwise kernels on torch's own stream
+        import torch
+        x = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); y = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        while not stop:
+            z = (x @ y).relu_().float().sum(); torch.cuda.synchronize()
+        return
     while not stop:
         b.forward(None, seed=1, first_image_id=0)
 NOISE = os.environ.get("NOISE", "1") != "0"
@@ -50,7 +57,16 @@ try:
         for i in range(0, batch, 1):
             a, r = e.get_posterior(i), ref_post[i]
             for k in r:
-                if not np.array_equal(a[k], r[k]): tot["posterior_arrays"] += 1; print("iter %d posterior img %d %s differs" % (it, i, k), flush=True)
+                if not np.array_equal(a[k], r[k]):
+                    tot["posterior_arrays"] += 1
+                    if tot["posterior_arrays"] <= 12:
+                        d = np.argwhere(np.asarray(a[k]) != np.asarray(r[k]))
+                        rows = sorted(set(int(x[0]) for x in d))
+                        print("iter %d posterior img %d %s differs in %d slots %s of %d; anchor_index equal %s; first slot got %s ref %s" % (
+                            it, i, k, len(rows), rows[:6], len(r[k]), np.array_equal(a["anchor_index"], r["anchor_index"]),
+                            np.asarray(a[k])[rows[0]].ravel()[:4], np.asarray(r[k])[rows[0]].ravel()[:4]), flush=True)
+        a0 = e.get_posterior(0)          # (read again, no kernel in between)
+        if any(not np.array_equal(a0[k], e.get_posterior(0)[k]) for k in a0): print("iter %d: two READS of the same posterior differ" % it, flush=True)
         e.nms(); e.cluster_fuse(); tot["posterior+nms+cluster"] += cmp_dets("iter %d posterior+nms+cluster" % it)
     print("mismatches:", tot, flush=True)
 finally:
