@@ -65,6 +65,11 @@ try:
                         print("iter %d posterior img %d %s differs in %d slots %s of %d; anchor_index equal %s; first slot got %s ref %s" % (
                             it, i, k, len(rows), rows[:6], len(r[k]), np.array_equal(a["anchor_index"], r["anchor_index"]),
                             np.asarray(a[k])[rows[0]].ravel()[:4], np.asarray(r[k])[rows[0]].ravel()[:4]), flush=True)
+                        if k == "means":          # are the wrong rows the RIGHT rows of other slots (of this image or any other)?
+                            for rr in rows[:16]:
+                                hit = [(j, int(np.nonzero((ref_post[j]["means"] == a[k][rr]).all(axis=1))[0][0])) for j in range(batch)
+                                       if (ref_post[j]["means"] == a[k][rr]).all(axis=1).any()]
+                                print("      slot %d: its wrong mean is the right mean of (image, slot) %s; anchor %d" % (rr, hit[:3], int(r["anchor_index"][rr])), flush=True)
         a0 = e.get_posterior(0)          # (read again, no kernel in between)
         if any(not np.array_equal(a0[k], e.get_posterior(0)[k]) for k in a0): print("iter %d: two READS of the same posterior differ" % it, flush=True)
         e.nms(); e.cluster_fuse(); tot["posterior+nms+cluster"] += cmp_dets("iter %d posterior+nms+cluster" % it)
