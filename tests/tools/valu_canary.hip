@@ -15,9 +15,18 @@ __global__ __launch_bounds__(256) void valu_canary_kernel(int iters, int mode, f
             const float s = sqrtf(x * x + 1.0f);
             y = 1.0f / (s + y * y);
             x = expf(-y) + 0.5f * x;
-        } else {                              // IEEE division (v_div_scale / v_div_fmas / v_div_fixup, denormal mode switches)
+        } else if (mode == 2) {               // IEEE division (v_div_scale / v_div_fmas / v_div_fixup, denormal mode switches)
             y = (x + 1.0f) / (y + 2.0f);
             x = (y + 3.0f) / (x + 1.5f);
+        } else if (mode == 3) {               // integer multiplies: v_mul_lo_u32 / v_mul_hi_u32 / v_mad_u64_u32 (address arithmetic)
+            unsigned a = __float_as_uint(x), b = __float_as_uint(y);
+            unsigned long long z = (unsigned long long)a * 2654435761ull + b;
+            a = (unsigned)(z >> 13) * 40503u + (unsigned)z; b = __umulhi(a, b | 1u) + (unsigned)(z >> 32);
+            x = __uint_as_float((a & 0x007FFFFFu) | 0x3F800000u); y = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+        } else {                              // fp64 fma chain
+            double dx = x, dy = y;
+            dx = __builtin_fma(dx, 0.99902343751, dy); dy = __builtin_fma(dy, 0.5, 0.25 * dx);
+            x = (float)dx; y = (float)dy;
         }
     }
     out[t] = x + y;
