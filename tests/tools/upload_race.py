@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""The asynchronous uint8 upload (copy + pre-processing kernel on the copy stream) while the SAME handle's forward keeps the main stream
+busy: are the pre-processed frames still bit-identical to an upload without company?  (development probe)"""
+import os, sys, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from bayes_od_rc_amd import synthetic
+from bayes_od_rc_amd.engine import Engine, make_config
+from bayes_od_rc_amd.distributed import DeviceArray
+hw, n, batch = (512, 512), 2, 64
+e = Engine(make_config(hw, batch=batch, mc_samples=n)); e.load_weights(synthetic.make_weights())
+rng = np.random.default_rng(0)
+u8 = [np.ascontiguousarray(rng.integers(0, 256, (batch, hw[0], hw[1], 3), dtype=np.uint8)) for _ in range(2)]
+pin = [torch.from_numpy(a).pin_memory() for a in u8]
+def dev_images(buf):
+    ptr = e.lib.bod_device_images_buffer(e.h, buf)
+    return torch.as_tensor(DeviceArray(ptr, (batch, hw[0], hw[1], 3), "<f4"), device="cuda").clone()
+ref = []
+for k in range(2):
+    e.upload_frames_u8_async(pin[k].numpy(), k); e.synchronize(); ref.append(dev_images(k))
+e.forward(None, image_buffer=0); e.synchronize()
+for company in (False, True):
+    bad = 0
+    for it in range(60):
+        k = it & 1
+        if company:
+            s = e.infer_async(None, image_buffer=k ^ 1) if False else None
+            e.forward(None, image_buffer=k ^ 1)              # enqueued on the main stream, returns at once
+        e.upload_frames_u8_async(pin[k].numpy(), k)           # copy stream, beside the forward
+        e.synchronize()
+        if not torch.equal(dev_images(k), ref[k]): bad += 1
+    print("upload beside the forward: %s -> %d of 60 uploads differ from the upload alone" % (company, bad), flush=True)
