@@ -12,7 +12,7 @@ from bayes_od_rc_amd.engine import Engine, make_config
 BAYES_CFG = {"ranking_method": "score", "dirichlet_prior": {"type": "non_informative"}, "gaussian_prior": {"type": "isotropic", "isotropic_variance": 100000.0}}
 NMS_CFG = {"max_output_size": 100, "iou_threshold": 0.5, "soft_nms_sigma": 0.5}
 hw, n, batch = (512, 512), 2, 64
-weights = synthetic.make_weights(cls_fg_bias=-1.0)
+weights = synthetic.make_weights(cls_fg_bias=float(os.environ.get("FG_BIAS", "-1.0")))
 anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
 frames = synthetic.make_frames(batch, hw[0], hw[1], seed=12)
 mk = lambda: Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
