@@ -184,6 +184,36 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
     print("end-to-end forward, precision %s, %dx%d depth %d: max rel err %.2e" % (precision, hw[0], hw[1], depth, worst))
 
 
+def test_f16mx4_with_the_box_tower_on_hx_rows(monkeypatch):
+    """BOD_MX4_BOX_HX=1: the box-regression tower keeps the e2m3 cross terms (hx rows) while the classification and covariance towers
+    run on h4 rows -- layer 0 reads ONE hx pyramid and writes each head's format, the two formats are separate launches from layer 1
+    on (engine.hip).  Same bound as the pure forms; the box outputs must then be as close as f16mx's."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, batch, n, seed, first = (128, 128), 2, 3, 99, 3
+    w = synthetic.make_weights()
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=3)
+    errs = {}
+    for mixed in (False, True):
+        if mixed:
+            monkeypatch.setenv("BOD_MX4_BOX_HX", "1")
+        eng = Engine(make_config(hw, batch=batch, mc_samples=n, precision="f16mx4"))
+        eng.load_weights(w)
+        assert eng.plan_info()["tower_mx_format"] == 2
+        eng.forward(frames, seed=seed, first_image_id=first)
+        cls, box, cov = eng.get_raw()
+        worst = {"cls": 0.0, "box": 0.0, "cov": 0.0}
+        for b in range(batch):
+            _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P)
+            for name, got, t in (("cls", cls[b], f64["anchors_class_predictions"]), ("box", box[b], f64["anchors_box_predictions"]), ("cov", cov[b], f64["_covar_params"])):
+                worst[name] = max(worst[name], float(np.max(np.abs(got - t) / (np.abs(t) + _rms(t)))))
+        errs[mixed] = worst
+        eng.close()
+    print("f16mx4, all towers on h4: %s; box tower on hx: %s" % (errs[False], errs[True]))
+    assert all(v < 1e-3 for v in errs[False].values()) and all(v < 1e-3 for v in errs[True].values())
+    assert errs[True]["box"] < 0.6 * errs[False]["box"]          # (e2m3 cross terms: ~4x less rounding error than e2m1)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx", "f16mx4"])
 @pytest.mark.parametrize("hw", [(192, 624), (360, 640)])
 def test_non_square_and_odd_pyramids(hw, precision):
