@@ -23,10 +23,22 @@ __global__ __launch_bounds__(256) void valu_canary_kernel(int iters, int mode, f
             unsigned long long z = (unsigned long long)a * 2654435761ull + b;
             a = (unsigned)(z >> 13) * 40503u + (unsigned)z; b = __umulhi(a, b | 1u) + (unsigned)(z >> 32);
             x = __uint_as_float((a & 0x007FFFFFu) | 0x3F800000u); y = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
-        } else {                              // fp64 fma chain
+        } else if (mode == 4) {               // fp64 fma chain
             double dx = x, dy = y;
             dx = __builtin_fma(dx, 0.99902343751, dy); dy = __builtin_fma(dy, 0.5, 0.25 * dx);
             x = (float)dx; y = (float)dy;
+        } else if (mode == 5) {               // packed fp32: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (what the 4x4 matrix code of the posterior compiles to)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p = {x, y}, q = {y, x};
+            p = p * (f2){0.9990234f, 0.5f} + q * (f2){0.25f, 0.125f};
+            q = q * p + (f2){0.001f, 0.002f};
+            p = p - q * (f2){0.5f, 0.25f};
+            x = p.x * 0.5f + 0.5f; y = q.y * 0.25f + p.y * 0.25f + 0.3f;
+            x = x - __builtin_floorf(x) + 0.5f; y = y - __builtin_floorf(y) + 0.5f;
+        } else {                              // 64-bit address arithmetic: v_lshl_add_u64 / v_mov_b64
+            unsigned long long pa = (unsigned long long)__float_as_uint(x), pb_ = (unsigned long long)__float_as_uint(y) << 7;
+            pa = (pa << 4) + pb_;  pb_ = (pb_ << 2) + pa;  pa = (pa << 3) + (pb_ >> 5);
+            x = __uint_as_float(((unsigned)(pa >> 9) & 0x007FFFFFu) | 0x3F800000u); y = __uint_as_float(((unsigned)(pb_ >> 17) & 0x007FFFFFu) | 0x3F800000u);
         }
     }
     out[t] = x + y;

@@ -20,7 +20,7 @@ def run(mode):
     rc = lib.valu_canary_run(BLOCKS, ITERS, mode, out.ctypes.data_as(C.POINTER(C.c_float)))
     assert rc == 0, rc
     return out
-NM = 5
+NM = 7
 refs = [run(m) for m in range(NM)]
 assert all(np.array_equal(run(m).view(np.uint32), refs[m].view(np.uint32)) for m in range(NM)), "not reproducible alone"
 stop = False
@@ -37,7 +37,7 @@ for name, fn in (("alone", None), ("this library's forward", company_forward)):
     t = threading.Thread(target=fn) if fn else None
     if t: t.start()
     try:
-        for mode, mname in enumerate(("fma chain", "sqrt / rcp / exp chain", "IEEE division chain", "integer multiply chain", "fp64 fma chain")):
+        for mode, mname in enumerate(("fma chain", "sqrt / rcp / exp chain", "IEEE division chain", "integer multiply chain", "fp64 fma chain", "packed fp32 chain", "64-bit shift-add chain")):
             bad_runs, rows = 0, []
             for r in range(RUNS):
                 out = run(mode)
