@@ -215,9 +215,10 @@ bod_status bod_device_raw(bod_handle h, void** ptrs3, int32_t mark_ready);
 bod_status bod_infer(bod_handle h, const float* images, int32_t images_on_device,
                      uint64_t seed, uint32_t first_image_id);
 
-/* Pipelined form for sustained throughput: enqueue the whole pass and return at once.  The
- * latency-bound soft-NMS + cluster-fuse of this batch run on a side stream underneath the next
- * batch's convolutions; detection records are double-buffered ("slots").  *slot receives the
+/* Pipelined form for sustained throughput: enqueue the whole pass and return at once, so that the host
+ * enqueues batch i+1 while batch i runs and its records travel to pinned memory.  (Until round 5 the
+ * soft-NMS + cluster-fuse of a batch ran on a side stream underneath the next batch's convolutions; they
+ * follow the posterior on the main stream now -- DESIGN.md 8.4.)  Detection records are double-buffered ("slots").  *slot receives the
  * ticket to pass to bod_collect, which waits for that batch and copies its padded records
  * (layout as bod_get_detections_batch).  At most two batches may be in flight. */
 bod_status bod_infer_async(bod_handle h, const float* images, int32_t images_on_device,
@@ -357,8 +358,8 @@ bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_con
  *
  * bod_gather_detections packs the records of `slot` (the ticket of bod_infer_async; pass -1 after a synchronous bod_infer) on the
  * device and issues ONE RCCL gather -- ncclGather(send, recv, batch*K*W, ncclFloat32, root, comm, stream).  For a ticket
- * (slot >= 0) both run on the handle's side stream, behind the slot's cluster-and-fuse kernels, so they overlap the next batch's
- * convolutions like bod_collect's copies do, and the slot's event is re-recorded behind them: bod_collect(slot) and the next
+ * (slot >= 0) both run on the handle's side stream, behind the slot's event (its cluster-and-fuse kernels and record copies), so the
+ * gather overlaps the next batch's convolutions, and the slot's event is re-recorded behind them: bod_collect(slot) and the next
  * bod_infer_async that reuses the slot wait for the send.  For slot == -1 both run on the handle's MAIN stream, behind the
  * synchronous bod_infer's own kernels: every later call on the handle (the next bod_infer, bod_synchronize, ...) is ordered behind
  * the pack and the gather by stream order.
