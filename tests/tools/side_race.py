@@ -15,9 +15,10 @@ hw, n, batch = (512, 512), 2, 64
 weights = synthetic.make_weights(cls_fg_bias=float(os.environ.get("FG_BIAS", "-1.0")))
 anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
 frames = synthetic.make_frames(batch, hw[0], hw[1], seed=12)
-mk = lambda: Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True))
+mk = lambda prec="bf16": Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True, precision=prec))
 e = mk(); e.load_weights(weights); e.set_anchors(anchors); e.upload_images(frames)
-b = mk(); b.load_weights(weights); b.set_anchors(anchors); b.upload_images(frames)
+b = mk(os.environ.get("NOISE_PRECISION", "bf16")); b.load_weights(weights); b.set_anchors(anchors)
+b.upload_images(frames if os.environ.get("NOISE_FRAMES", "same") == "same" else synthetic.make_frames(batch, hw[0], hw[1], seed=977)[:, ::-1].copy()); b.forward(None)
 e.infer(None, seed=3, first_image_id=0)
 ref = {k: v.copy() for k, v in e.get_detections_batch().items()}
 ref_post = [e.get_posterior(i) for i in range(batch)]
@@ -30,6 +31,9 @@ def noise():
         x = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); y = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
         while not stop:
             z = (x @ y).relu_().float().sum(); torch.cuda.synchronize()
+        return
+    if kind.startswith("tower"):              # one tower launch over and over (bench_head_conv: layer given after the colon)
+        while not stop: b.bench_head_conv(layer=int(kind.split(":")[1]), variant=0, iters=20)
         return
     while not stop:
         b.forward(None, seed=1, first_image_id=0)
