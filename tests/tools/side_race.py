@@ -32,6 +32,17 @@ def noise():
         while not stop:
             z = (x @ y).relu_().float().sum(); torch.cuda.synchronize()
         return
+    if kind.startswith("synthetic"):          # one instruction class at a time (noise_kernels.hip: mode after the colon)
+        import ctypes as C
+        here = os.path.dirname(os.path.abspath(__file__))
+        if not os.path.exists(os.path.join(here, "libnoise_kernels.so")):
+            import subprocess
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(here, "noise_kernels.hip"), "-o", os.path.join(here, "libnoise_kernels.so")])
+        lib = C.CDLL(os.path.join(here, "libnoise_kernels.so"))
+        mode = int(kind.split(":")[1])
+        while not stop:
+            assert lib.noise_run(mode, 8192, 2000 if mode != 3 else 400) == 0
+        return
     if kind.startswith("tower"):              # one tower launch over and over (bench_head_conv: layer given after the colon)
         while not stop: b.bench_head_conv(layer=int(kind.split(":")[1]), variant=0, iters=20)
         return
