@@ -2,6 +2,7 @@
 // class of this library's backbone kernels disturbs a posterior wave on the same SIMD.
 //   mode 0: v_cvt_pk_bf16_f32      mode 1: packed 16-bit integer ops (v_pk_max_i16 / v_pk_min_u16 / v_pk_mul_lo_u16 / v_pk_sub_u16)
 //   mode 2: v_mfma_f32_32x32x16_bf16     mode 3: LDS-DMA (global_load_lds_dwordx4) + ds_read_b128     mode 4: v_bitop3_b32 + v_perm_b32
+//   mode 5: the transcendental unit (v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32)
 // build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC tests/tools/noise_kernels.hip -o tests/tools/libnoise_kernels.so
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -40,6 +41,16 @@ __global__ __launch_bounds__(256) void noise_kernel(int mode, int iters, const f
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float4 r = *reinterpret_cast<const float4*>(lds + threadIdx.x * 16);
             x += r.x * 1e-9f;
+        } else if (mode == 5) {               // transcendental unit: v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float p, q, r, s_;
+                asm volatile("v_rcp_f32 %0, %1" : "=v"(p) : "v"(x));
+                asm volatile("v_rcp_iflag_f32 %0, %1" : "=v"(q) : "v"(y));
+                asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(p));
+                asm volatile("v_sqrt_f32 %0, %1" : "=v"(s_) : "v"(q));
+                x = x + r * 1e-7f + 1e-6f; y = y + s_ * 1e-7f + 1e-6f;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
