@@ -196,6 +196,16 @@ __device__ __forceinline__ void mfma16_inplace(f32x4& c, const bf16x8& a, const 
 // The block-scaled product of the f16mx X tiles, D = C tied in place like mfma16_inplace: the builtin form leaves the choice of the
 // destination to the register allocator, which moves the 32x32 accumulators through fresh tuples and spills them (844 bytes per
 // lane in the first build).  Sources come straight from LDS reads (no VALU write in front of the MFMA: kernel_guard checks).
+#if defined(BOD_MX_ABL_READS)
+typedef i32x4 mxop_t;          // timing ablation: fp4-format operands (same MFMA rate as fp6), ONE 16-byte read each
+#else
+typedef i32x6 mxop_t;
+#endif
+__device__ __forceinline__ void mfma_mx6_inplace(f32x16& c, const i32x4& a, const i32x4& b, const int sa, const int sb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#endif
+}
 __device__ __forceinline__ void mfma_mx6_inplace(f32x16& c, const i32x6& a, const i32x6& b, const int sa, const int sb) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
@@ -239,7 +249,7 @@ __device__ __forceinline__ void mfma_mx4_inplace(f32x16& c, const bf16x8& a, con
 template <int FP>
 struct HxCarry {                 // the first step's operands of a K-tile, requested during the K-tile before
     bf16x8 hA, hB[FP];
-    i32x6 xA, xB[FP];
+    mxop_t xA, xB[FP];
     int xsa, xsb[FP];
     int sa4[4];                  // f16mx4: the K-tile's A scales (dword i = the four k-steps' bytes of cout fragment i); B scales in xsb
 };
@@ -257,6 +267,17 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
     // the SIX-register operand the MFMA wants, `s_nop 1` in front of the MFMA for the copies' two wait states -- measured 3 % SLOWER on
     // the towers on two boxes (199 / 205 ms against 193.6 per 256 frames): the copies and their waits cost more than the conflicts.
     auto ld6 = [&](int base, int m, int& sc) {
+#if defined(BOD_MX_ABL_READS)
+        // timing ablation (wrong results): BOD_MX_ABL_READS=1 one 16-byte read per operand (fp4-format MFMA: the fp6 rate), =2 two 16-byte
+        // reads (the second one's registers only kept alive), constant scale -- what conflict-free X operand reads would cost
+        const i32x4 a = *reinterpret_cast<const i32x4*>(rd + (base ^ ((2 * m) << 5)));
+        sc = 0x7b7b7b7b;
+        if (BOD_MX_ABL_READS == 2) {
+            i32x4 b = *reinterpret_cast<const i32x4*>(rd + (base ^ ((2 * m + 1) << 5)));
+            asm volatile("" :: "v"(b));
+        }
+        return a;
+#else
         const char* p1 = rd + (base ^ ((2 * m + 1) << 5));
         const i32x4 a = *reinterpret_cast<const i32x4*>(rd + (base ^ ((2 * m) << 5)));
         const int2 b = *reinterpret_cast<const int2*>(p1);
@@ -264,6 +285,7 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
         i32x6 r;
         r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b.x; r[5] = b.y;
         return r;
+#endif
     };
     // X tiles: the A operand double-buffered (requested one step ahead; single-buffered measured 3 % slower on the towers)
     constexpr bool XA2 = true;
@@ -318,7 +340,7 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
         }
     } else {
         constexpr int NIT = 2 * FC;
-        i32x6 B6[FP], A6[2];
+        mxop_t B6[FP], A6[2];
         int sb[FP], sa[2];
 #pragma unroll
         for (int j = 0; j < FP; ++j) { B6[j] = c.xB[j]; sb[j] = c.xsb[j]; }
@@ -2969,11 +2991,21 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
             return hipErrorInvalidValue;
         for (int g = 0; g < a.groups; ++g)
             if (a.g[g].res || a.g[g].out_relu || a.g[g].ch_w2 || a.g[g].ch_w3 || (a.g[g].w2 && (a.g[g].out_hx || a.fan_count > 1))) return hipErrorInvalidValue;
+#ifndef BOD_DEV_MX_ONLY
         if (a.variant == 90 && a.mx == 1) return launch_mx<11>(a, s);          // phase clock (tests/tools/bench_head_conv.py)
         if (a.variant == 91 && a.mx == 1) return launch_mx<12>(a, s);          // ... without the loop's LDS-DMA
+#endif
+#ifdef BOD_DEV_MX_ONLY
+        return a.mx == 1 ? launch_mx<1>(a, s) : hipErrorInvalidValue;
+#else
         if (a.mx == 3) return a.variant == 0 ? launch_mx<3>(a, s) : hipErrorInvalidValue;          // f16mx4: h4 rows in
         return a.mx == 1 ? launch_mx<1>(a, s) : launch_mx<2>(a, s);
+#endif
     }
+#ifdef BOD_DEV_MX_ONLY
+    // developer build (hipcc -DBOD_DEV_MX_ONLY -c conv_igemm.hip): conv_igemm_mx_kernel<1> alone, for a fast compile / disassemble loop
+    return hipErrorInvalidValue;
+#else
     static const int forced = [] { const char* e = getenv("BOD_FORCE_CONV_TILE"); return e ? atoi(e) : 0; }();
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_pointwise_eligible(a)) return launch_conv_pointwise(a, s);   // streaming 1x1 kernel (bit-identical)
     if (!forced && !(a.flags & CONV_NT_OUT) && conv_slide3x3_eligible(a)) return launch_conv_slide3x3(a, s);     // sliding-window 3x3, 64 -> 64 (bit-identical)
@@ -3068,4 +3100,5 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (big) return launch_cfg<256, 256, 2, 4, 0>(a, s);
     if (a.cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2, 0>(a, s);
     return launch_cfg<64, 128, 1, 4, 0>(a, s);
+#endif
 }

@@ -17,7 +17,11 @@ The ONE JSON line carries, beside the headline (bf16, BASELINE config 3):
   parity_mode    the fastest precision mode that meets north_star's 1e-3 END TO END in this run -- f16mx4 / f16mx (round 5: head towers
                  on one f16 product + the two cross terms as one block-scaled e2m1 / e2m3 product) or bf16x3 (rounds 2-4) -- timed
                  in the same run, with its max relative error against the CPU port's fp32 forward of the same frame and Philox masks
-                 and the detection-level distance over every frame of the CPU leg; parity_mode_<name>: the other two beside it
+                 and the detection-level distance over every frame of the CPU leg; parity_mode_<name>: the other two beside it.
+                 Round 6: each carries its own `roofline` (its dominant kernel from the timed steps) and `meets_1e-3` = the gate as
+                 clauses with the max beside every p99 and every detection outside 1e-3 counted by CAUSE (a discrete flip of the
+                 filter / a cluster member / a draw / a centre, or arithmetic)
+  value_at_parity  images/sec of `parity_mode` when a measured mode met every clause (north_star's two clauses together), else null
   secondary      BASELINE configs 2 (N=1 forward), 4's geometry (384x1248, N=30, one GPU) and 5 (ResNet-101 training step)
   value_with_h2d the headline with the uint8 frames crossing PCIe every step (copy stream, overlapped with the convolutions)
 """
@@ -89,7 +93,7 @@ def _rel_errs(got, ref):
     return float(np.max(d / (np.abs(ref) + rms))), float(np.sqrt(((got - ref) ** 2).mean()) / rms), strict
 
 
-def detection_parity(dev, ref, arrays=False):
+def detection_parity(dev, ref, arrays=False, dev_ctx=None, cpu_ctx=None):
     """Final output of the path for one frame -- cluster-fused detections (scores [K,C], means [K,4] or [K,4,1], covs [K,4,4],
     counts [K,C]) -- device vs the CPU leg, both from the same frame, Philox dropout masks and categorical uniforms.
     Every CPU detection is paired with the device detection whose box overlaps it most (IoU > 0.5, each device detection used
@@ -138,9 +142,64 @@ def detection_parity(dev, ref, arrays=False):
                 "counts_equal": bool(np.array_equal(np.asarray(dev[3], np.float64)[di], np.asarray(ref[3], np.float64)[ri]))})
     if arrays:           # per matched detection: worst coordinate / entry / class (detection_statistics aggregates them over frames)
         out["_dmu_px"] = dmu.max(axis=1)
+        out["_rel_dmu"] = (dmu / (np.abs(rm[ri]) + 1.0)).max(axis=1)
         out["_rel_dsigma"] = rel_sig.reshape(len(ri), -1).max(axis=1)
+        # the same covariance distance norm-wise (no floor to choose): ||dSigma||_F / ||Sigma||_F
+        out["_fro_dsigma"] = (np.sqrt(((dc[di] - rc[ri]) ** 2).reshape(len(ri), -1).sum(axis=1)) /
+                              np.maximum(np.sqrt((rc[ri] ** 2).reshape(len(ri), -1).sum(axis=1)), 1e-30))
         out["_dscore"] = dsc.max(axis=1)
+        out["_cause"] = [explain_detection(int(i), int(j), dev_ctx, cpu_ctx) for i, j in zip(ri, di)]
+        out["_unmatched_cause"] = [explain_detection(int(i), None, dev_ctx, cpu_ctx) for i in range(len(rm)) if i not in set(ri.tolist())]
     return out
+
+
+def _vuhw_corners32(m):
+    m = np.asarray(m, np.float32).reshape(-1, 4)
+    return np.stack([m[:, 0] - m[:, 2] / 2, m[:, 1] - m[:, 3] / 2, m[:, 0] + m[:, 2] / 2, m[:, 1] + m[:, 3] / 2], 1)
+
+
+def _iou_column_a15(corners, c):
+    """bbox_iou_vuvu of every box against box c (box_utils.py:117-146: + 1 pixel in the intersection, the (min - max + 1) areas)."""
+    b = corners[c]
+    iv = np.maximum(np.minimum(corners[:, 2], b[2]) - np.maximum(corners[:, 0], b[0]) + 1, 0)
+    iu = np.maximum(np.minimum(corners[:, 3], b[3]) - np.maximum(corners[:, 1], b[1]) + 1, 0)
+    inter = iv * iu
+    area = lambda q: (q[..., 0] - q[..., 2] + 1) * (q[..., 1] - q[..., 3] + 1)
+    return inter / (area(corners) + area(b) - inter + 1e-5)
+
+
+def explain_detection(k_cpu, k_dev, dev_ctx, cpu_ctx):
+    """WHY a device detection may differ from the CPU leg's by more than rounding: the pipeline has three discrete decisions between the head
+    outputs and a detection, and a 1e-4 perturbation of the outputs can flip each of them for a few anchors per frame --
+      centre_differs : soft-NMS selected another anchor as this cluster's centre (ranking order of two candidates);
+      filter_flip    : an anchor is kept by one side's categorical filter and not by the other's (a draw at a CDF edge: inference_utils.py:37-51);
+      member_flip    : the same anchors are kept, but one sits on the other side of the affinity threshold (IoU > 0.5 of posterior means, :316);
+      draw_flip      : same centre, same members, but a member's sampled class counts differ (a draw at a CDF edge that did not change the filter);
+      numeric        : none of the above -- the difference is arithmetic.
+    Needs the posterior both sides kept (anchor ids, counts, means) and the centres; None when the bench did not collect them."""
+    if dev_ctx is None or cpu_ctx is None:
+        return None
+    ca = cpu_ctx["anchor_index"]
+    cpu_centre = int(ca[cpu_ctx["centres"][k_cpu]])
+    cpu_members = set(int(x) for x in ca[np.nonzero(cpu_ctx["iou"][:, cpu_ctx["centres"][k_cpu]] > 0.5)[0]])
+    da = dev_ctx["anchor_index"]
+    dev_kept, cpu_kept = cpu_ctx.setdefault("_dev_kept", set(int(x) for x in da)), cpu_ctx.setdefault("_cpu_kept", set(int(x) for x in ca))
+    if k_dev is None:
+        return "centre_differs" if cpu_centre in dev_kept else "filter_flip"
+    dcen = int(dev_ctx["centres"][k_dev])
+    if int(da[dcen]) != cpu_centre:
+        return "centre_differs" if cpu_centre in dev_kept else "filter_flip"
+    corners = dev_ctx.setdefault("_corners", _vuhw_corners32(dev_ctx["means"]))
+    dev_members = set(int(x) for x in da[np.nonzero(_iou_column_a15(corners, dcen) > 0.5)[0]])
+    if dev_members != cpu_members:
+        diff = dev_members ^ cpu_members
+        return "filter_flip" if any((a not in dev_kept) or (a not in cpu_kept) for a in diff) else "member_flip"
+    dpos = dev_ctx.setdefault("_pos", {int(a): i for i, a in enumerate(da)})
+    cpos = cpu_ctx.setdefault("_pos", {int(a): i for i, a in enumerate(ca)})
+    for a in cpu_members:
+        if not np.array_equal(np.asarray(dev_ctx["counts"][dpos[a]], np.float32), np.asarray(cpu_ctx["counts"][cpos[a]], np.float32)):
+            return "draw_flip"
+    return "numeric"
 
 
 def _posterior_pmc_bytes(B, n, hw):
@@ -159,20 +218,49 @@ def _posterior_pmc_bytes(B, n, hw):
 
 def detection_statistics(per_frame):
     """Detection-level distance of one precision mode to the CPU leg over EVERY frame the CPU leg computed (round-4 review: one frame is
-    an anecdote): match rate, frames whose detections come out in the CPU leg's order, and median / p95 / max of the per-detection worst
-    box coordinate error (pixels), covariance entry error (relative, floor 1 % of the matrix's largest entry) and score error."""
+    an anecdote): match rate, frames whose detections come out in the CPU leg's order, and median / p95 / p99 / max of the per-detection
+    worst box coordinate error (pixels and relative to |mu| + 1 px), covariance error (entries relative to |entry| + 1 % of the matrix's
+    largest entry; Frobenius-relative) and score error.  Round 6: every detection outside 1e-3 is counted WITH ITS CAUSE (explain_detection:
+    a discrete flip of the filter / a cluster member / a draw / the centre, or arithmetic), and the maxima are repeated over the detections
+    whose discrete decisions all agree (`numeric_only`): that is the statement the 1e-3 gate is about."""
     per_frame = [p for p in per_frame if p is not None]
     if not per_frame:
         return None
-    q = lambda name: np.concatenate([p[name] for p in per_frame if name in p]) if any(name in p for p in per_frame) else np.zeros(0)
+    q = lambda name: np.concatenate([np.asarray(p[name]) for p in per_frame if name in p]) if any(name in p for p in per_frame) else np.zeros(0)
     st = lambda v: ({"median": float("%.3g" % np.median(v)), "p95": float("%.3g" % np.quantile(v, 0.95)), "p99": float("%.3g" % np.quantile(v, 0.99)),
                      "max": float("%.3g" % v.max())} if len(v) else None)
-    return {"frames": len(per_frame),
-            "cpu_detections": int(sum(p["cpu_detections"] for p in per_frame)), "device_detections": int(sum(p["device_detections"] for p in per_frame)),
-            "matched": int(sum(p["matched"] for p in per_frame)),
-            "frames_in_same_order": int(sum(1 for p in per_frame if p.get("same_order"))),
-            "frames_counts_equal": int(sum(1 for p in per_frame if p.get("counts_equal"))),
-            "abs_dmu_px": st(q("_dmu_px")), "rel_dSigma": st(q("_rel_dsigma")), "dscore": st(q("_dscore"))}
+    out = {"frames": len(per_frame),
+           "cpu_detections": int(sum(p["cpu_detections"] for p in per_frame)), "device_detections": int(sum(p["device_detections"] for p in per_frame)),
+           "matched": int(sum(p["matched"] for p in per_frame)),
+           "frames_in_same_order": int(sum(1 for p in per_frame if p.get("same_order"))),
+           "frames_counts_equal": int(sum(1 for p in per_frame if p.get("counts_equal"))),
+           "abs_dmu_px": st(q("_dmu_px")), "rel_dmu": st(q("_rel_dmu")), "rel_dSigma": st(q("_rel_dsigma")), "fro_dSigma": st(q("_fro_dsigma")),
+           "dscore": st(q("_dscore"))}
+    causes = [c for p in per_frame for c in p.get("_cause", [])]
+    if causes and len(causes) == len(q("_rel_dmu")):
+        rel_mu, rel_sig, dsc = q("_rel_dmu"), q("_rel_dsigma"), q("_dscore")
+        outside = (rel_mu > 1e-3) | (rel_sig > 1e-3) | (dsc > 1e-3)
+        known = all(c is not None for c in causes)
+        by_cause = {}
+        for c, o in zip(causes, outside):
+            if o:
+                by_cause[c or "unexplained (posterior not collected)"] = by_cause.get(c or "unexplained (posterior not collected)", 0) + 1
+        unmatched = [c for p in per_frame for c in p.get("_unmatched_cause", [])]
+        for c in unmatched:
+            by_cause["unmatched: " + (c or "unexplained")] = by_cause.get("unmatched: " + (c or "unexplained"), 0) + 1
+        out["outside_1e-3"] = {"detections": int(outside.sum()) + len(unmatched), "of": out["cpu_detections"], "by_cause": by_cause}
+        if known:
+            num = np.array([c == "numeric" for c in causes])
+            out["discrete_flips"] = {"detections": int((~num).sum()) + len(unmatched),
+                                     "by_kind": {k: int(sum(1 for c in causes if c == k)) + int(sum(1 for c in unmatched if c == k))
+                                                 for k in ("centre_differs", "filter_flip", "member_flip", "draw_flip")}}
+            if num.any():
+                out["numeric_only"] = {"detections": int(num.sum()), "max_rel_dmu": float("%.3g" % rel_mu[num].max()),
+                                       "max_abs_dmu_px": float("%.3g" % q("_dmu_px")[num].max()),
+                                       "max_rel_dSigma": float("%.3g" % rel_sig[num].max()), "max_fro_dSigma": float("%.3g" % q("_fro_dsigma")[num].max()),
+                                       "max_dscore": float("%.3g" % dsc[num].max()),
+                                       "outside_1e-3": int((outside & num).sum())}
+    return out
 
 
 def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_raw=None, seed=0, first_image_id=0, device_dets=None):
@@ -245,11 +333,13 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
         corners = post["corners"].astype(np.float32)
         idx, _ = nms.soft_nms(corners, post["ranking"], 100, 0.5, 0.5)
         t3 = time.perf_counter()
-        dets = None
+        dets, iou = None, None
         if len(idx):
             iou = geometry.bbox_iou_vuvu(corners, corners)
             dets = clustering.bayes_od_clustering(post["counts"], post["means"], post["covs"], idx, iou, 0.5)
         t4 = time.perf_counter()
+        cpu_ctx = ({"anchor_index": np.nonzero(post["keep"])[0], "centres": np.asarray(idx), "iou": iou, "counts": post["counts"]}
+                   if iou is not None else None)
         if done == 0:
             cpu_dets0 = dets
         parts["forward"] += t1 - t0; parts["posterior"] += t2 - t1
@@ -261,10 +351,11 @@ def cpu_baseline(hw, n, frames, weights, anchors, seconds_budget=25.0, device_ra
                                                           (cov, "_covar_params"))]
                 parity[mode] = {"max_rel_err": max(e[0] for e in errs), "rel_rms": max(e[1] for e in errs), "max_rel_err_strict": max(e[2] for e in errs)}
             for mode, dev in (device_dets or {}).items():
-                parity.setdefault(mode, {})["detections"] = detection_parity(dev[0], cpu_dets0)
+                parity.setdefault(mode, {})["detections"] = detection_parity(dev[0][:4], cpu_dets0)
         for mode, dev in (device_dets or {}).items():
             if done < len(dev):
-                per_frame[mode].append(detection_parity(dev[done], dets, arrays=True))
+                dctx = dict(dev[done][4]) if len(dev[done]) > 4 and dev[done][4] is not None else None
+                per_frame[mode].append(detection_parity(dev[done][:4], dets, arrays=True, dev_ctx=dctx, cpu_ctx=dict(cpu_ctx) if cpu_ctx else None))
         done += 1
     for mode, pf in per_frame.items():
         parity.setdefault(mode, {})["detections_all_frames"] = detection_statistics(pf)
@@ -359,6 +450,18 @@ def make_engine(hw, B, n, device, precision="bf16", weights=None, anchors=None, 
     if anchors is not None:
         eng.set_anchors(anchors)
     return eng
+
+
+def frame_outputs(eng, i):
+    """Detections of frame i of the last synchronous infer + what explain_detection needs from the device: the kept anchors' ids, class
+    counts and posterior means, and the soft-NMS centres."""
+    det = eng.get_detections(i)
+    try:
+        post = eng.get_posterior(i)
+        ctx = {"anchor_index": post["anchor_index"], "counts": post["counts"], "means": post["means"], "centres": eng.get_nms(i)}
+    except Exception:          # (a plan that keeps no posterior readable: the comparison then reports its causes as unexplained)
+        ctx = None
+    return det + (ctx,)
 
 
 def raw_of_image0(eng):
@@ -895,7 +998,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
         # raw head outputs of frame 0 with (seed 0, image id lo) for the parity figures of the CPU leg
         eng.upload_images(frames)
         eng.infer(None, seed=0, first_image_id=lo)
-        device_dets["bf16"] = [eng.get_detections(i) for i in range(min(B, N_CMP_FRAMES))]
+        device_dets["bf16"] = [frame_outputs(eng, i) for i in range(min(B, N_CMP_FRAMES))]
         device_raw["bf16"] = raw_of_image0(eng)          # (re-runs the raw flavour of the last tower launches: same Philox streams)
         # ---- what the MC aggregation (a9-a10) costs where it now lives, inside the tower epilogues: the same steps on a handle
         # planned WITHOUT it (raw [B,N,A,.] tensors + the posterior's own loops over the samples), same box, same frames
@@ -966,10 +1069,13 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             engp = make_engine(hw, Bp, n, local_rank, precision=mode, weights=weights, anchors=anchors)
             engp.upload_images(frames[:Bp])
             engp.infer(None, seed=0, first_image_id=lo)
-            device_dets[mode] = [engp.get_detections(i) for i in range(min(Bp, N_CMP_FRAMES))]
+            device_dets[mode] = [frame_outputs(engp, i) for i in range(min(Bp, N_CMP_FRAMES))]
             device_raw[mode] = raw_of_image0(engp)
             p_steps = 5
-            dt = timed_pipeline(engp, p_steps, 2, False, Bp, first_id=lo)
+            timed_pipeline(engp, 2, 0, False, Bp, first_id=lo)          # warm-up
+            engp.profile_begin(which=1 if mode in ("f16mx", "f16mx4") else 0)      # HIP events on the engine's own stream around every launch of the dominant kernel
+            dt = timed_pipeline(engp, p_steps, 0, False, Bp, first_id=lo)
+            pprof = engp.profile_end()
             products = 1.5 if (mode in ("f16mx", "f16mx4") and engp.plan_info()["tower_mx"]) else 3.0
             out[key] = {"precision": mode, "images_per_sec": round(Bp * p_steps / dt, 2),
                         "ms_per_step": round(dt / p_steps * 1e3, 3), "frames_per_step": Bp, "steps": p_steps,
@@ -977,6 +1083,21 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                         "pipeline_tflops": round(image_gflop(hw, engp.P, n) * Bp * p_steps / dt / 1e3, 2),
                         "tower_bf16_product_equivalents_per_multiplication": products,
                         "max_rel_err": None, "plan": engp.plan_info()}
+            if pprof["head_conv_launches"] > 0 and pprof["head_conv_ms"] > 0:
+                # the dominant kernel of THIS mode, from the timed steps: algorithmic FLOPs (2 per multiply-add, whatever the mode issues per
+                # multiplication) / the launches' summed duration; `frac` against the bf16 dense peak as north_star words it, and
+                # `frac_of_own_mfma_floor` against the matrix-pipe time of the mode's own instruction mix (products x the bf16 time)
+                ach = pprof["head_conv_flops"] / (pprof["head_conv_ms"] * 1e-3) / 1e12
+                mx = mode in ("f16mx", "f16mx4") and engp.plan_info()["tower_mx"]
+                out[key]["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": ("conv_igemm_mx_kernel<%d> (head towers, layers 1-3: f16 hi*hi + block-scaled %s cross terms)" % ((1, "e2m3") if mode == "f16mx" else (3, "e2m1"))
+                               if mx else "conv_igemm_kernel<256,256,2,4,0,%s,true> (every head 3x3 launch, (hi, lo) bf16 pairs: three products per multiplication)" % ("true" if engp.plan_info().get("row_reuse") else "false")),
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "mfma_issue_tflops_bf16_equivalent": round(products * ach, 2), "frac_of_own_mfma_floor": round(products * ach / PEAK_BF16_TFLOPS, 4),
+                    "avg_launch_ms": round(pprof["head_conv_ms"] / pprof["head_conv_launches"], 4),
+                    "launches_per_step": int(pprof["head_conv_launches"] // p_steps),
+                    "share_of_step": round(pprof["head_conv_ms"] / p_steps / (dt / p_steps * 1e3), 3), "traffic": None}
             engp.close()
             del engp
         out["secondary"] = secondary_configs(local_rank, weights, lo)
@@ -1004,26 +1125,51 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             out["config"]["headline_mode_distance_to_cpu_forward"] = {k: (float("%.3g" % v) if not isinstance(v, dict) and v is not None else v)
                                                                       for k, v in parity["bf16"].items()}
     # `parity_mode` = the fastest of the measured modes that meets EVERY clause of north_star's "outputs (boxes, class logits, 4x4
-    # covariance) match ... within 1e-3" in this run: raw head outputs of frame 0, and over every frame of the CPU leg all detections
-    # matched in order, box means, scores and covariance ENTRIES (|d| / (|entry| + 1 % of the matrix's largest)) within 1e-3.  The other
-    # modes stay beside it with the clauses they meet (f16mx4: the covariance entries sit at ~2.5e-3 -- the epistemic part is a sample
-    # variance of N nearly equal boxes and amplifies the raw outputs' 6e-4).  Without the CPU leg nothing is known: first mode, nulls.
+    # covariance) match ... within 1e-3" in this run.  The gate (round 6; SURVEY 8d "Parity gate"), over every frame of the CPU leg:
+    #   raw_outputs            max |d| / (|ref| + rms(ref)) of the raw head outputs of frame 0 <= 1e-3 (the strict form is reported beside it);
+    #   numeric_max_within     over the detections whose DISCRETE decisions agree with the CPU leg's (same centre, same kept anchors, same
+    #                          cluster members, same sampled counts: explain_detection) the MAXIMUM of box means (|d| / (|mu| + 1 px)), scores
+    #                          (absolute: they are probabilities) and covariance entries (|d| / (|entry| + 1 % of the matrix's largest)) <= 1e-3;
+    #   discrete_flips         the others -- a categorical draw at a CDF edge, a cluster member at the affinity threshold, a centre swapped: a
+    #                          1e-4 perturbation flips a handful per frame in ANY arithmetic -- counted by kind and bounded at one per frame on
+    #                          average; every unmatched CPU detection must be one of them.
+    # p99 and max of every metric over ALL matched detections stand beside the gate so that nothing hides behind it.
     measured = [m for m in PARITY_MODES if "parity_mode_" + m in out]
     if measured:
         def clauses(r):
             st = r.get("detections_all_frames") or {}
             if r["max_rel_err"] is None or not st:
                 return None
-            # two candidates of one cluster at the affinity threshold may swap under a 1e-4 perturbation: the bound is on the p99
-            p99 = lambda k: (st.get(k) or {}).get("p99", float("inf"))
-            return {"raw_outputs": bool(r["max_rel_err"] <= 1e-3), "all_matched": st.get("matched") == st.get("cpu_detections") == st.get("device_detections"),
-                    "boxes_p99_le_1e-2_px": bool(p99("abs_dmu_px") <= 1e-2), "scores_p99": bool(p99("dscore") <= 1e-3), "covariance_entries_p99": bool(p99("rel_dSigma") <= 1e-3)}
+            num, flips = st.get("numeric_only"), st.get("discrete_flips")
+            stat = lambda k, f: (st.get(k) or {}).get(f)
+            c = {"raw_outputs": bool(r["max_rel_err"] <= 1e-3), "raw_outputs_max_rel_err": r["max_rel_err"], "raw_outputs_strict_max": r.get("max_rel_err_strict"),
+                 "p99": {k: stat(k, "p99") for k in ("rel_dmu", "abs_dmu_px", "rel_dSigma", "fro_dSigma", "dscore")},
+                 "max": {k: stat(k, "max") for k in ("rel_dmu", "abs_dmu_px", "rel_dSigma", "fro_dSigma", "dscore")},
+                 "outside_1e-3": st.get("outside_1e-3")}
+            if num is None or flips is None:            # (no posterior collected: the causes are unknown and the max over everything decides)
+                c["numeric_max_within_1e-3"] = bool(max(stat("rel_dmu", "max"), stat("rel_dSigma", "max"), stat("dscore", "max")) <= 1e-3)
+                c["all_matched"] = st.get("matched") == st.get("cpu_detections") == st.get("device_detections")
+                return c
+            c["numeric_only"] = num
+            c["numeric_max_within_1e-3"] = bool(max(num["max_rel_dmu"], num["max_rel_dSigma"], num["max_dscore"]) <= 1e-3)
+            c["discrete_flips"] = flips
+            c["discrete_flips_at_most_one_per_frame"] = bool(flips["detections"] <= st["frames"])
+            c["unmatched_all_explained"] = bool(st["cpu_detections"] - st["matched"] <=
+                                                sum(v for k, v in (st.get("outside_1e-3") or {}).get("by_cause", {}).items()
+                                                    if k.startswith("unmatched: ") and "unexplained" not in k))
+            return c
+        gate_ok = lambda c: bool(c) and all(v for v in c.values() if isinstance(v, bool))
         for m in measured:
             out["parity_mode_" + m]["meets_1e-3"] = clauses(out["parity_mode_" + m])
-        ok = [m for m in measured if out["parity_mode_" + m]["meets_1e-3"] and all(out["parity_mode_" + m]["meets_1e-3"].values())]
+        ok = [m for m in measured if gate_ok(out["parity_mode_" + m]["meets_1e-3"])]
         chosen = max(ok, key=lambda m: out["parity_mode_" + m]["images_per_sec"]) if ok else ("f16mx" if "f16mx" in measured else measured[0])
+        verified = any(out["parity_mode_" + m]["meets_1e-3"] for m in measured)
         out["parity_mode"] = out.pop("parity_mode_" + chosen)
-        out["parity_mode"]["chosen"] = ("fastest of %s that meets every clause" % "/".join(measured)) if ok else "no mode verified in this run (no CPU leg)"
+        out["parity_mode"]["chosen"] = ("fastest of %s that meets every clause" % "/".join(measured)) if ok else \
+            ("no measured mode meets every clause in this run" if verified else "no mode verified in this run (no CPU leg)")
+        # the images/sec that satisfies north_star's accuracy clause and its throughput clause TOGETHER (null when no mode was verified)
+        out["value_at_parity"] = out["parity_mode"]["images_per_sec"] if ok else None
+        out["value_at_parity_mode"] = chosen if ok else None
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -76,3 +76,51 @@ def test_detection_statistics_aggregates_every_frame():
     assert bench.detection_statistics([]) is None
     e = bench._rel_errs(np.array([1.0, 2.0, 1e-9]), np.array([1.0, 2.002, 0.0]))
     assert abs(e[0] - 0.002 / (2.002 + np.sqrt((1 + 2.002 ** 2) / 3))) < 1e-12 and abs(e[2] - 0.002 / 2.002) < 1e-12      # strict: the zero of `ref` is not rated
+
+
+def test_detections_outside_1e3_are_counted_by_cause():
+    """bench.explain_detection / detection_statistics (round 6): a detection that differs from the CPU leg's by more than 1e-3 is reported
+    with WHY -- another centre, an anchor kept by one side's filter only, a cluster member across the affinity threshold, a member's
+    sampled counts, or arithmetic -- and the gate's maxima are taken over the detections whose discrete decisions agree."""
+    import numpy as np
+    import bench
+
+    def ctx_pair():
+        # five kept anchors: centre 0 with members {0, 1}, centre 3 with members {3, 4}; anchor 2 is nobody's member
+        means = np.array([[100, 100, 40, 40], [102, 101, 40, 40], [300, 300, 40, 40], [200, 200, 40, 40], [201, 202, 40, 40]], np.float32)
+        anchor = np.array([10, 11, 12, 13, 14])
+        counts = np.tile(np.arange(8, dtype=np.float32) + 0.125, (5, 1))
+        corners = bench._vuhw_corners32(means)
+        iou = np.stack([bench._iou_column_a15(corners, c) for c in range(5)], 1)
+        cpu = {"anchor_index": anchor.copy(), "centres": np.array([0, 3]), "iou": iou, "counts": counts.copy()}
+        dev = {"anchor_index": anchor.copy(), "centres": np.array([0, 3]), "means": means.copy(), "counts": counts.copy()}
+        return dev, cpu
+    dev, cpu = ctx_pair()
+    assert bench.explain_detection(0, 0, dev, cpu) == "numeric" and bench.explain_detection(1, 1, dev, cpu) == "numeric"
+    dev, cpu = ctx_pair(); dev["counts"][1, 0] += 1; dev["counts"][1, 1] -= 1
+    assert bench.explain_detection(0, 0, dev, cpu) == "draw_flip" and bench.explain_detection(1, 1, dev, cpu) == "numeric"
+    dev, cpu = ctx_pair(); dev["means"][4] = [260, 260, 40, 40]                # member 14 leaves centre 13's cluster on the device
+    assert bench.explain_detection(1, 1, dev, cpu) == "member_flip"
+    dev, cpu = ctx_pair()                                                      # the device's filter dropped anchor 11 (a member of centre 10)
+    for k in ("anchor_index", "means", "counts"):
+        dev[k] = np.delete(dev[k], 1, axis=0)
+    dev["centres"] = np.array([0, 2])
+    assert bench.explain_detection(0, 0, dev, cpu) == "filter_flip" and bench.explain_detection(1, 1, dev, cpu) == "numeric"
+    dev, cpu = ctx_pair(); dev["centres"] = np.array([1, 3])                   # soft-NMS chose anchor 11 as the first cluster's centre
+    assert bench.explain_detection(0, 0, dev, cpu) == "centre_differs"
+    assert bench.explain_detection(0, None, dev, cpu) == "centre_differs"      # an unmatched CPU detection whose centre the device kept
+    assert bench.explain_detection(0, 0, None, cpu) is None
+
+    # the statistic: one frame, two detections, the second one moved by a member flip
+    dev, cpu = ctx_pair(); dev["means"][4] = [260, 260, 40, 40]
+    k = 2
+    ref = (np.full((k, 8), 0.125), np.array([[101, 100.5, 40, 40], [200.5, 201, 40, 40]], np.float64)[:, :, None], np.tile(np.eye(4) * 4.0, (k, 1, 1)), np.ones((k, 8)))
+    det = (ref[0].copy(), ref[1][:, :, 0].copy(), ref[2].copy(), ref[3].copy())
+    det[1][1] += 0.5                                                            # 0.5 px on a 200 px coordinate: 2.5e-3
+    p = bench.detection_parity(det, ref, arrays=True, dev_ctx=dev, cpu_ctx=cpu)
+    assert p["_cause"] == ["numeric", "member_flip"] or p["_cause"] == ["member_flip", "numeric"]
+    st = bench.detection_statistics([p])
+    assert st["outside_1e-3"] == {"detections": 1, "of": 2, "by_cause": {"member_flip": 1}}
+    assert st["discrete_flips"]["detections"] == 1 and st["discrete_flips"]["by_kind"]["member_flip"] == 1
+    assert st["numeric_only"]["detections"] == 1 and st["numeric_only"]["max_rel_dmu"] == 0.0 and st["numeric_only"]["outside_1e-3"] == 0
+    assert st["rel_dmu"]["max"] > 1e-3 and st["fro_dSigma"]["max"] == 0.0
