@@ -320,6 +320,8 @@ struct bod_context {
     bool in_overlap_call = false;
     int n_cu = 256;                                     // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     hipEvent_t ev_posterior = nullptr; hipEvent_t ev_done[2] = {nullptr, nullptr};
+    int dev_op_lo = 0, dev_op_hi = 1 << 30;                   // BOD_FORWARD_OPS=lo:hi (development: tests/tools/selfcheck_probe.py): forward runs ops [lo, hi) only
+    hipStream_t done_stream[2] = {nullptr, nullptr};          // the stream that finished a slot's records (bod_infer_async): a ticket's gather follows on it
     bool side_pending[2] = {false, false};
     char* host_stage[2] = {nullptr, nullptr};     // pinned host copy of a slot's records (filled on the side stream)
     float* rec_send = nullptr; float* rec_recv = nullptr; size_t rec_recv_elems = 0;      // bod_gather_detections: packed records, gathered blocks
@@ -1302,6 +1304,7 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
         hipStream_t st = is_front ? fs : h->stream;
         ++op_i;
         if ((op.flavour != FLAVOUR_BOTH && op.flavour != flavour) || (only_flavoured && op.flavour == FLAVOUR_BOTH)) continue;
+        if ((int)op_i - 1 < h->dev_op_lo || (int)op_i - 1 >= h->dev_op_hi) continue;          // (BOD_FORWARD_OPS: development)
         if (ov && first_back) {                          // the pyramid is complete: hand it to the back
             HIPCHK(h, hipEventRecord(h->ev_front_done[par], fs));
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done[par], 0));
@@ -1549,14 +1552,27 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
     h->split = c.precision == BOD_PRECISION_BF16X3 || c.precision == BOD_PRECISION_F16MX || c.precision == BOD_PRECISION_F16MX4;
     h->mx = c.precision == BOD_PRECISION_F16MX ? 1 : c.precision == BOD_PRECISION_F16MX4 ? 2 : 0;
     if (hipSetDevice(c.device) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipSetDevice(%d) failed", c.device));
-    // BOD_MAIN_CUS_PER_XCD=k (development aid, tests/tools): the main stream owns only CU slots [0, k) of each of the 8 XCDs
-    // (mask bit i = slot i / 8 of XCD i % 8: tests/tools/cu_mask_probe.hip)
-    if (const char* e = getenv("BOD_MAIN_CUS_PER_XCD")) {
-        uint32_t mask[8];
-        cu_slot_mask(0, std::max(1, std::min(32, atoi(e))), mask);
-        if (hipExtStreamCreateWithCUMask(&h->stream, 8, mask) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipExtStreamCreateWithCUMask failed"));
-    } else
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
+    // Development switches of the section-8.4 probes (tests/tools/selfcheck_probe.py), read when the handle is created:
+    //   BOD_CU_MASK_SLOTS=lo:hi  the handle's main stream may use CU slots [lo, hi) of every XCD only (hipExtStreamCreateWithCUMask);
+    //   BOD_FORWARD_OPS=lo:hi    bod_forward runs ops [lo, hi) of the plan only (a company of chosen kernels; the outputs are garbage).
+    if (const char* e = getenv("BOD_FORWARD_OPS")) { int lo = 0, hi = 0; if (sscanf(e, "%d:%d", &lo, &hi) == 2 && lo >= 0 && hi > lo) { h->dev_op_lo = lo; h->dev_op_hi = hi; } }
+    bool masked_main = false;
+    // (BOD_MAIN_CUS_PER_XCD=k, the older spelling: slots [0, k))
+    const std::string mask_env = getenv("BOD_CU_MASK_SLOTS") ? std::string(getenv("BOD_CU_MASK_SLOTS")) :
+                                 getenv("BOD_MAIN_CUS_PER_XCD") ? "0:" + std::to_string(std::max(1, std::min(32, atoi(getenv("BOD_MAIN_CUS_PER_XCD"))))) : std::string();
+    if (!mask_env.empty()) {
+        const char* e = mask_env.c_str();
+        int lo = 0, hi = 0;
+        hipDeviceProp_t prop;
+        if (sscanf(e, "%d:%d", &lo, &hi) == 2 && hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount % 8 == 0 &&
+            lo >= 0 && hi > lo && hi <= prop.multiProcessorCount / 8) {
+            uint32_t m[8];
+            cu_slot_mask(lo, hi, m);
+            if (hipExtStreamCreateWithCUMask(&h->stream, 8, m) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipExtStreamCreateWithCUMask failed"));
+            masked_main = true;
+        } else return bail(h->fail(BOD_ERR_INVALID_ARG, "BOD_CU_MASK_SLOTS=%s: want lo:hi within the XCD's CU slots", e));
+    }
+    if (!masked_main && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(BOD_ERR_HIP, "hipStreamCreate failed"));
     h->full = h->stream;
     {
@@ -1569,6 +1585,11 @@ bod_status bod_create(const bod_config* cfg, bod_handle* out) {
         int want = c.pipeline_overlap ? 1 : 0;
         if (const char* e = getenv("BOD_OVERLAP")) want = atoi(e);
         if (c.training) want = 0;
+        // Round 6: the mode runs kernels of this library beside each other by design, and those can miscompute a 16-lane row
+        //  -- it is slower than one stream anyway (8.3).  An experiment, never a default: refused without the switch.
+        if (want && !(getenv("BOD_OVERLAP_EXPERIMENTAL") && atoi(getenv("BOD_OVERLAP_EXPERIMENTAL")) == 1))
+            return bail(h->fail(BOD_ERR_INVALID_ARG, "pipeline_overlap is experimental (slower than one stream and not bit-reproducible: include/bayesod.h, "
+                                                     "DESIGN.md 8.3-8.4): set BOD_OVERLAP_EXPERIMENTAL=1 to create such a handle"));
         if (want) {
             const int slots = h->n_cu / 8;
             int fs = getenv("BOD_OVERLAP_FRONT_SLOTS") ? atoi(getenv("BOD_OVERLAP_FRONT_SLOTS")) : 4;
@@ -2188,6 +2209,7 @@ bod_status bod_infer_async(bod_handle h, const float* images, int32_t on_device,
         HIPCHK(h, hipMemcpyAsync(hs, h->out_counts_s[sidx], BK * C * 4, hipMemcpyDeviceToHost, sd));
     }
     HIPCHK(h, hipEventRecord(h->ev_done[sidx], sd));
+    h->done_stream[sidx] = sd;
     h->side_pending[sidx] = true;
     *slot_out = sidx;
     return BOD_OK;
@@ -2692,7 +2714,13 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     const size_t block = (size_t)B * K * W;
     // where the records are and which stream finished them
     int sidx = slot;
-    hipStream_t st = h->side;
+    // Round 6: a ticket's pack kernel and gather no longer run on the side stream beside the next call's forward -- a kernel
+    // of this library beside its convolution kernels can miscompute a 16-lane row, and the pack kernel is one.  They follow the slot's
+    // records on the stream that finished them (the main stream; the back stream of a pipeline_overlap handle): if the next
+    // bod_infer_async is already enqueued they run behind its kernels -- one step of latency, nothing beside anything.
+    // BOD_SIDE_STREAM=1 (the repro switch of bod_infer_async): the side stream again.
+    static const bool side_on = [] { const char* e = getenv("BOD_SIDE_STREAM"); return e && atoi(e) != 0; }();
+    hipStream_t st = (slot >= 0 && slot <= 1 && !side_on && h->done_stream[slot]) ? h->done_stream[slot] : h->side;
     if (slot < 0) {
         // synchronous bod_infer / bod_cluster_fuse: the records are the current buffers, finished on the MAIN stream -- pack and gather
         // go out on that stream too, so the next bod_infer (which rewrites nms_nsel / out_* of this slot on the main stream) and
@@ -2709,7 +2737,7 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     // rec_send / rec_recv are shared by the ticket gathers (side stream) and the synchronous form (main stream): a gather that goes to
     // the other stream than the previous one waits for it -- nothing else orders the two streams against each other (round-4 advisor finding)
     if (h->ev_gather && h->gather_stream && h->gather_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_gather, 0));
-    // a ticket's records are finished on the main stream since round 5 (bod_infer_async): the side stream waits for the slot's event
+    // (on the side stream: behind the slot's event; on the records' own stream the wait is a no-op)
     if (slot >= 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_done[slot], 0));
     HIPCHK(h, launch_pack_records(h->nms_nsel_s[sidx], h->out_scores_s[sidx], h->out_means_s[sidx], h->out_covs_s[sidx],
                                   h->out_counts_s[sidx], h->rec_send, B, K, C, st));
@@ -2736,7 +2764,7 @@ bod_status bod_gather_detections(bod_handle h, int32_t slot, void* nccl_comm, in
     if (rank == root && gathered_host) {
         HIPCHK(h, hipMemcpyAsync(gathered_host, recv, block * world * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipEventRecord(h->ev_gather, st)); h->gather_stream = st;
-        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipEventSynchronize(h->ev_gather));          // (the copy, not whatever was enqueued on the stream behind it)
     } else {
         HIPCHK(h, hipEventRecord(h->ev_gather, st)); h->gather_stream = st;
     }

@@ -214,8 +214,22 @@ __global__ __launch_bounds__(POST_BLOCK) void post_compact_kernel(PostCfg c, Pos
 }
 
 // K3: per kept anchor fusion, written straight to its compacted slot
+// BOD_POST_SELFCHECK (development build, tests/tools/build_variant.sh + selfcheck_probe.py): every slot is computed TWICE
+// in the same thread through ONE out-of-line copy of the code -- the same machine instructions on the same inputs -- and the two
+// results are compared bit for bit; a difference is logged with where the wave ran (HW_REG_HW_ID: SIMD / CU / SE, HW_REG_XCC_ID).
+#if defined(BOD_POST_SELFCHECK)
+#define POST_FUSE_INLINE __noinline__
+#define POST_FUSE_OUT , float* __restrict__ out20
+struct SelfcheckRec { uint32_t hw_id, xcc_id, image, slot, lane, elem; float first, second; };
+__device__ unsigned int g_selfcheck_count;
+__device__ unsigned long long g_selfcheck_waves;          // waves that ran the check (the rate's denominator)
+__device__ SelfcheckRec g_selfcheck_recs[4096];
+#else
+#define POST_FUSE_INLINE __forceinline__
+#define POST_FUSE_OUT
+#endif
 template <int C>
-__device__ __forceinline__ void post_fuse_anchor(const PostCfg& c, const PostBuffers& pb, const int b, const int slot) {
+__device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBuffers& pb, const int b, const int slot POST_FUSE_OUT) {
     const size_t o = (size_t)b * c.A + slot;
     const int a = pb.anchor_index[o];
 
@@ -386,6 +400,14 @@ __device__ __forceinline__ void post_fuse_anchor(const PostCfg& c, const PostBuf
 #pragma unroll
         for (int j = 0; j < 4; ++j) pb.covs[o * 16 + i * 4 + j] = pcov.m[i][j];
     }
+#if defined(BOD_POST_SELFCHECK)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out20[i] = pm[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out20[4 + i * 4 + j] = pcov.m[i][j];
+    }
+#endif
     pb.ranking[o] = best;                                         // ranking_method 'score' (:202)
     // box_utils.vuhw_to_vuvu (:5-23)
     pb.corners[o * 4 + 0] = pm[0] - pm[2] / 2.0f;
@@ -400,8 +422,45 @@ template <int C>
 __global__ __launch_bounds__(POST_BLOCK) void post_fuse_kernel(PostCfg c, PostBuffers pb, int nblocks) {
     const int b = blockIdx.y;
     const int m = pb.num_kept[b];
+#if defined(BOD_POST_SELFCHECK)
+    for (int slot = blockIdx.x * POST_BLOCK + threadIdx.x; slot < m; slot += gridDim.x * POST_BLOCK) {
+        float r1[20], r2[20];
+        post_fuse_anchor<C>(c, pb, b, slot, r1);
+        post_fuse_anchor<C>(c, pb, b, slot, r2);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_selfcheck_waves, 1ull);
+        int bad = -1;
+        for (int i = 19; i >= 0; --i) if (__float_as_uint(r1[i]) != __float_as_uint(r2[i])) bad = i;
+        if (bad >= 0) {
+            const unsigned int k = atomicAdd(&g_selfcheck_count, 1u);
+            if (k < 4096u) {
+                SelfcheckRec r;
+                r.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID, all 32 bits
+                r.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);        // HW_REG_XCC_ID
+                r.image = (uint32_t)b; r.slot = (uint32_t)slot; r.lane = threadIdx.x & 63; r.elem = (uint32_t)bad;
+                r.first = r1[bad]; r.second = r2[bad];
+                g_selfcheck_recs[k] = r;
+            }
+        }
+    }
+#else
     for (int slot = blockIdx.x * POST_BLOCK + threadIdx.x; slot < m; slot += gridDim.x * POST_BLOCK) post_fuse_anchor<C>(c, pb, b, slot);
+#endif
 }
+#if defined(BOD_POST_SELFCHECK)
+// (development builds only: not in include/bayesod.h)  count of mismatching slots since the last call, the waves that ran the check, up to
+// `max` records of 8 dwords {hw_id, xcc_id, image, slot, lane, element, first, second}; resets the log.
+extern "C" int bod_debug_selfcheck_read(unsigned int* count, unsigned long long* waves, void* recs, int max) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_selfcheck_count), 4) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_selfcheck_waves), 8) != hipSuccess) return 1;
+    const unsigned int m = n < (unsigned)max ? n : (unsigned)max;
+    if (m && hipMemcpyFromSymbol(recs, HIP_SYMBOL(g_selfcheck_recs), (size_t)(m < 4096u ? m : 4096u) * sizeof(SelfcheckRec)) != hipSuccess) return 1;
+    const unsigned int z = 0; const unsigned long long z8 = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_selfcheck_count), &z, 4) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_selfcheck_waves), &z8, 8) != hipSuccess) return 1;
+    *count = n;
+    return 0;
+}
+#endif
 
 hipError_t launch_posterior(const PostCfg& c, const PostBuffers& b, hipStream_t s) {
     const int nblocks = (c.A + POST_BLOCK - 1) / POST_BLOCK;

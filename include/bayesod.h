@@ -93,10 +93,14 @@ typedef struct {
     int32_t pipeline_overlap;    /* 1: bod_infer_async overlaps the memory-bound front of batch i+1 (stem, backbone, FPN) with the
                                     MFMA-bound back of batch i (fan-out layer, towers, posterior) on two CU-partitioned streams
                                     (hipExtStreamCreateWithCUMask: the front owns the last 4 CU slots of every XCD, 32 of 256 CUs,
-                                    the back the other 224; the pyramid is double-buffered).  Results are bit-identical to the
-                                    serial pipeline; every other entry point keeps the whole chip.  Inference handles only.
-                                    Images are independent (run_inference.py:137-149), so the order of two batches' kernels
-                                    is free.  0 (default): one stream.                                           */
+                                    the back the other 224; the pyramid is double-buffered).  EXPERIMENTAL, measured 8.5 % SLOWER
+                                    than one stream (the chip is power-bound: DESIGN.md 8.3) and NOT reproducible bit for bit:
+                                    kernels of this library running beside each other can miscompute a 16-lane row of a wave
+                                    (about one detection in 10^3 frames moved by up to 0.4 px in the probes; cause
+                                    not found), and this mode runs the front of call i+1 beside the back of call i by design.
+                                    bod_create refuses it unless BOD_OVERLAP_EXPERIMENTAL=1 is set in the environment.  Every
+                                    other entry point keeps the whole chip.  Inference handles only.  0 (default): one stream:
+                                    no kernel of the library runs beside another.                                 */
     int32_t reserved[2];
 } bod_config;
 
@@ -358,16 +362,19 @@ bod_status bod_profile_end(bod_handle h, double* head_conv_ms, int64_t* head_con
  *
  * bod_gather_detections packs the records of `slot` (the ticket of bod_infer_async; pass -1 after a synchronous bod_infer) on the
  * device and issues ONE RCCL gather -- ncclGather(send, recv, batch*K*W, ncclFloat32, root, comm, stream).  For a ticket
- * (slot >= 0) both run on the handle's side stream, behind the slot's event (its cluster-and-fuse kernels and record copies), so the
- * gather overlaps the next batch's convolutions, and the slot's event is re-recorded behind them: bod_collect(slot) and the next
- * bod_infer_async that reuses the slot wait for the send.  For slot == -1 both run on the handle's MAIN stream, behind the
+ * (slot >= 0) both run on the stream that finished the slot's records -- the handle's MAIN stream -- behind its cluster-and-fuse
+ * kernels and record copies, and the slot's event is re-recorded behind them: bod_collect(slot) and the next bod_infer_async that
+ * reuses the slot wait for the send.  If the next bod_infer_async has already been enqueued, pack and gather run BEHIND its kernels
+ * (one step of latency): since round 6 no kernel of this library runs beside another one by default (until then the
+ * two ran on a side stream underneath the next batch's convolutions, where a kernel of this library can miscompute a 16-lane row;
+ * BOD_SIDE_STREAM=1 restores that placement for reproduction runs).  For slot == -1 both run on the handle's MAIN stream, behind the
  * synchronous bod_infer's own kernels: every later call on the handle (the next bod_infer, bod_synchronize, ...) is ordered behind
  * the pack and the gather by stream order.
  * `nccl_comm` is the caller's ncclComm_t (created with ncclCommInitRank on this handle's device; librccl.so is opened at run time,
  * the library does not link it); `world` / `rank` are the communicator's size and this process' rank.  nccl_comm == NULL is the
  * single-process form (world must be 1: the block is "gathered" by a device copy).
- * On `root`, `gathered_host` (may be NULL) receives [world][batch][K][W] floats, in rank order, after the stream has been waited
- * for; *gathered_device (may be NULL) is set to the device copy, valid until the next gather: its contents are complete once
+ * On `root`, `gathered_host` (may be NULL) receives [world][batch][K][W] floats, in rank order, after the copy has been waited
+ * for (an event behind it, not the whole stream); *gathered_device (may be NULL) is set to the device copy, valid until the next gather: its contents are complete once
  * bod_collect(slot) has returned (slot >= 0) or after bod_synchronize (slot == -1) -- unless gathered_host was given, in which case
  * the call itself has waited.  Other ranks pass NULL for both (their call returns once the send is enqueued).  A pending slot is
  * NOT released: bod_collect still may. */
