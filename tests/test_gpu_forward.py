@@ -33,13 +33,36 @@ def _setup(hw, batch, n):
     return w, frames, eng
 
 
-def _oracles(w, frame, n, seed, image_id, P):
+_ORACLE_CACHE = {}
+
+
+def _oracle_key(w, frame, n, seed, image_id, P, depth):
+    import hashlib
+    probe = w["conv1"]
+    while isinstance(probe, (dict, tuple, list)):          # the first array of the first layer: enough to tell two weight sets apart
+        probe = next(iter(probe.values())) if isinstance(probe, dict) else probe[0]
+    wsum = float(np.asarray(probe, np.float64).sum())
+    return (hashlib.sha1(np.ascontiguousarray(frame).tobytes()).hexdigest(), frame.shape, n, seed, image_id, P, depth, len(w), wsum)
+
+
+def _oracle_f64(w, frame, n, seed, image_id, P, **kw):
+    """The float64 literal forward of one frame -- computed once per (weights, frame, masks) in the session: the precision modes of a
+    parametrized test compare against the same oracle run (suite time: the NumPy forward of a 192 x 624 frame takes seconds)."""
     from oracle import network, philox
-    km = (lambda s, lid: philox.dropout_keep_mask(seed, image_id, s, lid, P, 256, 0.3)) if n > 1 else None
-    emu = network.retinanet_forward(w, frame[None], n, 8, mode="bf16", keep_masks=km, return_pyramid=True)
-    f64 = network.retinanet_forward(w, frame[None], n, 8, mode="literal", dtype=np.float64, keep_masks=km,
-                                    return_pyramid=True)
-    return emu, f64
+    key = ("f64",) + _oracle_key(w, frame, n, seed, image_id, P, kw.get("backbone_depth", 50))
+    if key not in _ORACLE_CACHE:
+        km = (lambda s, lid: philox.dropout_keep_mask(seed, image_id, s, lid, P, 256, 0.3)) if n > 1 else None
+        _ORACLE_CACHE[key] = network.retinanet_forward(w, frame[None], n, 8, mode="literal", dtype=np.float64, keep_masks=km, return_pyramid=True, **kw)
+    return _ORACLE_CACHE[key]
+
+
+def _oracles(w, frame, n, seed, image_id, P, emulation=True):
+    from oracle import network, philox
+    emu = None
+    if emulation:
+        km = (lambda s, lid: philox.dropout_keep_mask(seed, image_id, s, lid, P, 256, 0.3)) if n > 1 else None
+        emu = network.retinanet_forward(w, frame[None], n, 8, mode="bf16", keep_masks=km, return_pyramid=True)
+    return emu, _oracle_f64(w, frame, n, seed, image_id, P)
 
 
 @pytest.mark.parametrize("hw,batch,n", [((128, 128), 2, 3), ((96, 160), 1, 2), ((128, 192), 1, 1)])
@@ -171,7 +194,7 @@ def test_fp32_mode_end_to_end(hw, batch, n, depth, precision):
     pyr = [eng.get_pyramid(l) for l in range(5)]
     worst = 0.0
     for b in range(batch):
-        _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P)
+        _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P, emulation=False)
         items = [("P%d" % (l + 3), pyr[l][b], f64["_pyramid"][l][0]) for l in range(5)]
         items += [("cls", cls[b], f64["anchors_class_predictions"]), ("box", box[b], f64["anchors_box_predictions"]),
                   ("cov", cov[b], f64["_covar_params"])]
@@ -204,7 +227,7 @@ def test_f16mx4_with_the_box_tower_on_hx_rows(monkeypatch):
         cls, box, cov = eng.get_raw()
         worst = {"cls": 0.0, "box": 0.0, "cov": 0.0}
         for b in range(batch):
-            _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P)
+            _, f64 = _oracles(w, frames[b], n, seed, first + b, eng.P, emulation=False)
             for name, got, t in (("cls", cls[b], f64["anchors_class_predictions"]), ("box", box[b], f64["anchors_box_predictions"]), ("cov", cov[b], f64["_covar_params"])):
                 worst[name] = max(worst[name], float(np.max(np.abs(got - t) / (np.abs(t) + _rms(t)))))
         errs[mixed] = worst
@@ -229,7 +252,7 @@ def test_non_square_and_odd_pyramids(hw, precision):
     eng.load_weights(w)
     eng.forward(frames, seed=seed, first_image_id=0)
     cls, box, cov = eng.get_raw()
-    _, f64 = _oracles(w, frames[0], n, seed, 0, eng.P)
+    _, f64 = _oracles(w, frames[0], n, seed, 0, eng.P, emulation=False)
     assert [tuple(p.shape[1:3]) for p in f64["_pyramid"]] == eng.levels
     for l in range(5):
         t = f64["_pyramid"][l][0]

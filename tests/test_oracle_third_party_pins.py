@@ -94,3 +94,89 @@ def test_half_pixel_nearest_against_torch_nearest_exact(ih, iw, oh, ow):
     got = network.resize_nearest(x, oh, ow)
     ref = F.interpolate(torch.from_numpy(x).permute(0, 3, 1, 2), size=(oh, ow), mode="nearest-exact").permute(0, 2, 3, 1).numpy()
     assert np.array_equal(got, ref)
+
+
+# ---- round 6: rules and examples PUBLISHED IN THE LIBRARIES' OWN DOCUMENTATION (TensorFlow / Keras / TensorFlow Probability API pages),
+# restated here verbatim and checked against the oracle.  They pin what a docstring pins -- a rule and one example -- not an execution.
+
+def _tfp_fill_triangular(x, upper=False):
+    """tfp.math.fill_triangular as its API page gives it: for the lower triangle, concatenate x[n:] with reverse(x), reshape to n x n,
+    keep the lower band (upper: concatenate x with reverse(x[n:]), keep the upper band)."""
+    x = np.asarray(x)
+    m = x.shape[-1]
+    n = int(np.sqrt(0.25 + 2.0 * m) - 0.5)
+    assert n * (n + 1) // 2 == m
+    cat = np.concatenate([x, x[n:][::-1]]) if upper else np.concatenate([x[n:], x[::-1]])
+    mat = cat.reshape(n, n)
+    return np.triu(mat) if upper else np.tril(mat)
+
+
+def test_fill_triangular_documented_example_and_the_oracles_4x4():
+    """The API page's example -- fill_triangular([1, 2, 3, 4, 5, 6]) = [[4, 0, 0], [6, 5, 0], [3, 2, 1]], upper=True: [[1, 2, 3], [0, 5, 6],
+    [0, 0, 4]] -- reproduces with the documented algorithm; the same algorithm at n = 4 is oracle/network.py's fill_triangular_4
+    (retinanet_model.py:110,144) for random vectors, and the host mirror's."""
+    assert _tfp_fill_triangular([1, 2, 3, 4, 5, 6]).tolist() == [[4, 0, 0], [6, 5, 0], [3, 2, 1]]
+    assert _tfp_fill_triangular([1, 2, 3, 4, 5, 6], upper=True).tolist() == [[1, 2, 3], [0, 5, 6], [0, 0, 4]]
+    from bayes_od_rc_amd.model import fill_triangular_4 as host_fill
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        x = rng.normal(0, 1, 10)
+        want = _tfp_fill_triangular(x)
+        assert np.array_equal(network.fill_triangular_4(x[None])[0], want) and np.array_equal(np.asarray(host_fill(x[None]))[0], want)
+
+
+@pytest.mark.parametrize("rate,kept_value", [(0.5, 2.0), (0.8, 5.0), (0.3, 1.0 / 0.7)])
+def test_dropout_scaling_rule_of_tf_nn_dropout(rate, kept_value):
+    """tf.nn.dropout's API page: "With probability `rate` elements of x are set to 0.  The remaining elements are scaled up by
+    1.0 / (1 - rate), so that the expected value is preserved", with the examples rate 0.5 -> kept ones become 2, rate 0.8 -> 5
+    (multitask_headers.py:104-116 calls keras Dropout(0.3)(x, training=True) = this op).  The oracle's head tower on a ones tensor."""
+    from oracle import philox
+
+    class Ones(object):             # a numerics object whose convs return ones: the tower's output IS the dropout pattern
+        def conv(self, x, name, padding="same", relu=False, store=True):
+            return np.ones(x.shape[:3] + (256 if name[-1].isdigit() else 36,), np.float32)
+
+        def store(self, x):
+            return x
+    P, n = 64, 3
+    pyr = [np.ones((1, 8, 8, 256), np.float32)]
+    masks = lambda s, lid: philox.dropout_keep_mask(7, 0, s, lid, P, 256, rate)
+    seen = {}
+
+    class Spy(Ones):
+        def store(self, x):
+            seen.setdefault("x", x.copy())
+            return x
+    network.head_tower(Spy(), pyr, "cls", n, masks, rate, 4)
+    vals = np.unique(seen["x"])
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - np.float32(kept_value)) <= 1e-6 * kept_value
+    dropped = float((seen["x"] == 0).mean())
+    assert abs(dropped - rate) < 0.01                                     # "with probability rate"
+    assert abs(float(seen["x"].mean()) - 1.0) < 0.02                      # "so that the expected value is preserved"
+
+
+def test_keras_batchnormalization_documented_defaults_and_inference_formula():
+    """tf.keras.layers.BatchNormalization(axis=-1, momentum=0.99, epsilon=0.001, ...) -- the reference passes no epsilon
+    (feature_extractor.py:30) -- and the page's inference rule gamma * (batch - moving_mean) / sqrt(moving_var + epsilon) + beta."""
+    assert network.BN_EPS == 1e-3
+    rng = np.random.default_rng(1)
+    x = rng.normal(0, 1, (2, 3, 3, 5))
+    bn = {"gamma": rng.uniform(0.5, 1.5, 5), "beta": rng.normal(0, 0.1, 5), "mean": rng.normal(0, 0.1, 5), "var": rng.uniform(0.5, 1.5, 5)}
+    want = bn["gamma"] * (x - bn["mean"]) / np.sqrt(bn["var"] + 0.001) + bn["beta"]
+    assert np.allclose(network.batchnorm_eval(x, bn), want, rtol=1e-12, atol=1e-12)
+    # and the folded form the device uses (App. A.3) is the same function
+    w = rng.normal(0, 1, (1, 1, 5, 5))
+    conv = {"kernel": w, "bias": rng.normal(0, 1, 5)}
+    y = network.batchnorm_eval(network.conv2d(x, w, conv["bias"], 1, "valid"), bn)
+    wf, bf = network.fold_bn(conv, bn)
+    assert np.allclose(network.conv2d(x, wf.astype(np.float64), bf.astype(np.float64), 1, "valid"), y, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,k,s", [(512, 3, 1), (512, 3, 2), (16, 3, 2), (8, 3, 2), (23, 3, 2), (39, 3, 2), (45, 3, 1), (512, 7, 2), (7, 3, 2), (2, 3, 2)])
+def test_same_padding_rule_of_the_tf_nn_guide(n, k, s):
+    """tf.nn's "Notes on padding": out = ceil(in / stride); pad_along = max((out - 1) * stride + filter - in, 0); pad_before =
+    pad_along // 2; pad_after = pad_along - pad_before (the odd pixel goes to the bottom / right) -- oracle/network.py's _same_pads,
+    which every SAME convolution of the FPN and the heads goes through (feature_decoder.py:140-143)."""
+    out = -(-n // s)
+    pad = max((out - 1) * s + k - n, 0)
+    assert tuple(network._same_pads(n, k, s)) == (pad // 2, pad - pad // 2, out)

@@ -1,0 +1,136 @@
+// WHICH instruction class of a victim wave is miscomputed in its last 16-lane row while a convolution kernel of
+// the library shares the compute unit?  Micro-victims, one instruction class each: every thread computes the same chain TWICE (the
+// compiler is kept from merging the two copies by opaque register barriers) and logs a difference with HW_REG_HW_ID / HW_REG_XCC_ID.
+// Built by tests/tools/row3_probe.py (hipcc -O3 --offload-arch=gfx950 -shared); not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+struct Rec { uint32_t hw_id, xcc_id, mode, lane, block, iter; float first, second; };
+__device__ unsigned int g_count;
+__device__ unsigned long long g_waves;
+__device__ Rec g_recs[4096];
+
+__device__ __forceinline__ void opaque(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void report(int mode, int it, float a, float b) {
+    if (__float_as_uint(a) == __float_as_uint(b)) return;
+    const unsigned int k = atomicAdd(&g_count, 1u);
+    if (k < 4096u) {
+        Rec r;
+        r.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4); r.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        r.mode = mode; r.lane = threadIdx.x & 63; r.block = blockIdx.x; r.iter = it; r.first = a; r.second = b;
+        g_recs[k] = r;
+    }
+}
+
+// the chains: x is a per-lane seed in (1, 2)
+__device__ __forceinline__ float chain_fma(float x) {
+    float y = x;
+#pragma unroll 16
+    for (int i = 0; i < 256; ++i) y = fmaf(y, 0.99993f, x * 7.0e-5f);
+    return y;
+}
+__device__ __forceinline__ float chain_div(float x) {          // IEEE fp32 division: v_div_scale / v_rcp / v_div_fmas / v_div_fixup + denormal-mode toggles
+    float y = x;
+#pragma unroll 4
+    for (int i = 0; i < 64; ++i) y = (y + 3.0f) / (x + 1.0f + 1e-3f * y);
+    return y;
+}
+__device__ __forceinline__ float chain_trans(float x) {        // the transcendental unit: exp, sqrt, rcp, rsq, log
+    float y = x;
+#pragma unroll 4
+    for (int i = 0; i < 64; ++i) y = __expf(-y) + sqrtf(y + 1.0f) + __frcp_rn(y + 2.0f) + __logf(y + 1.5f) * 0.1f;
+    return y;
+}
+__device__ __forceinline__ float chain_int(float x) {          // integer multiplies / shifts / bit ops (quarter-rate v_mul_lo_u32)
+    uint32_t u = __float_as_uint(x);
+#pragma unroll 16
+    for (int i = 0; i < 256; ++i) u = u * 1664525u + (u >> 7) + 1013904223u;
+    return __uint_as_float((u >> 9) | 0x3F800000u);
+}
+__device__ __forceinline__ float chain_f64(float x) {
+    double y = x;
+#pragma unroll 8
+    for (int i = 0; i < 96; ++i) y = fma(y, 0.99993, (double)x * 7.0e-5);
+    return (float)y;
+}
+__device__ __forceinline__ float chain_xlane(float x) {        // cross-lane: DPP / ds_bpermute / readlane paths
+    float y = x;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        y += __shfl_xor(y, 1) * 1e-3f;
+        y += __shfl_xor(y, 16) * 1e-3f;
+        y += __shfl(y, (threadIdx.x + 17) & 63) * 1e-3f;
+    }
+    return y;
+}
+__device__ __noinline__ float call_fma(float x) { return chain_fma(x); }                       // the same chain behind a function call
+__device__ __noinline__ void call_fma_scratch(float x, float* __restrict__ out8) {             // ... writing its results through private memory
+    float y = x;
+    for (int k = 0; k < 8; ++k) { y = chain_fma(y); out8[k] = y; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ seeds, float* __restrict__ sink, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float x = seeds[t & 65535];
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_waves, (unsigned long long)iters);
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        float xa = x, xb = x;
+        opaque(xa); opaque(xb);
+        float a, b;
+        if constexpr (MODE == 0) { a = chain_fma(xa); b = chain_fma(xb); }
+        else if constexpr (MODE == 1) { a = chain_div(xa); b = chain_div(xb); }
+        else if constexpr (MODE == 2) { a = chain_trans(xa); b = chain_trans(xb); }
+        else if constexpr (MODE == 3) { a = chain_int(xa); b = chain_int(xb); }
+        else if constexpr (MODE == 4) { a = chain_f64(xa); b = chain_f64(xb); }
+        else if constexpr (MODE == 5) { a = chain_xlane(xa); b = chain_xlane(xb); }
+        else if constexpr (MODE == 6) { a = call_fma(xa); b = call_fma(xb); }
+        else if constexpr (MODE == 7) {
+            float r1[8], r2[8];
+            call_fma_scratch(xa, r1); call_fma_scratch(xb, r2);
+            a = r1[7] + r1[3]; b = r2[7] + r2[3];
+        } else {                                   // 8: memory only -- the same gathered global reads twice (volatile: two loads)
+            const volatile float* s = seeds;
+            a = 0.f; b = 0.f;
+            for (int k = 0; k < 16; ++k) { const int i = (t * 7 + k * 4099 + it * 13) & 65535; a += s[i]; }
+            for (int k = 0; k < 16; ++k) { const int i = (t * 7 + k * 4099 + it * 13) & 65535; b += s[i]; }
+        }
+        report(MODE, it, a, b);
+        acc += a;
+        x = 1.0f + (a - floorf(a)) * 0.5f + 1e-3f * (float)(it & 7);
+    }
+    if (acc == 12345.678f) sink[t & 65535] = acc;          // (keeps the chains alive)
+}
+
+static float* g_seeds = nullptr; static float* g_sink = nullptr; static hipStream_t g_stream = nullptr;
+extern "C" int victim_run(int mode, int blocks, int iters, int cu_lo, int cu_hi) {
+    if (!g_seeds) {
+        if (hipMalloc(&g_seeds, 65536 * 4) != hipSuccess || hipMalloc(&g_sink, 65536 * 4) != hipSuccess) return 1;
+        static float h[65536];
+        uint32_t u = 12345u;
+        for (int i = 0; i < 65536; ++i) { u = u * 1664525u + 1013904223u; h[i] = 1.0f + (float)(u >> 8) / 16777216.0f; }
+        if (hipMemcpy(g_seeds, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    }
+    if (!g_stream) {
+        if (cu_hi > cu_lo) {            // CU slots [lo, hi) of every XCD (mask bit i = slot i / 8 of XCD i % 8: tests/tools/cu_mask_probe.hip)
+            uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = cu_lo; s < cu_hi; ++s) for (int x = 0; x < 8; ++x) { const int bit = s * 8 + x; m[bit >> 5] |= 1u << (bit & 31); }
+            if (hipExtStreamCreateWithCUMask(&g_stream, 8, m) != hipSuccess) return 2;
+        } else if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
+    }
+#define LAUNCH(M) case M: hipLaunchKernelGGL(victim_kernel<M>, dim3(blocks), dim3(256), 0, g_stream, g_seeds, g_sink, iters); break;
+    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) default: return 3; }
+    if (hipGetLastError() != hipSuccess) return 4;
+    return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : 5;
+}
+extern "C" int victim_read(unsigned int* count, unsigned long long* waves, void* recs, int max) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_count), 4) != hipSuccess || hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_waves), 8) != hipSuccess) return 1;
+    const unsigned int m = n < (unsigned)max ? (n < 4096u ? n : 4096u) : (unsigned)max;
+    if (m && hipMemcpyFromSymbol(recs, HIP_SYMBOL(g_recs), (size_t)m * sizeof(Rec)) != hipSuccess) return 1;
+    const unsigned int z = 0; const unsigned long long z8 = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_count), &z, 4) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_waves), &z8, 8) != hipSuccess) return 1;
+    *count = n;
+    return 0;
+}
