@@ -25,7 +25,7 @@
 struct Mat4 { float m[4][4]; };
 
 // inverse of a symmetric positive definite 4x4 through Cholesky A = G G^T, inv = G^-T G^-1
-__device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) {
+__device__ __forceinline__ Mat4 inv_spd4_once(const Mat4& a) {
     float g[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -76,6 +76,41 @@ __device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) {
             r.m[j][i] = s;
         }
     return r;
+}
+
+// DESIGN.md 8.4 (round 6): while a convolution kernel of this library shares the compute unit, THIS computation -- the two Cholesky
+// inverses of the prior fusion and nothing in front of them -- can come out wrong in lanes 48-63 of a wave (transiently: the same
+// instructions on the same inputs give the right result the next time; never without such company; mechanism not known, probes in
+// tests/tools/selfcheck_probe.py).  No entry point runs kernels beside each other by default, but two handles or two processes on one
+// GPU do: the inverse is therefore computed until two consecutive evaluations agree bit for bit (two in the normal case; the second
+// evaluation costs 0.1 ms per 512 frames).  Same arithmetic, same result as a single evaluation.  BOD_NO_INV_GUARD: compiled out (A/B).
+__device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) {
+#if defined(BOD_NO_INV_GUARD)
+    return inv_spd4_once(a);
+#else
+    auto fresh = [&]() {              // the input behind an opaque barrier: the compiler must not merge two evaluations into one
+        Mat4 b = a;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(b.m[i][j]));
+#endif
+        return b;
+    };
+    Mat4 r = inv_spd4_once(fresh());
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const Mat4 r2 = inv_spd4_once(fresh());
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) same = same && (__float_as_uint(r.m[i][j]) == __float_as_uint(r2.m[i][j]));
+        if (same) break;
+        r = r2;
+    }
+    return r;
+#endif
 }
 
 __device__ __forceinline__ void decode_box(const float4 anc, const float4 t, float o[4]) {
@@ -219,7 +254,14 @@ __global__ __launch_bounds__(POST_BLOCK) void post_compact_kernel(PostCfg c, Pos
 // results are compared bit for bit; a difference is logged with where the wave ran (HW_REG_HW_ID: SIMD / CU / SE, HW_REG_XCC_ID).
 #if defined(BOD_POST_SELFCHECK)
 #define POST_FUSE_INLINE __noinline__
+#if BOD_POST_SELFCHECK == 2
+// variant 2: the slot's inputs are loaded ONCE by the kernel and handed to the out-of-line copy in registers; the copy neither loads nor
+// stores (pure VALU between call and return) -- does the difference between two computations survive without memory operations?
+struct FuseIn { float4 anc, ab[4]; float2 cv[5]; float dc[8]; };
+#define POST_FUSE_OUT , float* __restrict__ out20, const FuseIn& fin
+#else
 #define POST_FUSE_OUT , float* __restrict__ out20
+#endif
 struct SelfcheckRec { uint32_t hw_id, xcc_id, image, slot, lane, elem; float first, second; };
 __device__ unsigned int g_selfcheck_count;
 __device__ unsigned long long g_selfcheck_waves;          // waves that ran the check (the rate's denominator)
@@ -231,9 +273,14 @@ __device__ SelfcheckRec g_selfcheck_recs[4096];
 template <int C>
 __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBuffers& pb, const int b, const int slot POST_FUSE_OUT) {
     const size_t o = (size_t)b * c.A + slot;
+#if defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2
+    const int a = 0; (void)a; (void)o;
+    const float4 anc = fin.anc;
+#else
     const int a = pb.anchor_index[o];
 
     const float4 anc = reinterpret_cast<const float4*>(pb.anchors)[a];
+#endif
     // ---- epistemic: two-pass mean / unbiased covariance over MC samples (:220-244)
     float mu[4] = {0.f, 0.f, 0.f, 0.f};
     Mat4 epi;
@@ -243,7 +290,11 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
         for (int j = 0; j < 4; ++j) epi.m[i][j] = 0.f;
     const int n_raw = c.aggregated ? 0 : c.N;
     if (c.aggregated) {                     // Welford mean and co-moment sums from the head epilogue (agg_reduce_box)
+#if defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2
+        const float4* ab = fin.ab;
+#else
         const float4* ab = reinterpret_cast<const float4*>(pb.agg_box) + ((size_t)b * c.A + a) * 4;
+#endif
         const float4 m = ab[0], q0 = ab[1], q1 = ab[2], q2 = ab[3];
         mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w;
         epi.m[0][0] = q0.x; epi.m[1][0] = q0.y; epi.m[1][1] = q0.z; epi.m[2][0] = q0.w;
@@ -278,6 +329,10 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
 #pragma unroll
         for (int j = 0; j <= i; ++j) { epi.m[i][j] = epi.m[i][j] / nm1; epi.m[j][i] = epi.m[i][j]; }
 
+#if defined(BOD_POST_SELFCHECK_PART) && BOD_POST_SELFCHECK_PART == 1          // (bisection of the self-check: stop behind the epistemic block)
+    for (int i = 0; i < 4; ++i) { out20[i] = mu[i]; for (int j = 0; j < 4; ++j) out20[4 + i * 4 + j] = epi.m[i][j]; }
+    return;
+#endif
     // ---- aleatoric (:62-84): mean of the raw lower-triangular params, D = exp(diag), L = inv(unit lower)
     Mat4 al;
 #pragma unroll
@@ -289,7 +344,11 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
 #pragma unroll
         for (int q = 0; q < 10; ++q) x[q] = 0.f;
         if (c.aggregated) {                 // sum_n of the raw parameters from the head epilogue (agg_reduce_cov)
+#if defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2
+            const float* p = reinterpret_cast<const float*>(fin.cv);
+#else
             const float* p = pb.agg_cov + ((size_t)b * c.A + a) * 10;
+#endif
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const float2 t = reinterpret_cast<const float2*>(p)[q];
@@ -332,6 +391,10 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
             al.m[0][0] = d0; al.m[1][1] = d1; al.m[2][2] = d2; al.m[3][3] = d3;
         }
     }
+#if defined(BOD_POST_SELFCHECK_PART) && BOD_POST_SELFCHECK_PART == 2          // ... behind the aleatoric block (exp, unit-lower inverse, L D L^T)
+    for (int i = 0; i < 4; ++i) { out20[i] = mu[i]; for (int j = 0; j < 4; ++j) out20[4 + i * 4 + j] = al.m[i][j]; }
+    return;
+#endif
     Mat4 lik;                                                     // (:86-87)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -339,7 +402,11 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
         for (int j = 0; j < 4; ++j) lik.m[i][j] = (10.0f * al.m[i][j] + 1.0f * epi.m[i][j]) / 11.0f;
 
     // ---- Dirichlet posterior (:90-97)
+#if defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2
+    const float* dc = fin.dc;
+#else
     const float* dc = pb.d_counts + ((size_t)b * c.A + a) * C;
+#endif
     float pc[C];
     float csum = 0.f;
     const float alpha = c.dirichlet ? 1.0f / (float)C : 0.f;
@@ -349,11 +416,17 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const float s = pc[j] / csum;
+#if !(defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2)
         pb.counts[o * C + j] = pc[j];
         pb.score[o * C + j] = s;
+#endif
         best = j == 0 ? s : fmaxf(best, s);
     }
 
+#if defined(BOD_POST_SELFCHECK_PART) && BOD_POST_SELFCHECK_PART == 3          // ... behind the likelihood mix and the Dirichlet scores
+    for (int i = 0; i < 4; ++i) { out20[i] = mu[i] + best; for (int j = 0; j < 4; ++j) out20[4 + i * 4 + j] = lik.m[i][j]; }
+    return;
+#endif
     // ---- Gaussian prior fusion (:100-145): prior mean = the anchor, prior cov = iso_var * I
     Mat4 pcov;
     float pm[4];
@@ -394,12 +467,14 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
             for (int j = 0; j < 4; ++j) pcov.m[i][j] = sc[i] * pcov.m[i][j] * sc[j];
         }
     }
+#if !(defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         pb.means[o * 4 + i] = pm[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pb.covs[o * 16 + i * 4 + j] = pcov.m[i][j];
     }
+#endif
 #if defined(BOD_POST_SELFCHECK)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -408,12 +483,17 @@ __device__ POST_FUSE_INLINE void post_fuse_anchor(const PostCfg& c, const PostBu
         for (int j = 0; j < 4; ++j) out20[4 + i * 4 + j] = pcov.m[i][j];
     }
 #endif
+#if defined(BOD_POST_SELFCHECK) && BOD_POST_SELFCHECK == 2
+    out20[0] += best * 0.f;
+    return;
+#else
     pb.ranking[o] = best;                                         // ranking_method 'score' (:202)
     // box_utils.vuhw_to_vuvu (:5-23)
     pb.corners[o * 4 + 0] = pm[0] - pm[2] / 2.0f;
     pb.corners[o * 4 + 1] = pm[1] - pm[3] / 2.0f;
     pb.corners[o * 4 + 2] = pm[0] + pm[2] / 2.0f;
     pb.corners[o * 4 + 3] = pm[1] + pm[3] / 2.0f;
+#endif
 }
 
 // a few blocks per image walk its compact list (POST_FUSE_BLOCKS x 256 slots per pass: one pass up to 2 048 kept anchors)
@@ -425,8 +505,23 @@ __global__ __launch_bounds__(POST_BLOCK) void post_fuse_kernel(PostCfg c, PostBu
 #if defined(BOD_POST_SELFCHECK)
     for (int slot = blockIdx.x * POST_BLOCK + threadIdx.x; slot < m; slot += gridDim.x * POST_BLOCK) {
         float r1[20], r2[20];
+#if BOD_POST_SELFCHECK == 2
+        FuseIn fin;
+        {
+            const size_t o = (size_t)b * c.A + slot;
+            const int a = pb.anchor_index[o];
+            fin.anc = reinterpret_cast<const float4*>(pb.anchors)[a];
+            for (int q = 0; q < 4; ++q) fin.ab[q] = (reinterpret_cast<const float4*>(pb.agg_box) + ((size_t)b * c.A + a) * 4)[q];
+            for (int q = 0; q < 5; ++q) fin.cv[q] = reinterpret_cast<const float2*>(pb.agg_cov + ((size_t)b * c.A + a) * 10)[q];
+            for (int q = 0; q < 8; ++q) fin.dc[q] = q < C ? pb.d_counts[((size_t)b * c.A + a) * C + q] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        post_fuse_anchor<C>(c, pb, b, slot, r1, fin);
+        post_fuse_anchor<C>(c, pb, b, slot, r2, fin);
+#else
         post_fuse_anchor<C>(c, pb, b, slot, r1);
         post_fuse_anchor<C>(c, pb, b, slot, r2);
+#endif
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_selfcheck_waves, 1ull);
         int bad = -1;
         for (int i = 19; i >= 0; --i) if (__float_as_uint(r1[i]) != __float_as_uint(r2[i])) bad = i;

@@ -18,13 +18,17 @@ lib = C.CDLL(so)
 lib.victim_run.argtypes = [C.c_int] * 5
 lib.victim_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_void_p, C.c_int]
 NAMES = {0: "fma chain", 1: "IEEE division chain", 2: "transcendental chain", 3: "integer chain", 4: "fp64 chain", 5: "cross-lane chain",
-         6: "fma chain behind a call", 7: "fma chain behind a call, results through scratch", 8: "global loads twice"}
+         6: "fma chain behind a call", 7: "fma chain behind a call, results through scratch", 8: "global loads twice (4 bytes per lane)",
+         9: "global_load_dwordx4 twice", 10: "global_load_dwordx2 twice", 11: "scratch array round trip twice"}
 company = os.environ.get("COMPANY", "forward")
-modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11").split(",")]
 blocks, iters = int(os.environ.get("BLOCKS", "2048")), int(os.environ.get("ITERS", "40"))
 hw, batch = (512, 512), int(os.environ.get("B", "64"))
 b = None
-if company != "none":
+lib.company_run.argtypes = [C.c_int] * 3
+if company.startswith("dma"):          # COMPANY=dma:0 (LDS-DMA only) / dma:1 (the same bytes without LDS-DMA): row3_victims.hip's synthetic company
+    lib.victim_run(0, 1, 1, 0, 0)      # (allocates the seeds)
+elif company != "none":
     if os.environ.get("COMPANY_SLOTS"):
         os.environ["BOD_CU_MASK_SLOTS"] = os.environ["COMPANY_SLOTS"]
     if company.startswith("ops:"):
@@ -39,10 +43,14 @@ n_company = [0]
 
 def noise():
     while not stop:
-        b.forward(None, seed=1, first_image_id=0); n_company[0] += 1
+        if company.startswith("dma"):
+            assert lib.company_run(int(company.split(":")[1]), int(os.environ.get("COMPANY_BLOCKS", "512")), 20000) == 0
+        else:
+            b.forward(None, seed=1, first_image_id=0)
+        n_company[0] += 1
 
 
-t = threading.Thread(target=noise if b is not None else (lambda: None)); t.start()
+t = threading.Thread(target=noise if (b is not None or company.startswith("dma")) else (lambda: None)); t.start()
 cnt, waves = C.c_uint(0), C.c_ulonglong(0)
 recs = np.zeros((4096, 8), np.uint32)
 try:

@@ -90,11 +90,43 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ s
             float r1[8], r2[8];
             call_fma_scratch(xa, r1); call_fma_scratch(xb, r2);
             a = r1[7] + r1[3]; b = r2[7] + r2[3];
-        } else {                                   // 8: memory only -- the same gathered global reads twice (volatile: two loads)
+        } else if constexpr (MODE == 8) {          // memory only -- the same gathered global reads twice (volatile: two loads)
             const volatile float* s = seeds;
             a = 0.f; b = 0.f;
             for (int k = 0; k < 16; ++k) { const int i = (t * 7 + k * 4099 + it * 13) & 65535; a += s[i]; }
             for (int k = 0; k < 16; ++k) { const int i = (t * 7 + k * 4099 + it * 13) & 65535; b += s[i]; }
+        } else if constexpr (MODE == 9 || MODE == 10) {   // 16-byte (9) / 8-byte (10) loads per lane, twice: global_load_dwordx4 / dwordx2
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                float acc2 = 0.f;
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) {
+                    const int i = ((t * 5 + k * 4099 + it * 13) & 16383) * 4;
+                    if constexpr (MODE == 9) {
+                        float4 v;
+                        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(seeds + i) : "memory");
+                        acc2 += v.x + 2.f * v.y + 3.f * v.z + 5.f * v.w;
+                    } else {
+                        float2 v;
+                        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(seeds + i) : "memory");
+                        acc2 += v.x + 2.f * v.y;
+                    }
+                }
+                if (pass == 0) a = acc2; else b = acc2;
+            }
+        } else {                                   // 11: private memory round trip (scratch_store / scratch_load of 16-byte pieces), twice
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                float arr[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) arr[k] = x * (float)(k + 1) + (float)it;
+                float acc2 = 0.f;
+#pragma unroll 1
+                for (int k = 0; k < 32; ++k) acc2 += arr[(k * 7 + (t & 31) + it) & 31] * (float)(k + 1);        // (dynamic index: the array lives in scratch)
+                if (pass == 0) a = acc2; else b = acc2;
+            }
         }
         report(MODE, it, a, b);
         acc += a;
@@ -120,9 +152,40 @@ extern "C" int victim_run(int mode, int blocks, int iters, int cu_lo, int cu_hi)
         } else if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
     }
 #define LAUNCH(M) case M: hipLaunchKernelGGL(victim_kernel<M>, dim3(blocks), dim3(256), 0, g_stream, g_seeds, g_sink, iters); break;
-    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) default: return 3; }
+    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) default: return 3; }
     if (hipGetLastError() != hipSuccess) return 4;
     return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : 5;
+}
+// ---- a synthetic COMPANY: workgroups that do nothing but LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction) and read the
+// landed bytes back, for `us` microseconds; mode 1: the same bytes through plain global_load_dwordx4 + ds_write (no LDS-DMA)
+__global__ __launch_bounds__(256) void dma_company_kernel(const float* __restrict__ src, float* __restrict__ sink, int mode, long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x, wave = tid >> 6;
+    float acc = 0.f;
+    unsigned int it = blockIdx.x * 977u;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        for (int k = 0; k < 8; ++k) {
+            const float* g = src + (((it + k) * 256u + tid) & 16383u) * 4;
+            if (mode == 0) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                             (__attribute__((address_space(3))) void*)(smem + (k * 4 + wave) * 1024), 16, 0, 0);
+            else *reinterpret_cast<float4*>(smem + (k * 256 + tid) * 16) = *reinterpret_cast<const float4*>(g);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc += *reinterpret_cast<const float*>(smem + ((tid * 52 + it) & 32764));
+        __syncthreads();
+        ++it;
+    }
+    if (acc == 12345.678f) sink[tid] = acc;
+}
+static hipStream_t g_cstream = nullptr;
+extern "C" int company_run(int mode, int blocks, int microseconds) {
+    if (!g_seeds) return 1;
+    if (!g_cstream && hipStreamCreateWithFlags(&g_cstream, hipStreamNonBlocking) != hipSuccess) return 2;
+    hipLaunchKernelGGL(dma_company_kernel, dim3(blocks), dim3(256), 32768, g_cstream, g_seeds, g_sink, mode, (long long)microseconds * 100);
+    if (hipGetLastError() != hipSuccess) return 4;
+    return hipStreamSynchronize(g_cstream) == hipSuccess ? 0 : 5;
 }
 extern "C" int victim_read(unsigned int* count, unsigned long long* waves, void* recs, int max) {
     unsigned int n = 0;
