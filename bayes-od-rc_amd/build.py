@@ -14,9 +14,11 @@ SOURCES = [
     ("conv_igemm_f32.hip", []),
     ("conv_pointwise.hip", []),
     ("aux_kernels.hip", []),
-    # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
-    ("post_kernels.hip", ["-ffp-contract=off"]),
-    ("loss_kernels.hip", ["-ffp-contract=off"]),
+    # the Bayesian stages are compared against a NumPy oracle: no FMA contraction.  -fno-slp-vectorize: no packed fp32 instructions
+    # (v_pk_*_f32) in these kernels -- with them their 4x4 inverses / matrix products come out wrong in lanes 48-63 of a wave while a
+    # convolution kernel of the library shares the compute unit (same IEEE operations, bit-identical results)
+    ("post_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("loss_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("train_kernels.hip", []),
     ("engine.hip", []),
 ]

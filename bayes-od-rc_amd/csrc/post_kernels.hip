@@ -78,40 +78,15 @@ __device__ __forceinline__ Mat4 inv_spd4_once(const Mat4& a) {
     return r;
 }
 
-// DESIGN.md 8.4 (round 6): while a convolution kernel of this library shares the compute unit, THIS computation -- the two Cholesky
-// inverses of the prior fusion and nothing in front of them -- can come out wrong in lanes 48-63 of a wave (transiently: the same
-// instructions on the same inputs give the right result the next time; never without such company; mechanism not known, probes in
-// tests/tools/selfcheck_probe.py).  No entry point runs kernels beside each other by default, but two handles or two processes on one
-// GPU do: the inverse is therefore computed until two consecutive evaluations agree bit for bit (two in the normal case; the second
-// evaluation costs 0.1 ms per 512 frames).  Same arithmetic, same result as a single evaluation.  BOD_NO_INV_GUARD: compiled out (A/B).
-__device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) {
-#if defined(BOD_NO_INV_GUARD)
-    return inv_spd4_once(a);
-#else
-    auto fresh = [&]() {              // the input behind an opaque barrier: the compiler must not merge two evaluations into one
-        Mat4 b = a;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(b.m[i][j]));
-#endif
-        return b;
-    };
-    Mat4 r = inv_spd4_once(fresh());
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        const Mat4 r2 = inv_spd4_once(fresh());
-        bool same = true;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) same = same && (__float_as_uint(r.m[i][j]) == __float_as_uint(r2.m[i][j]));
-        if (same) break;
-        r = r2;
-    }
-    return r;
-#endif
-}
+// DESIGN.md 8.4 (round 6): this file is compiled WITHOUT the SLP vectoriser (bayes_od_rc_amd/build.py: -fno-slp-vectorize), i.e. without
+// packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  With them, post_fuse_kernel and cluster_fuse_kernel -- the 4x4
+// inverses and matrix-vector products, which the vectoriser packs two floats at a time -- returned wrong results in lanes 48-63 of a wave
+// whenever a convolution kernel of the library shared the compute unit (0.2-10 % of the waves in the self-check build,
+// tests/tools/selfcheck_probe.py; never alone; never on disjoint CUs); without them: 0 of 56 million waves, and the canary test
+// (tests/test_gpu_zz_canary.py) passes.  Same IEEE operations either way: results are bit-identical to the packed build's when nothing
+// runs beside it.  (A round-6 interim form evaluated the inverse until two consecutive evaluations agreed: it removed 85 % of the events,
+// not all -- the products behind the inverse are packed too.)
+__device__ __forceinline__ Mat4 inv_spd4(const Mat4& a) { return inv_spd4_once(a); }
 
 __device__ __forceinline__ void decode_box(const float4 anc, const float4 t, float o[4]) {
     // box_utils.box_from_anchor_and_target_bnms (:171-192): anchors (v,u,h,w)

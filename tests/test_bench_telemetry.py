@@ -123,4 +123,5 @@ def test_detections_outside_1e3_are_counted_by_cause():
     assert st["outside_1e-3"] == {"detections": 1, "of": 2, "by_cause": {"member_flip": 1}}
     assert st["discrete_flips"]["detections"] == 1 and st["discrete_flips"]["by_kind"]["member_flip"] == 1
     assert st["numeric_only"]["detections"] == 1 and st["numeric_only"]["max_rel_dmu"] == 0.0 and st["numeric_only"]["outside_1e-3"] == 0
+    assert st["numeric_only"]["max_rms_dSigma"] == 0.0 and st["numeric_only"]["covariance_entries_1pct_floor"] == {"max": 0.0, "outside_1e-3": 0}
     assert st["rel_dmu"]["max"] > 1e-3 and st["fro_dSigma"]["max"] == 0.0

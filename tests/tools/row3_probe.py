@@ -19,9 +19,10 @@ lib.victim_run.argtypes = [C.c_int] * 5
 lib.victim_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_void_p, C.c_int]
 NAMES = {0: "fma chain", 1: "IEEE division chain", 2: "transcendental chain", 3: "integer chain", 4: "fp64 chain", 5: "cross-lane chain",
          6: "fma chain behind a call", 7: "fma chain behind a call, results through scratch", 8: "global loads twice (4 bytes per lane)",
-         9: "global_load_dwordx4 twice", 10: "global_load_dwordx2 twice", 11: "scratch array round trip twice"}
+         9: "global_load_dwordx4 twice", 10: "global_load_dwordx2 twice", 11: "scratch array round trip twice",
+         12: "packed fp32 chain (v_pk_mul_f32 + v_pk_add_f32)", 13: "packed fp32 chain (v_pk_fma_f32)"}
 company = os.environ.get("COMPANY", "forward")
-modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11,12,13").split(",")]
 blocks, iters = int(os.environ.get("BLOCKS", "2048")), int(os.environ.get("ITERS", "40"))
 hw, batch = (512, 512), int(os.environ.get("B", "64"))
 b = None

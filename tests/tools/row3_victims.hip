@@ -115,6 +115,25 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ s
                 }
                 if (pass == 0) a = acc2; else b = acc2;
             }
+        } else if constexpr (MODE == 12 || MODE == 13) {  // packed fp32 (12: v_pk_mul_f32 + v_pk_add_f32; 13: v_pk_fma_f32): 64-bit datapath ops
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                f2 y = {x, x * 1.5f}, k1 = {0.99993f, 0.99991f}, k2 = {x * 7.0e-5f, x * 9.0e-5f};
+                asm volatile("" : "+v"(y));
+#pragma unroll 16
+                for (int i = 0; i < 128; ++i) {
+                    if constexpr (MODE == 12) {
+                        f2 t;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(y), "v"(k1));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2));
+                    } else {
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(y), "v"(k1), "v"(k2));
+                    }
+                }
+                if (pass == 0) a = y.x + y.y; else b = y.x + y.y;
+            }
         } else {                                   // 11: private memory round trip (scratch_store / scratch_load of 16-byte pieces), twice
             a = 0.f; b = 0.f;
 #pragma unroll 1
@@ -152,7 +171,7 @@ extern "C" int victim_run(int mode, int blocks, int iters, int cu_lo, int cu_hi)
         } else if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
     }
 #define LAUNCH(M) case M: hipLaunchKernelGGL(victim_kernel<M>, dim3(blocks), dim3(256), 0, g_stream, g_seeds, g_sink, iters); break;
-    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) default: return 3; }
+    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) default: return 3; }
     if (hipGetLastError() != hipSuccess) return 4;
     return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : 5;
 }
