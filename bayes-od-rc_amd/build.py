@@ -14,16 +14,21 @@ SOURCES = [
     ("conv_igemm_f32.hip", []),
     ("conv_pointwise.hip", []),
     ("aux_kernels.hip", []),
-    # the Bayesian stages are compared against a NumPy oracle: no FMA contraction.  -fno-slp-vectorize: no packed fp32 instructions
-    # (v_pk_*_f32) in these kernels -- with them their 4x4 inverses / matrix products come out wrong in lanes 48-63 of a wave while a
-    # convolution kernel of the library shares the compute unit (same IEEE operations, bit-identical results)
-    ("post_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
-    ("loss_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
+    # the Bayesian stages are compared against a NumPy oracle: no FMA contraction
+    ("post_kernels.hip", ["-ffp-contract=off"]),
+    ("loss_kernels.hip", ["-ffp-contract=off"]),
     ("train_kernels.hip", []),
     ("engine.hip", []),
 ]
+# -fno-slp-vectorize (round 6): NO packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in any kernel of
+# the library.  With them, post_fuse_kernel / cluster_fuse_kernel -- whose 4x4 inverses and matrix products the SLP vectoriser packs two
+# floats at a time -- returned wrong results in lanes 48-63 of a wave whenever a convolution kernel of the library shared the compute
+# unit (tests/tools/selfcheck_probe.py: 0.2-10 % of the self-checked waves; without them 0 of 56 million, and tests/test_gpu_zz_canary.py
+# is green).  Same IEEE operations either way (bit-identical results when nothing runs beside the kernel); the convolution kernels'
+# epilogues measure the same speed without them (profiles/round6_mx_ablations.txt: headline 1 877-1 881 against 1 873-1 876 frames/s,
+# f16mx 893-895 against 894-896 on one box).
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-result", "-Wno-unused-value"]
+          "-Wno-unused-result", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
 def _hipcc():
@@ -112,6 +117,9 @@ def build(force=False, verbose=True):
             regs = kernel_guard.verify(os.path.join(obj_dir, "conv_igemm.o"))
             regs.update(kernel_guard.verify_aux(os.path.join(obj_dir, "aux_kernels.o")))
             regs.update(kernel_guard.verify_pointwise(os.path.join(obj_dir, "conv_pointwise.o")))
+            n_checked = sum(kernel_guard.check_no_packed_fp32(o) for o in objs)          # (-fno-slp-vectorize took effect everywhere)
+            if verbose:
+                print("no packed fp32 instruction in %d kernels" % n_checked, flush=True)
             if verbose:
                 print("kernel guards ok: %d production kernels, no spills, inline-asm MFMA windows clean" % len(regs), flush=True)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]

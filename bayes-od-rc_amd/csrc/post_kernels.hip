@@ -78,7 +78,7 @@ __device__ __forceinline__ Mat4 inv_spd4_once(const Mat4& a) {
     return r;
 }
 
-// DESIGN.md 8.4 (round 6): this file is compiled WITHOUT the SLP vectoriser (bayes_od_rc_amd/build.py: -fno-slp-vectorize), i.e. without
+// DESIGN.md 8.4 (round 6): this file -- like every source of the library -- is compiled WITHOUT the SLP vectoriser (bayes_od_rc_amd/build.py: -fno-slp-vectorize), i.e. without
 // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  With them, post_fuse_kernel and cluster_fuse_kernel -- the 4x4
 // inverses and matrix-vector products, which the vectoriser packs two floats at a time -- returned wrong results in lanes 48-63 of a wave
 // whenever a convolution kernel of the library shared the compute unit (0.2-10 % of the waves in the self-check build,

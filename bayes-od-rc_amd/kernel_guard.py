@@ -344,6 +344,26 @@ def verify_pointwise(host_obj):
     return regs
 
 
+PACKED_FP32_RE = r"v_pk_(?:mul|add|fma)_f32\b"
+
+
+def check_no_packed_fp32(host_obj):
+    """Round 6: no kernel of the library may contain packed fp32 instructions -- with them the posterior's 4x4 inverses
+    came out wrong in lanes 48-63 of a wave while a convolution kernel shared the compute unit.  The sources are built with
+    -fno-slp-vectorize; a toolchain that packs anyway must fail the BUILD.  Returns the number of kernels checked."""
+    sections = subprocess.run([_tool("llvm-readelf"), "-S", host_obj], capture_output=True, text=True, check=True).stdout
+    if ".hip_fatbin" not in sections:
+        return 0                                  # host code only (engine.hip)
+    with tempfile.TemporaryDirectory() as d:
+        funcs = disassemble(extract_device_object(host_obj, d))
+    for name, body in funcs.items():
+        hits = [l for l in body if re.match(PACKED_FP32_RE, l)]
+        if hits:
+            raise GuardError("%s: %d packed fp32 instruction(s) in %s, e.g. `%s` (build with -fno-slp-vectorize: DESIGN.md 8.4)"
+                             % (os.path.basename(host_obj), len(hits), name, hits[0]))
+    return len(funcs)
+
+
 def verify(host_obj, wanted=PRODUCTION, asm_kernels=INLINE_ASM_MFMA):
     """All guards on a built conv_igemm.o.  Raises GuardError; returns {kernel: vgpr_count} of the production kernels."""
     with tempfile.TemporaryDirectory() as wd:

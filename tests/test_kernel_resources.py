@@ -117,3 +117,30 @@ def test_the_guard_catches_both_hazards():
     with pytest.raises(guard.GuardError, match="spills"):
         guard.check_no_spills({"_Z17" + guard.PRODUCTION[0] + "v8ConvArgs": {"vgpr_spill_count": 3, "private_segment_fixed_size": 16}},
                               wanted=guard.PRODUCTION[:1])
+
+
+def test_no_kernel_of_the_library_contains_packed_fp32_instructions():
+    """DESIGN.md 8.4 (round 6): with packed fp32 instructions (what the SLP vectoriser makes of 4x4 inverses and matrix products) the
+    posterior's fusion kernels came out wrong in lanes 48-63 of a wave while a convolution kernel shared the compute unit; the library
+    is built with -fno-slp-vectorize and the build refuses an object that contains one (kernel_guard.check_no_packed_fp32).  Here: the
+    objects of the in-tree build are clean, and the check does fire on a source compiled with the vectoriser on."""
+    import subprocess
+    import tempfile
+    obj_dir = os.path.join(ROOT, "bayes-od-rc_amd", "lib", "obj")
+    objs = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o")]
+    if not objs:
+        pytest.skip("library not built in-tree")
+    assert sum(guard.check_no_packed_fp32(o) for o in objs) > 50
+    packed = ("#include <hip/hip_runtime.h>\n"
+              "typedef float f2 __attribute__((ext_vector_type(2)));\n"
+              "__global__ void k(const f2* a, const f2* b, f2* c) { c[threadIdx.x] = a[threadIdx.x] * b[threadIdx.x] + a[threadIdx.x]; }\n")
+    plain = ("#include <hip/hip_runtime.h>\n"
+             "__global__ void k(const float* a, const float* b, float* c) { c[threadIdx.x] = a[threadIdx.x] * b[threadIdx.x] + a[threadIdx.x]; }\n")
+    with tempfile.TemporaryDirectory() as d:
+        for name, src in (("packed", packed), ("plain", plain)):
+            with open(os.path.join(d, name + ".hip"), "w") as fp:
+                fp.write(src)
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-c", os.path.join(d, name + ".hip"), "-o", os.path.join(d, name + ".o")])
+        with pytest.raises(guard.GuardError):
+            guard.check_no_packed_fp32(os.path.join(d, "packed.o"))          # (an explicit two-float vector operation: v_pk_fma_f32 / v_pk_mul_f32)
+        assert guard.check_no_packed_fp32(os.path.join(d, "plain.o")) == 1

@@ -8,7 +8,8 @@ NAME=$1; SRC=$2; FLAGS=$3
 mkdir -p "$ROOT/.ab"
 OBJ="$ROOT/.ab/${NAME}_${SRC%.hip}.o"
 EXTRA=""
-case "$SRC" in post_kernels.hip|loss_kernels.hip) EXTRA="-ffp-contract=off -fno-slp-vectorize";; esac   # (as bayes_od_rc_amd/build.py; a variant that wants packed fp32 passes -fslp-vectorize in its flags)
+EXTRA="-fno-slp-vectorize"          # (as bayes_od_rc_amd/build.py COMMON; a variant that wants packed fp32 passes -fslp-vectorize in its flags)
+case "$SRC" in post_kernels.hip|loss_kernels.hip) EXTRA="$EXTRA -ffp-contract=off";; esac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-result -Wno-unused-value $EXTRA $FLAGS \
   -c "$ROOT/bayes-od-rc_amd/csrc/$SRC" -o "$OBJ"
 OBJS=""

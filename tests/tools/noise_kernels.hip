@@ -3,6 +3,7 @@
 //   mode 0: v_cvt_pk_bf16_f32      mode 1: packed 16-bit integer ops (v_pk_max_i16 / v_pk_min_u16 / v_pk_mul_lo_u16 / v_pk_sub_u16)
 //   mode 2: v_mfma_f32_32x32x16_bf16     mode 3: LDS-DMA (global_load_lds_dwordx4) + ds_read_b128     mode 4: v_bitop3_b32 + v_perm_b32
 //   mode 5: the transcendental unit (v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32)
+//   mode 6: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)     mode 7: packed fp32 between bf16 MFMAs (round 6)
 // build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC tests/tools/noise_kernels.hip -o tests/tools/libnoise_kernels.so
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -41,6 +42,17 @@ __global__ __launch_bounds__(256) void noise_kernel(int mode, int iters, const f
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float4 r = *reinterpret_cast<const float4*>(lds + threadIdx.x * 16);
             x += r.x * 1e-9f;
+        } else if (mode == 6 || mode == 7) {  // 6: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); 7: the same between MFMAs (a conv epilogue's mix)
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            f2 p = {x, y}, k1 = {0.99993f, 0.99991f}, k2 = {7.0e-5f, 9.0e-5f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(k1), "v"(k2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(p), "v"(k1));
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p) : "v"(p), "v"(k2));
+                if (mode == 7) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+            x = p.x; y = p.y;
         } else if (mode == 5) {               // transcendental unit: v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

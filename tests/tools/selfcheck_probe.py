@@ -9,6 +9,8 @@ The VICTIM handle re-runs the posterior on unchanged MC statistics; a COMPANY ha
   COMPANY=forward            the whole bf16 forward (the round-5 trigger)
   COMPANY=ops:lo:hi          ops [lo, hi) of the forward's plan only (BOD_FORWARD_OPS) -- bisection over the real kernels
   COMPANY=none               nothing (control)
+  COMPANY=synthetic:m        tests/tools/noise_kernels.hip mode m (one instruction class: 0 cvt_pk_bf16, 1 packed int16, 2 bf16 MFMA, 3 LDS-DMA +
+                             ds_read, 4 bitop3 / perm, 5 transcendental, 6 packed fp32, 7 packed fp32 between MFMAs)
   VICTIM_SLOTS=lo:hi / COMPANY_SLOTS=lo:hi   CU slots of every XCD the victim's / the company's main stream may use (disjoint masks:
                              if the fault persists, SIMD co-residency is not what causes it)
 usage: selfcheck_probe.py [iterations]   prints one JSON line per configuration"""
@@ -57,7 +59,15 @@ e.infer(None, seed=3, first_image_id=0)
 e.synchronize()
 ref = [e.get_posterior(i) for i in range(0, batch, max(1, batch // 8))]
 b = None
-if company != "none":
+noise_lib = None
+if company.startswith("synthetic:"):
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so_ = os.path.join(here, "libnoise_kernels.so")
+    if not os.path.exists(so_) or os.path.getmtime(so_) < os.path.getmtime(os.path.join(here, "noise_kernels.hip")):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(here, "noise_kernels.hip"), "-o", so_])
+    noise_lib = C.CDLL(so_)
+elif company != "none":
     b = make("COMPANY_SLOTS", ops=company.split(":", 1)[1] if company.startswith("ops:") else None, prec=os.environ.get("COMPANY_PRECISION", "bf16"))
     b.forward(None)
     b.synchronize()
@@ -70,11 +80,14 @@ n_company = [0]
 
 def noise():
     while not stop:
-        b.forward(None, seed=1, first_image_id=0)
+        if noise_lib is not None:
+            assert noise_lib.noise_run(int(company.split(":")[1]), 4096, 400) == 0
+        else:
+            b.forward(None, seed=1, first_image_id=0)
         n_company[0] += 1
 
 
-t = threading.Thread(target=noise if b is not None else (lambda: None)); t.start()
+t = threading.Thread(target=noise if (b is not None or noise_lib is not None) else (lambda: None)); t.start()
 t0 = time.time()
 try:
     for it in range(iters):
