@@ -20,14 +20,22 @@ lib.victim_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_v
 NAMES = {0: "fma chain", 1: "IEEE division chain", 2: "transcendental chain", 3: "integer chain", 4: "fp64 chain", 5: "cross-lane chain",
          6: "fma chain behind a call", 7: "fma chain behind a call, results through scratch", 8: "global loads twice (4 bytes per lane)",
          9: "global_load_dwordx4 twice", 10: "global_load_dwordx2 twice", 11: "scratch array round trip twice",
-         12: "packed fp32 chain (v_pk_mul_f32 + v_pk_add_f32)", 13: "packed fp32 chain (v_pk_fma_f32)"}
+         12: "packed fp32 chain (v_pk_mul_f32 + v_pk_add_f32)", 13: "packed fp32 chain (v_pk_fma_f32)",
+         14: "packed fp32 chain, op_sel_hi broadcast", 15: "packed fp32 chain, neg modifiers", 16: "packed fp32 chain, both modifiers + scalar consumers",
+         17: "the posterior's prior fusion (two 4x4 Cholesky inverses + matrix-vector products), SLP-vectorised"}
 company = os.environ.get("COMPANY", "forward")
-modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11,12,13").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17").split(",")]
 blocks, iters = int(os.environ.get("BLOCKS", "2048")), int(os.environ.get("ITERS", "40"))
 hw, batch = (512, 512), int(os.environ.get("B", "64"))
 b = None
 lib.company_run.argtypes = [C.c_int] * 3
-if company.startswith("dma"):          # COMPANY=dma:0 (LDS-DMA only) / dma:1 (the same bytes without LDS-DMA): row3_victims.hip's synthetic company
+noise_lib = None
+if company.startswith("synthetic:"):      # tests/tools/noise_kernels.hip: one instruction class per mode (7: packed fp32 between MFMAs)
+    so2 = os.path.join(HERE, "libnoise_kernels.so")
+    if not os.path.exists(so2) or os.path.getmtime(so2) < os.path.getmtime(os.path.join(HERE, "noise_kernels.hip")):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(HERE, "noise_kernels.hip"), "-o", so2])
+    noise_lib = C.CDLL(so2)
+elif company.startswith("dma"):          # COMPANY=dma:0 (LDS-DMA only) / dma:1 (the same bytes without LDS-DMA): row3_victims.hip's synthetic company
     lib.victim_run(0, 1, 1, 0, 0)      # (allocates the seeds)
 elif company != "none":
     if os.environ.get("COMPANY_SLOTS"):
@@ -44,14 +52,16 @@ n_company = [0]
 
 def noise():
     while not stop:
-        if company.startswith("dma"):
+        if noise_lib is not None:
+            assert noise_lib.noise_run(int(company.split(":")[1]), 4096, 400) == 0
+        elif company.startswith("dma"):
             assert lib.company_run(int(company.split(":")[1]), int(os.environ.get("COMPANY_BLOCKS", "512")), 20000) == 0
         else:
             b.forward(None, seed=1, first_image_id=0)
         n_company[0] += 1
 
 
-t = threading.Thread(target=noise if (b is not None or company.startswith("dma")) else (lambda: None)); t.start()
+t = threading.Thread(target=noise if (b is not None or company.startswith("dma") or noise_lib is not None) else (lambda: None)); t.start()
 cnt, waves = C.c_uint(0), C.c_ulonglong(0)
 recs = np.zeros((4096, 8), np.uint32)
 try:

@@ -69,6 +69,87 @@ __device__ __noinline__ void call_fma_scratch(float x, float* __restrict__ out8)
     for (int k = 0; k < 8; ++k) { y = chain_fma(y); out8[k] = y; }
 }
 
+// mode 17: the arithmetic in which the library saw the fault -- the posterior's prior fusion (csrc/post_kernels.hip: two Cholesky inverses
+// of a 4x4 SPD matrix and two matrix-vector products), plain C++ that the SLP vectoriser packs into v_pk_mul_f32 / v_pk_add_f32 with
+// op_sel / neg modifiers.  This file is compiled with the vectoriser ON (the library is not, since round 6).
+struct M4 { float m[4][4]; };
+__device__ __forceinline__ M4 inv_spd4_v(const M4& a) {
+    float g[4][4], h[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[i][j] = 0.f; h[i][j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float d = a.m[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= g[j][k] * g[j][k];
+        const float dj = sqrtf(d);
+        g[j][j] = dj;
+        const float inv = 1.0f / dj;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            float s = a.m[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= g[i][k] * g[j][k];
+            g[i][j] = s * inv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j][j] = 1.0f / g[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) s += g[i][k] * h[k][j];
+            h[i][j] = -s / g[i][i];
+        }
+    }
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = i; k < 4; ++k) s += h[k][i] * h[k][j];
+            r.m[i][j] = s; r.m[j][i] = s;
+        }
+    return r;
+}
+__device__ __noinline__ float prior_fusion(float x, float pp) {
+    M4 lik;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lik.m[i][j] = i == j ? 2.0f + x * (float)(i + 1) : 0.05f * x * (float)(i + j + 1);
+    const float mu[4] = {100.f * x, 120.f * x, 40.f + x, 30.f + x}, am[4] = {101.f * x, 119.f * x, 41.f, 29.f};
+    const M4 prec = inv_spd4_v(lik);
+    M4 post = prec;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) post.m[i][i] += pp;
+    const M4 pcov = inv_spd4_v(post);
+    float inter[4], pm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += prec.m[i][k] * mu[k];
+        inter[i] = pp * am[i] + s;
+    }
+    float out = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += pcov.m[i][k] * inter[k];
+        pm[i] = s;
+        out += pm[i] * (float)(i + 1) + pcov.m[i][i] + pcov.m[i][(i + 1) & 3];
+    }
+    return out;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ seeds, float* __restrict__ sink, int iters) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -134,6 +215,35 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ s
                 }
                 if (pass == 0) a = y.x + y.y; else b = y.x + y.y;
             }
+        } else if constexpr (MODE == 17) {
+            a = prior_fusion(xa, 1e-5f); b = prior_fusion(xb, 1e-5f);
+        } else if constexpr (MODE >= 14 && MODE <= 16) {  // packed fp32 WITH operand modifiers, as the SLP vectoriser emits them for 4x4 inverses:
+            // 14: op_sel_hi:[1,0] (the low half of src1 broadcast to both halves); 15: neg_lo / neg_hi (a packed subtraction);
+            // 16: both, plus a scalar consumer of each half right behind the packed instruction (the dot-product pattern)
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                f2 y = {x, x * 1.5f}, k1 = {0.99993f, 0.99991f}, k2 = {x * 7.0e-5f, x * 9.0e-5f};
+                asm volatile("" : "+v"(y));
+                float s_ = 0.f;
+#pragma unroll 16
+                for (int i = 0; i < 128; ++i) {
+                    f2 t;
+                    if constexpr (MODE == 14) {
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(y), "v"(k1));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2));
+                    } else if constexpr (MODE == 15) {
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(y), "v"(k1));
+                        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(y) : "v"(t), "v"(k2));
+                    } else {
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(y), "v"(k1));
+                        s_ += t.x * 1e-3f; s_ -= t.y * 1e-3f;
+                        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(y) : "v"(t), "v"(k2));
+                    }
+                }
+                if (pass == 0) a = y.x + y.y + s_; else b = y.x + y.y + s_;
+            }
         } else {                                   // 11: private memory round trip (scratch_store / scratch_load of 16-byte pieces), twice
             a = 0.f; b = 0.f;
 #pragma unroll 1
@@ -171,7 +281,7 @@ extern "C" int victim_run(int mode, int blocks, int iters, int cu_lo, int cu_hi)
         } else if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
     }
 #define LAUNCH(M) case M: hipLaunchKernelGGL(victim_kernel<M>, dim3(blocks), dim3(256), 0, g_stream, g_seeds, g_sink, iters); break;
-    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) default: return 3; }
+    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16) LAUNCH(17) default: return 3; }
     if (hipGetLastError() != hipSuccess) return 4;
     return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : 5;
 }
