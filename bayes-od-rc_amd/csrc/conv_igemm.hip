@@ -1736,6 +1736,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                             __builtin_amdgcn_sched_barrier(0);           // one fragment at a time (register pressure)
                         }
                         *reinterpret_cast<uint32_t*>(prow + (((48 ^ lr) & (CPR2 - 1)) << 4) + wc * 8 + fh_i * 4) = sdw;
+                        // the rest of the scale chunk and the unused eighth chunk are part of the 1 KiB row the store loop copies: zeros, not
+                        // whatever the staging buffers left there (the activation buffers stay byte-for-byte reproducible; never read)
+                        {
+                            const int zq = wc * 2 + fh_i;
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                const int pz = 49 + zq + 4 * z;
+                                if (pz < 64) *reinterpret_cast<uint4*>(prow + (((pz ^ lr) & (CPR2 - 1)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+                            }
+                        }
                         continue;
                     }
                     if (G.out_hx) {

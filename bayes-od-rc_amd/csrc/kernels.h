@@ -52,9 +52,10 @@ struct ConvGroup {         // element type of in / w / res / out_relu: bf16 (def
     // + bias + ReLU) of the SAME input tile -- a ConvBlock's `2a` riding on its projection shortcut `branch1` -- instead of one of
     // the finished output tile.
     int32_t ch_dual;
-    // f16mx precision (ConvArgs.mx != 0): 1 = this group's output rows leave in the tower format "hx" (conv_igemm.hip: per 64 channels
-    // 64 f16 hi + 128 bytes of e5m2 copies of hi and of lo * 2^12) for the next tower layer; 0 = (hi, lo) bf16 pairs (what the fused
-    // 1x1 + aggregation and every other consumer read); 2 = "h4" rows (f16mx4)
+    // f16mx precision (ConvArgs.mx != 0): 1 = this group's output rows leave in the tower format "hx" (header of conv_igemm.hip: per 64
+    // channels a 128-byte H chunk of 64 f16 hi and a 128-byte X chunk of four 32-byte slots -- 16 channels as 32 e2m3 (fp6) elements
+    // {hi6, lo6'}, lo' = lo * 2^11, 24 bytes + the block's E8M0 scale at byte 28) for the next tower layer; 0 = (hi, lo) bf16 pairs (what
+    // the fused 1x1 + aggregation and every other consumer read); 2 = "h4" rows (f16mx4: e2m1 cross terms, scale bytes in chunk 6)
     int32_t out_hx;
 };
 enum : int32_t { AGG_NONE = 0, AGG_CLS = 1, AGG_BOX = 2, AGG_COV = 3 };
@@ -116,12 +117,13 @@ struct ConvArgs {
     // at once (conv_igemm.hip).  0 = off.
     int32_t stagger_ticks;
     // f16mx precision, head towers on the row-reuse loop (with `split`: same slot counts, same 1 KiB pixel rows): 1 = activations and
-    // weights in the hx format, one f16 product + one block-scaled e5m2 product (the two cross terms) per multiplication; 2 = (hi, lo)
+    // weights in the hx format, one f16 product + half a block-scaled e2m3 (fp6) product (the two cross terms) per multiplication; 2 = (hi, lo)
     // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer); 3 = activations and weights in the h4 format
     // (f16mx4: the cross terms as e2m1 products of twice the channels; the weight buffer carries a compact copy of its scale bytes behind
     // the 256 rows).  0 = off.
     int32_t mx;
-    int32_t mx_loader;     // f16mx loop: which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four)
+    int32_t mx_loader;     // f16mx loop: bits 0-1 = which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four); bit 2 = the late
+                           // waves issue their LDS-DMA pieces in front of a step's MFMAs (round 6 A/B: slower, off)
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute

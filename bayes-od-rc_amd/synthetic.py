@@ -33,9 +33,28 @@ def _bn(rng, c, gamma_lo=0.5, gamma_hi=1.5):
             "var": rng.uniform(0.5, 1.5, c).astype(np.float32)}
 
 
+_WEIGHT_CACHE = {}
+
+
 def make_weights(num_classes_with_bknd=8, anchors_per_location=9, seed=1000, cls_fg_bias=None,
                  cov_out_std=0.02, backbone_bias=True, depth=50):
-    """Returns {layer_name: {...}} for ResNet-50 (or -101: depth=101) + FPN + the three heads."""
+    """Returns {layer_name: {...}} for ResNet-50 (or -101: depth=101) + FPN + the three heads.  Deterministic in its arguments; the arrays
+    of a parameter set are generated once per process (seconds of host time: the GPU suite asks for the same set a hundred times) and
+    handed out READ-ONLY inside fresh dictionaries -- replace an entry to change a weight, never write into an array."""
+    key = (num_classes_with_bknd, anchors_per_location, seed, cls_fg_bias, cov_out_std, backbone_bias, depth)
+    if key not in _WEIGHT_CACHE:
+        if len(_WEIGHT_CACHE) >= 6:
+            _WEIGHT_CACHE.pop(next(iter(_WEIGHT_CACHE)))
+        w = _make_weights(*key)
+        for layer in w.values():
+            for arr in layer.values():
+                if isinstance(arr, np.ndarray):
+                    arr.setflags(write=False)
+        _WEIGHT_CACHE[key] = w
+    return {name: dict(layer) for name, layer in _WEIGHT_CACHE[key].items()}
+
+
+def _make_weights(num_classes_with_bknd, anchors_per_location, seed, cls_fg_bias, cov_out_std, backbone_bias, depth):
     w = {}
     idx = [0]
 

@@ -1140,6 +1140,8 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     #                          (absolute: they are probabilities) and covariance entries (|d| / (|entry| + rms of the matrix's entries): the raw
     #                          outputs' form -- a signed entry's zero crossings have no relative error; the rounds-4/5 floor, 1 % of the largest
     #                          entry, is reported beside it as `covariance_entries_1pct_floor`, the norm-wise distance as fro_dSigma) <= 1e-3;
+    #   covariance_entries_1pct_floor   in the stricter entry-wise form (|d| / (|entry| + 1 % of the largest entry)) at most one such detection
+    #                          per frame above 1e-3;
     #   discrete_flips         the others -- a categorical draw at a CDF edge, a cluster member at the affinity threshold, a centre swapped: a
     #                          1e-4 perturbation flips a handful per frame in ANY arithmetic -- counted by kind and bounded at one per frame on
     #                          average; every unmatched CPU detection must be one of them.
@@ -1164,6 +1166,10 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
             c["numeric_max_within_1e-3"] = bool(max(num["max_rel_dmu"], num["max_rms_dSigma"], num["max_dscore"]) <= 1e-3)
             c["discrete_flips"] = flips
             c["discrete_flips_at_most_one_per_frame"] = bool(flips["detections"] <= st["frames"])
+            # the STRICTER entry-wise covariance form of rounds 4-5 (floor: 1 % of the matrix's largest entry) stays a clause: at most one
+            # detection per frame may exceed 1e-3 in it (f16mx: 1 of 1 600 at 1.2e-3; f16mx4: ~90 of 1 600 up to 4e-3 -- which is why that
+            # mode is reported beside the parity mode and never chosen as it, whatever the matrix-scale form says)
+            c["covariance_entries_1pct_floor_at_most_one_per_frame"] = bool(num["covariance_entries_1pct_floor"]["outside_1e-3"] <= st["frames"])
             c["unmatched_all_explained"] = bool(st["cpu_detections"] - st["matched"] <=
                                                 sum(v for k, v in (st.get("outside_1e-3") or {}).get("by_cause", {}).items()
                                                     if k.startswith("unmatched: ") and "unexplained" not in k))
