@@ -1022,11 +1022,12 @@ bod_status build_plan(bod_context* h) {
     // layer 1 on; layer 0 then reads ONE pyramid (hx) and writes each head's format.
     int hfmt[3] = {mxf, mxf, mxf};
     if (mxf == 2) { const char* e = getenv("BOD_MX4_BOX_HX"); if (e && atoi(e) != 0) hfmt[1] = 1; }
-    // f16mx, round 6: BOD_MX_CLS_H4=1 puts the CLASSIFICATION tower alone on h4 rows (e2m1 cross terms: three quarters of the staged bytes
-    // and K-tiles of 3 of the 8 per-sample convs) -- its logits go through a softmax and a 30-draw categorical and lose nothing measurable
-    // (raw class logits 1.2e-4 against 9.3e-5 on hx rows), while the box and covariance towers, whose rounding reaches the fused
-    // covariance entries, stay on hx rows.  The same mixed plan as above: the towers run as one launch per format from layer 1 on.
-    if (mxf == 1) { static const bool cls_h4 = [] { const char* e = getenv("BOD_MX_CLS_H4"); return e && atoi(e) != 0; }(); if (cls_h4) hfmt[0] = 2; }
+    // f16mx, round 6: the CLASSIFICATION tower alone runs on h4 rows (e2m1 cross terms: three quarters of the staged bytes and K-tiles of 3
+    // of the 8 per-sample convs) -- its logits go through a softmax and a 30-draw categorical and lose nothing measurable (raw class
+    // logits 1.2e-4 against 9.3e-5 on hx rows; the bench line's gate: every clause unchanged, categorical draw flips 1 -> 5 of 1 600
+    // detections), while the box and covariance towers, whose rounding reaches the fused covariance entries, stay on hx rows.  The same
+    // mixed plan as above: the towers run as one launch per format from layer 1 on.  +1.6-2.1 % frames/s.  BOD_MX_CLS_H4=0: all on hx rows.
+    if (mxf == 1) { static const bool cls_h4 = [] { const char* e = getenv("BOD_MX_CLS_H4"); return !e || atoi(e) != 0; }(); if (cls_h4) hfmt[0] = 2; }
     const bool mixed = mx_plan && hfmt[0] != hfmt[1];
     const int pyr_fmt = mixed ? 1 : mxf;
     h->pyr_fmt = pyr_fmt;

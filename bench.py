@@ -1099,7 +1099,9 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
                 mx = mode in ("f16mx", "f16mx4") and engp.plan_info()["tower_mx"]
                 out[key]["roofline"] = {
                     "bound": "mfma",
-                    "kernel": ("conv_igemm_mx_kernel<%d> (head towers, layers 1-3: f16 hi*hi + block-scaled %s cross terms)" % ((1, "e2m3") if mode == "f16mx" else (3, "e2m1"))
+                    "kernel": (("conv_igemm_mx_kernel<1> (box / covariance towers: f16 hi*hi + block-scaled e2m3 cross terms) + <3> (classification tower: e2m1 cross terms), layers 1-3"
+                                if (mode == "f16mx" and os.environ.get("BOD_MX_CLS_H4", "1") != "0") else
+                                "conv_igemm_mx_kernel<%d> (head towers, layers 1-3: f16 hi*hi + block-scaled %s cross terms)" % ((1, "e2m3") if mode == "f16mx" else (3, "e2m1")))
                                if mx else "conv_igemm_kernel<256,256,2,4,0,%s,true> (every head 3x3 launch, (hi, lo) bf16 pairs: three products per multiplication)" % ("true" if engp.plan_info().get("row_reuse") else "false")),
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "mfma_issue_tflops_bf16_equivalent": round(products * ach, 2), "frac_of_own_mfma_floor": round(products * ach / PEAK_BF16_TFLOPS, 4),
