@@ -896,7 +896,7 @@ def run(args, out, rank, world, local_rank, backend, hw, n, B, fwd_only):
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes) when they were taken on this exact configuration, else null
     traffic, traffic_source = None, None
-    for pmc_file in ("round5_head_conv_pmc.json", "round4_head_conv_pmc.json", "round3_head_conv_pmc.json", "round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
+    for pmc_file in ("round6_head_conv_pmc.json", "round5_head_conv_pmc.json", "round4_head_conv_pmc.json", "round3_head_conv_pmc.json", "round2_head_conv_pmc.json", "round1_head_conv_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as fp:
                 pmc = json.load(fp)
