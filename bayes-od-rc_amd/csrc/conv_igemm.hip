@@ -259,7 +259,7 @@ struct HxCarry {                 // the first step's operands of a K-tile, reque
 template <int FC, int FP, int ROWB, bool XT, bool NXT, bool F4 = false, class SYNC, class SLOT>
 __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __restrict__ rd, char* __restrict__ wr, const int wa, const int (&xb)[FP],
                                          const int wa_n, const int (&xb_n)[FP], const bool has_next, HxCarry<FP>& c, SYNC&& sync, SLOT&& slot,
-                                         const int ws_n = 0, const int* xs_n = nullptr, const bool dfirst = false) {
+                                         const int ws_n = 0, const int* xs_n = nullptr) {
     auto ldH = [&](int base, int ks) { return *reinterpret_cast<const bf16x8*>(rd + (base ^ (ks << 5))); };
     // an X operand = 24 bytes of elements (first piece + 8 bytes of the second) + the scale byte (second piece, byte 12): read straight
     // into a 6-register tuple and one scale register.  The 8- and 4-byte reads run 2- / 4-way bank conflicts (rows r and r + 16 of a
@@ -323,10 +323,6 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
             if (it + 1 < NIT) Af[cur ^ 1] = ldH(wa + ((it + 1) % FC) * 32 * ROWB, (it + 1) / FC);
             if (it == NIT - 1) { sync(); if (has_next) next_A(); }
             __builtin_amdgcn_sched_barrier(0);
-            // `dfirst` (wave-uniform; ConvArgs.mx_loader bit 2: the four LATE waves): this wave issues the step's LDS-DMA piece IN FRONT of the
-            // step's MFMAs instead of behind them -- the two waves of a SIMD then alternate (one parks on its piece while the other's MFMAs
-            // run) instead of both parking at the same moment with the matrix pipe empty
-            if (dfirst && (it & 1)) { slot(it >> 1, wr); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 if constexpr (XT && F4) {
@@ -339,7 +335,7 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
                 if (it == NIT - 1 && has_next) next_B(j);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!dfirst && (it & 1)) slot(it >> 1, wr);
+            if (it & 1) slot(it >> 1, wr);
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
@@ -356,7 +352,6 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
             else if (it > 0) A6[0] = ld6(wa + i * 32 * ROWB, m, sa[0]);
             if (it == NIT - 1) { sync(); if (has_next) next_A(); }
             __builtin_amdgcn_sched_barrier(0);
-            if (dfirst) { slot(it, wr); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 mfma_mx6_inplace(acc[i][j], A6[cur], B6[j], sa[cur], sb[j]);
@@ -364,7 +359,7 @@ __device__ __forceinline__ void hx_ktile(f32x16 (&acc)[FC][FP], const char* __re
                 if (it == NIT - 1 && has_next) next_B(j);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!dfirst) slot(it, wr);
+            slot(it, wr);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1067,8 +1062,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
             // source, 4 KiB in LDS), the other four none.  The two waves of a SIMD share one matrix pipe and a wave parks 60-185 cycles per
             // piece it issues: with every wave issuing, one wave of each SIMD reaches the K-tile's barrier ~620 cycles before the other
             // (phase clock: `s_barrier` 44 k of 223 k cycles per tile) and idles there while its partner's parks leave the pipe empty.
+            // (round 6, measured and not kept: the four late waves issuing their LDS-DMA piece IN FRONT of a step's MFMAs instead of behind
+            // them, so that the two waves of a SIMD alternate between parking on a piece and issuing MFMAs -- 81.5 against 78.9 ms per
+            // layer-1 launch on one box, profiles/round6_mx_ablations.txt)
             const int mx_loader = a.mx_loader & 3;
-            const bool dma_first = (a.mx_loader & 4) && wave >= 4;          // (hx_ktile: the late waves' pieces in front of the step's MFMAs)
             const bool w_issuer = mx_loader == 0 || (mx_loader == 1 ? wave < 4 : wave >= 4);
             auto dma_w = [&](const int piece, const int kt_, char* __restrict__ wr) {
                 if (!w_issuer) return;
@@ -1208,7 +1205,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(wr + xdst + (i * THREADS + wave * 64) * 16), 16, (int)xo[i], 0, 0, 0);
                                 }
                             }
-                        }, ws_n, xs_n, dma_first);
+                        }, ws_n, xs_n);
                     if constexpr (MXI) mx_t_body += __builtin_amdgcn_s_memtime() - mx_tb;
                 };
                 ktile(std::integral_constant<int, 0>{}); ktile(std::integral_constant<int, 1>{}); ktile(std::integral_constant<int, 2>{});

@@ -122,8 +122,7 @@ struct ConvArgs {
     // (f16mx4: the cross terms as e2m1 products of twice the channels; the weight buffer carries a compact copy of its scale bytes behind
     // the 256 rows).  0 = off.
     int32_t mx;
-    int32_t mx_loader;     // f16mx loop: bits 0-1 = which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four); bit 2 = the late
-                           // waves issue their LDS-DMA pieces in front of a step's MFMAs (round 6 A/B: slower, off)
+    int32_t mx_loader;     // f16mx loop: which waves issue the weight pieces (conv_igemm.hip; 0 all, 1 lower four, 2 upper four)
 };
 
 // hipFuncSetAttribute is per device: remember which devices of this process already have the attribute
