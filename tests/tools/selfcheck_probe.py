@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """WHERE and BESIDE WHAT does post_fuse_kernel miscompute a 16-lane row?  (development probe)
 
-Needs a BOD_POST_SELFCHECK build of the library (tests/tools/build_variant.sh selfcheck post_kernels.hip -DBOD_POST_SELFCHECK;
-BOD_LIB_OVERRIDE=.ab/libselfcheck.so): post_fuse_kernel computes every slot twice in the same thread through one out-of-line copy of
-the code and logs every slot whose two results differ with the wave's HW_REG_HW_ID / HW_REG_XCC_ID.
+Needs a BOD_POST_SELFCHECK build of the library: post_fuse_kernel computes every slot twice in the same thread through one out-of-line
+copy of the code and logs every slot whose two results differ with the wave's HW_REG_HW_ID / HW_REG_XCC_ID.
+    tests/tools/build_variant.sh sc2packed post_kernels.hip "-DBOD_POST_SELFCHECK=2 -fslp-vectorize"   # the victim WITH packed fp32 (the fault)
+    tests/tools/build_variant.sh sc2       post_kernels.hip "-DBOD_POST_SELFCHECK=2"                    # as the product is built: without (0 events)
+    BOD_LIB_OVERRIDE=.ab/libsc2packed.so COMPANY=synthetic:7 python3 tests/tools/selfcheck_probe.py 2000
+(-DBOD_POST_SELFCHECK=1: loads and stores inside the twice-run code; =2: inputs in registers; -DBOD_POST_SELFCHECK_PART=1..3 cuts the
+twice-run code behind the epistemic / aleatoric / likelihood block.  Records of round 6: profiles/round6_selfcheck_probes.txt.)
 
 The VICTIM handle re-runs the posterior on unchanged MC statistics; a COMPANY handle runs on another host thread:
   COMPANY=forward            the whole bf16 forward (the round-5 trigger)
