@@ -4,6 +4,7 @@
 //   mode 2: v_mfma_f32_32x32x16_bf16     mode 3: LDS-DMA (global_load_lds_dwordx4) + ds_read_b128     mode 4: v_bitop3_b32 + v_perm_b32
 //   mode 5: the transcendental unit (v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32)
 //   mode 6: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)     mode 7: packed fp32 between bf16 MFMAs (round 6)
+//   modes 8-12: ONE kind of instruction between bf16 MFMAs: v_pk_max_i16 / v_cvt_pk_bf16_f32 / v_mov_b64 / v_pk_mul_f32 / v_fma_f64
 // build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC tests/tools/noise_kernels.hip -o tests/tools/libnoise_kernels.so
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -53,6 +54,20 @@ __global__ __launch_bounds__(256) void noise_kernel(int mode, int iters, const f
                 if (mode == 7) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
             x = p.x; y = p.y;
+        } else if (mode >= 8 && mode <= 12) { // ONE kind of instruction between bf16 MFMAs: 8 v_pk_max_i16, 9 v_cvt_pk_bf16_f32, 10 v_mov_b64,
+            typedef __attribute__((ext_vector_type(2))) float f2;     // 11 v_pk_mul_f32 alone, 12 v_fma_f64 (64-bit datapath, not packed)
+            f2 p = {x, y}, k1 = {0.99993f, 0.99991f};
+            double dd = x;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (mode == 8) { unsigned q; asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(q) : "v"(u), "v"(v)); u = q + 1u; }
+                else if (mode == 9) { unsigned q; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(q) : "v"(x), "v"(y)); x += __uint_as_float(q << 16) * 1e-6f; }
+                else if (mode == 10) { f2 q; asm volatile("v_mov_b64 %0, %1" : "=v"(q) : "v"(p)); p = q; p.x += 1e-6f; }
+                else if (mode == 11) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(p), "v"(k1)); }
+                else { asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(dd) : "v"(dd), "v"(0.99993), "v"(1e-5)); }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+            x = p.x + (float)dd * 1e-9f; y = p.y;
         } else if (mode == 5) {               // transcendental unit: v_rcp_f32 / v_rcp_iflag_f32 / v_exp_f32 / v_sqrt_f32 / v_rsq_f32
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

@@ -4,8 +4,9 @@
 #   victim  : tests/tools/row3_victims.hip, mode 17 -- the posterior's prior fusion as plain C++ (two 4x4 Cholesky inverses + two
 #             matrix-vector products), compiled with hipcc -O3 defaults, i.e. SLP-vectorised into v_pk_mul_f32 / v_pk_add_f32 /
 #             v_pk_fma_f32; every thread evaluates it TWICE on the same input and logs a bitwise difference with HW_REG_HW_ID;
-#   company : tests/tools/noise_kernels.hip, mode 7 -- a kernel that interleaves packed fp32 instructions with
-#             v_mfma_f32_32x32x16_bf16, on another stream from another host thread.
+#   company : tests/tools/noise_kernels.hip, mode 7 -- a kernel that interleaves VALU instructions (here: packed fp32; modes 8-12: v_pk_max_i16,
+#             v_cvt_pk_bf16_f32, v_mov_b64, v_pk_mul_f32, v_fma_f64 -- any kind will do) with v_mfma_f32_32x32x16_bf16, on another stream
+#             from another host thread.
 #
 # Observed (profiles/round6_selfcheck_probes.txt, section 12): alone 0 differences; beside mode 7: ~4 % of the (wave, iteration) pairs,
 # ALWAYS lanes 48-63 of a wave (the last 16-lane row), uniformly over all XCCs and SIMDs; beside MFMAs only (mode 2), packed fp32 only
@@ -16,3 +17,5 @@ ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=none python3 tests/
 ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=synthetic:7 python3 tests/tools/row3_probe.py
 ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=synthetic:2 python3 tests/tools/row3_probe.py
 ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=synthetic:6 python3 tests/tools/row3_probe.py
+ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=synthetic:8 python3 tests/tools/row3_probe.py          # v_pk_max_i16 between MFMAs: the strongest trigger
+VICTIM_NOSLP=1 ITERS=${ITERS:-300} LAUNCHES=${LAUNCHES:-3} MODES=17 COMPANY=synthetic:7 python3 tests/tools/row3_probe.py   # the victim without packed fp32: 0

@@ -11,9 +11,12 @@ import numpy as np
 from bayes_od_rc_amd import synthetic
 from bayes_od_rc_amd.engine import Engine, make_config
 
-so = os.path.join(HERE, "librow3_victims.so")
-if not os.path.exists(so):
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(HERE, "row3_victims.hip"), "-o", so])
+# VICTIM_NOSLP=1: the victims built with -fno-slp-vectorize (no packed fp32 instruction in mode 17's arithmetic)
+noslp = os.environ.get("VICTIM_NOSLP") == "1"
+so = os.path.join(HERE, "librow3_victims_noslp.so" if noslp else "librow3_victims.so")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "row3_victims.hip")):
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC"] + (["-fno-slp-vectorize"] if noslp else []) +
+                          [os.path.join(HERE, "row3_victims.hip"), "-o", so])
 lib = C.CDLL(so)
 lib.victim_run.argtypes = [C.c_int] * 5
 lib.victim_read.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_void_p, C.c_int]
