@@ -599,7 +599,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
     constexpr bool MXL = MXK == 1 || MXK == 11 || MXK == 12 || MXK == 3;
     constexpr bool MX4 = MXK == 3;          // f16mx4: h4 rows in (4 H chunks + 2 X chunks of e2m1 cross terms + the scale bytes)
     constexpr bool MXI = MXK == 11 || MXK == 12;
-    unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0, mx_t_cnt = 0;
+    unsigned long long mx_t_wait = 0, mx_t_body = 0, mx_t0 = 0, mx_t_cnt = 0, mx_t_h = 0, mx_t_x = 0;          // (_h / _x, round 6: whole H / X K-tiles)
     if constexpr (MXI) mx_t0 = __builtin_amdgcn_s_memtime();
     using Cfg = ConvCfg<BC, BP, WC, WP, XR>;
     constexpr int THREADS = Cfg::THREADS;
@@ -1173,8 +1173,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                     }
                     // the extended rows' scale pieces of the next group leave in this group's first K-tile (slot 6), when it is an X group
                     constexpr bool xs_here = MX4 && xt_next_group && kxc == 0;
-                    unsigned long long mx_tb = 0;
-                    if constexpr (MXI) mx_tb = __builtin_amdgcn_s_memtime();
+                    unsigned long long mx_tb = 0, mx_tk = 0;
+                    if constexpr (MXI) { mx_tb = __builtin_amdgcn_s_memtime(); mx_tk = mx_tb; }
                     hx_ktile<FC, FP, ROWB, xt, nxt, MX4>(acc, smem, smem, wa_, xb_, wa_n, xb_n, has_next, carry,
                         [&]() {
                             unsigned long long ta = 0;
@@ -1206,7 +1206,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 }
                             }
                         }, ws_n, xs_n);
-                    if constexpr (MXI) mx_t_body += __builtin_amdgcn_s_memtime() - mx_tb;
+                    if constexpr (MXI) {
+                        const unsigned long long te = __builtin_amdgcn_s_memtime();
+                        mx_t_body += te - mx_tb;
+                        if (xt) mx_t_x += te - mx_tk; else mx_t_h += te - mx_tk;
+                    }
                 };
                 ktile(std::integral_constant<int, 0>{}); ktile(std::integral_constant<int, 1>{}); ktile(std::integral_constant<int, 2>{});
                 if (++ky == 3) { ky = 0; ++cc; }
@@ -1223,8 +1227,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 group(g0 + 3, std::true_type{}, std::false_type{}); group(g0 + 4, std::true_type{}, std::false_type{}); group(g0 + 5, std::true_type{}, std::true_type{});
             }
             if constexpr (MXI) {
+                // (round 6: whole K-tiles by flavour, wave 0 -- an early wave, which issues the weight pieces -- and wave 4, its late partner on the SIMD)
+                if (threadIdx.x == 256) { atomicAdd(&g_phase_cycles[2], mx_t_h); atomicAdd(&g_phase_cycles[3], mx_t_x); atomicAdd(&g_phase_cycles[4], mx_t_wait); }
                 if (threadIdx.x == 0) {
                     const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    atomicAdd(&g_phase_cycles[0], mx_t_h); atomicAdd(&g_phase_cycles[1], mx_t_x);
                     atomicAdd(&g_phase_cycles[6], mx_t_wait); atomicAdd(&g_phase_cycles[7], mx_t_body); atomicAdd(&g_phase_cycles[13], mx_t_cnt);
                     atomicAdd(&g_phase_cycles[8], now - mx_t0); atomicAdd(&g_phase_cycles[15], 1ull);
                     mx_t0 = now;

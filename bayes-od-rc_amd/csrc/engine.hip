@@ -2653,6 +2653,11 @@ bod_status bod_bench_head_conv(bod_handle h, int32_t layer, int32_t variant, int
                         "K-tile bodies %.0f; 72 K-tiles) + epilogue %.0f; of the wait: vmcnt / lgkmcnt %.0f, s_barrier %.0f\n", tiles, (double)c[9] / tiles, ((double)c[8] - (double)c[6] - (double)c[7]) / tiles,
                 ((double)c[6] + (double)c[7]) / tiles, (double)c[6] / tiles, (double)c[7] / tiles, ((double)c[9] - (double)c[8]) / tiles,
                 (double)c[13] / tiles, ((double)c[6] - (double)c[13]) / tiles);
+        // round 6: the loop by K-tile flavour (36 H K-tiles of four f16 k-steps, 36 X K-tiles of two block-scaled products: half the MFMA issue on
+        // the same staged bytes), for wave 0 (early: issues the weight pieces) and wave 4 (late: its partner on the SIMD)
+        fprintf(stderr, "# f16mx phase clock by K-tile flavour, cycles per K-tile: wave 0: H %.0f  X %.0f | wave 4: H %.0f  X %.0f, wait + barrier per K-tile %.0f (wave 0: %.0f)"
+                        " | MFMA issue of a SIMD's two waves: H 2048, X 1024\n",
+                (double)c[0] / tiles / 36.0, (double)c[1] / tiles / 36.0, (double)c[2] / tiles / 36.0, (double)c[3] / tiles / 36.0, (double)c[4] / tiles / 72.0, (double)c[6] / tiles / 72.0);
     } else if (variant == 90) {
         unsigned long long c[16];
         conv_igemm_phase_cycles(c, true);
