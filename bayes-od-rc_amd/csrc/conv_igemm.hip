@@ -1118,6 +1118,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                 }
             };
             HxCarry<FP> carry;
+            // (round 6, measured and not kept: s_setprio 1 for the four late waves -- which reach every K-tile's barrier last -- 73.3-73.6 against
+            // 72.2-72.4 ms per layer-1 launch; for the four early ones 72.4-72.5: profiles/round6_mx_ablations.txt)
             // prologue: K-tile 0's weights and group 0's rows are on their way (issued above); piece 0 of K-tile 1 behind them
             if (KT > 1 && MXK != 12) dma_w(0, 1, smem);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
