@@ -25,9 +25,12 @@ NAMES = {0: "fma chain", 1: "IEEE division chain", 2: "transcendental chain", 3:
          9: "global_load_dwordx4 twice", 10: "global_load_dwordx2 twice", 11: "scratch array round trip twice",
          12: "packed fp32 chain (v_pk_mul_f32 + v_pk_add_f32)", 13: "packed fp32 chain (v_pk_fma_f32)",
          14: "packed fp32 chain, op_sel_hi broadcast", 15: "packed fp32 chain, neg modifiers", 16: "packed fp32 chain, both modifiers + scalar consumers",
-         17: "the posterior's prior fusion (two 4x4 Cholesky inverses + matrix-vector products), SLP-vectorised"}
+         17: "the posterior's prior fusion (two 4x4 Cholesky inverses + matrix-vector products), SLP-vectorised",
+         18: "packed fp32 chain, op_sel:[0,1] op_sel_hi:[1,0]", 19: "packed fp32 chain, op_sel:[1,0]",
+         20: "v_pk_mul_f32 op_sel:[0,1] (src1 high half to both lanes)", 21: "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (src0 halves swapped)",
+         22: "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0] (both sources swapped)", 23: "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (src1 halves swapped)"}
 company = os.environ.get("COMPANY", "forward")
-modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23").split(",")]
 blocks, iters = int(os.environ.get("BLOCKS", "2048")), int(os.environ.get("ITERS", "40"))
 hw, batch = (512, 512), int(os.environ.get("B", "64"))
 b = None

@@ -215,6 +215,39 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ s
                 }
                 if (pass == 0) a = y.x + y.y; else b = y.x + y.y;
             }
+        } else if constexpr (MODE >= 20 && MODE <= 23) {   // which op_sel form: 20 src1 high half to BOTH lanes; 21 src0 halves swapped; 22 both swapped; 23 v_pk_add_f32 with src1 swapped
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                f2 y = {x, x * 1.5f}, k1 = {0.99993f, 0.99991f}, k2 = {x * 7.0e-5f, x * 9.0e-5f};
+                asm volatile("" : "+v"(y));
+#pragma unroll 16
+                for (int i = 0; i < 128; ++i) {
+                    f2 t;
+                    if constexpr (MODE == 20) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t) : "v"(y), "v"(k1)); asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2)); }
+                    else if constexpr (MODE == 21) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(y), "v"(k1)); asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2)); }
+                    else if constexpr (MODE == 22) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(t) : "v"(y), "v"(k1)); asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2)); }
+                    else { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(y), "v"(k1)); asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(y) : "v"(t), "v"(k2)); }
+                }
+                if (pass == 0) a = y.x + y.y; else b = y.x + y.y;
+            }
+        } else if constexpr (MODE == 18 || MODE == 19) {   // packed fp32 with op_sel (a result half fed from the OTHER half of a source pair), as in mode 17's code
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            a = 0.f; b = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                f2 y = {x, x * 1.5f}, k1 = {0.99993f, 0.99991f}, k2 = {x * 7.0e-5f, x * 9.0e-5f};
+                asm volatile("" : "+v"(y));
+#pragma unroll 16
+                for (int i = 0; i < 128; ++i) {
+                    f2 t;
+                    if constexpr (MODE == 18) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(y), "v"(k1));
+                    else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(t) : "v"(y), "v"(k1));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(t), "v"(k2));
+                }
+                if (pass == 0) a = y.x + y.y; else b = y.x + y.y;
+            }
         } else if constexpr (MODE == 17) {
             a = prior_fusion(xa, 1e-5f); b = prior_fusion(xb, 1e-5f);
         } else if constexpr (MODE >= 14 && MODE <= 16) {  // packed fp32 WITH operand modifiers, as the SLP vectoriser emits them for 4x4 inverses:
@@ -281,7 +314,7 @@ extern "C" int victim_run(int mode, int blocks, int iters, int cu_lo, int cu_hi)
         } else if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return 2;
     }
 #define LAUNCH(M) case M: hipLaunchKernelGGL(victim_kernel<M>, dim3(blocks), dim3(256), 0, g_stream, g_seeds, g_sink, iters); break;
-    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16) LAUNCH(17) default: return 3; }
+    switch (mode) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16) LAUNCH(17) LAUNCH(18) LAUNCH(19) LAUNCH(20) LAUNCH(21) LAUNCH(22) LAUNCH(23) default: return 3; }
     if (hipGetLastError() != hipSuccess) return 4;
     return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : 5;
 }
