@@ -1047,3 +1047,36 @@ def test_gather_detections_issues_a_real_rccl_gather():
         eng.close()
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16mx"])
+def test_no_detections_flow_through_the_whole_pipeline(precision):
+    """The reference's initialisation -- class bias -log(99) on every foreground class (multitask_headers.py:79-83) -- makes (almost) every
+    anchor's sampled class the background: M = 0 kept anchors, K = 0 centres.  Empty detections are not errors in the reference (size-0
+    arrays flow through run_inference.py:147-161): the fused pipeline, its pipelined form, the getters and the C gather must do the same --
+    zero counts, empty arrays of the right shapes, no failure -- also when only SOME images of a batch are empty."""
+    from bayes_od_rc_amd import synthetic
+    from bayes_od_rc_amd.anchor_generator import FpnAnchorGenerator
+    from bayes_od_rc_amd.engine import Engine, make_config
+    hw, n, batch = (128, 128), 3, 3
+    anchors = FpnAnchorGenerator(ANCHOR_CFG).generate_all((hw[0], hw[1], 3))
+    frames = synthetic.make_frames(batch, hw[0], hw[1], seed=21)
+    eng = Engine(make_config(hw, batch=batch, mc_samples=n, bayes_od_config=BAYES_CFG, nms_config=NMS_CFG, use_full_covar=True, precision=precision))
+    eng.load_weights(synthetic.make_weights(cls_fg_bias=-12.0))          # (beyond -log(99): no draw of 30 ever lands on a foreground class)
+    eng.set_anchors(anchors)
+    eng.infer(frames, seed=4, first_image_id=0)
+    assert np.array_equal(eng.num_kept(), np.zeros(batch, np.int32))
+    for i in range(batch):
+        post = eng.get_posterior(i)
+        assert post["means"].shape == (0, 4) and post["covs"].shape == (0, 4, 4) and post["counts"].shape == (0, 8)
+        assert eng.get_nms(i).shape == (0,)
+        s, m, c, k = eng.get_detections(i)
+        assert s.shape == (0, 8) and m.shape == (0, 4) and c.shape == (0, 4, 4) and k.shape == (0, 8)
+    det = eng.get_detections_batch()
+    assert np.array_equal(det["num"], np.zeros(batch, np.int32))
+    rec = eng.gather_detections(slot=-1)
+    assert rec.shape[:3] == (1, batch, eng.K) and not rec[..., 0].any()
+    slot = eng.infer_async(frames, seed=4, first_image_id=0)
+    got = eng.collect(slot)
+    assert np.array_equal(got["num"], np.zeros(batch, np.int32))
+    eng.close()
