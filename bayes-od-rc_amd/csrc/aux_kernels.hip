@@ -522,15 +522,207 @@ __global__ __launch_bounds__(256 * NCH, 1) void stem_pool_fused_kernel(const flo
     }
 }
 
-hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int B, int H, int W, int oh, int ow,
-                                  int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s) {
+// Round 6: the same walk for the (hi, lo) precisions (bf16x3, f16mx, f16mx4: the backbone on pairs of bf16).  Until now those modes ran
+// the exact fp32 stem (v_mfma_f32_32x32x2_f32, 75 TFLOP/s) and a separate pooling launch that split the maxima into pairs: 5.2 ms per
+// 256 frames of 512 x 512 against 0.8 for the bf16 kernel above.  Here the stem is three bf16 products like every other conv of those
+// modes -- w_hi x (x_hi + x_lo): the eleven k-steps of the kernel above on the hi weights; w_lo x x_hi: six more k-steps whose four
+// lane groups read four hi chunks -- the running maximum of the pooling window is fp32 (the max itself is exact), the window leaves
+// through an fp32 LDS tile, and the pooled pixel is stored as (hi, lo) pairs in the layout stem_pool_split_kernel writes (32 hi then
+// 32 lo per 64-slot group).  Per-layer error of the three-product form: 4e-6 of the output RMS, the class of every other
+// backbone conv of these modes.  BOD_STEM_POOL_FUSED=0 or a traced / training handle: the fp32 stem and the pooling launch as before.
+constexpr int SB_WROW_LO = 200;                     // uint16 per lo-weight row: 24 chunks x 8 + 8 pad (400 B rows: 16-byte aligned reads)
+constexpr int SFS_LDS_BYTES = SF_RING * 2 * SR_ROWE * 2 + 256 * 256;      // ring + fp32 tile [256 px][64 ch]
+static_assert(64 * SB_WROW * 2 + 64 * SB_WROW_LO * 2 <= 256 * 256, "both weight tables live in the tile until the loop starts");
+
+__global__ __launch_bounds__(512, 1) void stem_pool_fused_split_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias, uint16_t* __restrict__ pooled,
+                                                                       int B, int H, int W, int oh, int ow, int ph, int pw, int pool_pitch,
+                                                                       int pool_plane) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t sf_smem[];
+    uint16_t* const ring = sf_smem;
+    char* const tile = reinterpret_cast<char*>(sf_smem + SF_RING * 2 * SR_ROWE);      // [256 px][256 B], 16-byte chunks swizzled by the pixel
+    uint16_t (*wl)[SB_WROW] = reinterpret_cast<uint16_t (*)[SB_WROW]>(tile);
+    uint16_t (*wlo)[SB_WROW_LO] = reinterpret_cast<uint16_t (*)[SB_WROW_LO]>(tile + 64 * SB_WROW * 2);
+    constexpr int THREADS = 512, FW = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxq = wave & 3, chh = wave >> 2;
+    const int li = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < 64 * SB_WROW_LO; i += THREADS) {
+        const int co = i / SB_WROW_LO, kp = i % SB_WROW_LO;
+        const int c = kp >> 3, t = kp & 7, ky = c / 3, j = (c % 3) * 8 + t;
+        const float wv = (c < 21 && j < 21) ? w[(ky * 21 + j) * 64 + co] : 0.f;
+        const uint32_t hi = f32_to_bf16_a(wv);
+        if (kp < SB_WROW) wl[co][kp] = (uint16_t)hi;
+        wlo[co][kp] = (uint16_t)f32_to_bf16_a(wv - bf16_to_f32_a(hi));
+    }
+    constexpr int ROWQ = SR_ROWF / 4;
+    auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
+    const int valid = W * 3;
+    const float* const im = img + (size_t)blockIdx.x * H * W * 3;
+    auto fetch_quad = [&](int ir, int q) {
+        const int c = q * 4;
+        return (q < ROWQ && c < valid && ir < H) ? *reinterpret_cast<const float4*>(im + (size_t)ir * W * 3 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit_quad = [&](int ir, int q, const float4 v) {
+        if (q >= ROWQ) return;
+        uint16_t* pb = ring + ((ir & (SF_RING - 1)) * 2) * SR_ROWE + q * 4;
+        const uint32_t h0 = pk(v.x, v.y), h1 = pk(v.z, v.w);
+        const uint32_t l0 = pk(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xFFFF0000u));
+        const uint32_t l1 = pk(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xFFFF0000u));
+        *reinterpret_cast<uint2*>(pb) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pb + SR_ROWE) = make_uint2(l0, l1);
+    };
+    for (int ir = 0; ir < 7; ++ir)
+        for (int q = tid; q < ROWQ; q += THREADS) commit_quad(ir, q, fetch_quad(ir, q));
+    __syncthreads();
+    const int role = lq & 1, k1 = lq >> 1;
+    stem_bf16x8_t aqr[11][FW], alr[5][FW];
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int f = 0; f < FW; ++f) aqr[s][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wl[(chh * FW + f) * 16 + li][(2 * s + k1) * 8]);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int f = 0; f < FW; ++f) alr[t][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wlo[(chh * FW + f) * 16 + li][(4 * t + lq) * 8]);
+    // the last k-step of the first pass has a free slot: chunk 21 (k1 = 1) carries zero weights and reads chunk 20's data, plane `role` --
+    // the lane group with role 0 (lq = 2) takes w_lo of chunk 20 there, so the second pass is five k-steps (chunks 0 .. 19), not six
+    if (lq == 2) {
+#pragma unroll
+        for (int f = 0; f < FW; ++f) aqr[10][f] = *reinterpret_cast<const stem_bf16x8_t*>(&wlo[(chh * FW + f) * 16 + li][20 * 8]);
+    }
+    __syncthreads();                                                    // the tables' LDS becomes the pooling tile
+    f32x4_t vm[FW][4];                                                  // running maximum of the open pooling window (fp32)
+#pragma unroll
+    for (int f = 0; f < FW; ++f)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vm[f][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint16_t* const obase = pooled + (size_t)blockIdx.x * pool_plane * 128;
+
+    for (int r = 0; r < oh; ++r) {
+        constexpr int NQ = 1024 / THREADS;
+        float4 st[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { const int q = i * THREADS + tid; st[i] = fetch_quad(2 * r + 7 + (q >= 512), q & 511); }
+        f32x4_t acc[FW][4];
+#pragma unroll
+        for (int f = 0; f < FW; ++f)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[f][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // w_hi x (x_hi, x_lo): the k-steps of the bf16 kernel
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int c = 2 * s + k1;
+            const int cc = c < 21 ? c : 20;
+            const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
+            const uint16_t* pb = ring + ((((2 * r + ky) & (SF_RING - 1)) * 2) + role) * SR_ROWE + (pxq * 64 + li) * 6 + j0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                union { uint32_t u[4]; stem_bf16x8_t v; } bq;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(pb + p * 96);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq.u[t] = src[t];
+#pragma unroll
+                for (int f = 0; f < FW; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqr[s][f], bq.v, acc[f][p], 0, 0, 0);
+            }
+        }
+        // w_lo x x_hi: lane group lq reads hi chunk 4t + lq (chunk 20: see aqr[10] above)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int cc = 4 * t + lq;
+            const int ky = cc / 3, j0 = (cc - 3 * ky) * 8;
+            const uint16_t* pb = ring + (((2 * r + ky) & (SF_RING - 1)) * 2) * SR_ROWE + (pxq * 64 + li) * 6 + j0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                union { uint32_t u[4]; stem_bf16x8_t v; } bq;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(pb + p * 96);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq.u[u] = src[u];
+#pragma unroll
+                for (int f = 0; f < FW; ++f) acc[f][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alr[t][f], bq.v, acc[f][p], 0, 0, 0);
+            }
+        }
+        // bias + ReLU in fp32 (stem_conv_kernel<true>'s epilogue), then the window's running maximum
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+            const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + (chh * FW + f) * 16 + lq * 4);      // (per row: registers are short here)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = fmaxf(acc[f][p][q] + bv[q], 0.f);
+                    vm[f][p][q] = fmaxf(vm[f][p][q], v);
+                    acc[f][p][q] = v;                                  // (kept: an odd row opens the next window)
+                }
+        }
+        const bool closes = (r & 1) || r == oh - 1;
+        if (closes) {
+            const int prow = r >> 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int px = pxq * 64 + p * 16 + li;
+#pragma unroll
+                for (int f = 0; f < FW; ++f)
+                    *reinterpret_cast<f32x4_t*>(tile + px * 256 + ((((chh * FW + f) * 4 + lq) ^ (px & 15)) << 4)) = vm[f][p];
+            }
+            __syncthreads();
+            if (prow < ph) {
+                // horizontal window as above; a thread = (pooled column, eight channels): maxima of two 16-byte chunks, split into pairs
+                for (int i = tid; i < pw * 8; i += THREADS) {
+                    const int q = i >> 3, ch = i & 7;
+                    float m[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int px = 2 * q + kx - 2;
+                        if (px < 0 || px >= ow) continue;
+                        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(tile + px * 256 + (((2 * ch) ^ (px & 15)) << 4));
+                        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(tile + px * 256 + (((2 * ch + 1) ^ (px & 15)) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { m[e] = fmaxf(m[e], v0[e]); m[4 + e] = fmaxf(m[4 + e], v1[e]); }
+                    }
+                    uint32_t hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = pk(m[2 * e], m[2 * e + 1]);
+                        lo[e] = pk(m[2 * e] - __uint_as_float(hi[e] << 16), m[2 * e + 1] - __uint_as_float(hi[e] & 0xFFFF0000u));
+                    }
+                    const int c = ch * 8, slot = (c >> 5) * 64 + (c & 31);
+                    uint16_t* o = obase + ((size_t)(prow + 1) * pool_pitch + (q + 1)) * 128 + slot;
+                    *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                    *reinterpret_cast<uint4*>(o + 32) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int f = 0; f < FW; ++f) vm[f][p] = acc[f][p];
+        }
+        __syncthreads();
+        if (r + 1 < oh) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { const int q = i * THREADS + tid; commit_quad(2 * r + 7 + (q >= 512), q & 511, st[i]); }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int split, int B, int H, int W, int oh,
+                                  int ow, int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s) {
     static PerDeviceOnce once;
     bool& attr_set = *once.slot();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_fused_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SFS_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    if (split) {
+        hipLaunchKernelGGL(stem_pool_fused_split_kernel, dim3(B), dim3(512), SFS_LDS_BYTES, s, img, w, bias, reinterpret_cast<uint16_t*>(pooled), B, H, W,
+                           oh, ow, ph, pw, pool_pitch, pool_plane);
+        return hipGetLastError();
     }
     // BOD_STEM_WAVES=4: the four-wave form (round 3), A/B aid -- bit-identical pooled plane
     static const bool eight = [] { const char* e = getenv("BOD_STEM_WAVES"); return !e || atoi(e) != 4; }();

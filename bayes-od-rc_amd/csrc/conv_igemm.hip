@@ -2650,7 +2650,13 @@ __global__ __launch_bounds__(64 * WC * WP, (ABL == 10 ? (BC == 64 ? 3 : 2) : 1))
     // grid (tiles * groups, ny, 1), work item = tile * groups + group -- so that a pixel tile's three workgroups run back to
     // back on one XCD and the second and third find the pyramid rows in that XCD's L2 (grid.z-major order re-read the
     // 0.78 GB pyramid from HBM once per head: 3.2 GB fetched for 0.72 GB algorithmic, profiles/round2_head_conv_pmc.json)
-    if (gridDim.z == 1 && a.groups > 1 && a.ksplit <= 1) { gz = bx % a.groups; bx = bx / a.groups; }
+    if (gridDim.z == 1 && a.groups > 1 && a.ksplit <= 1) {
+        if (a.fan_chunk > 0) {
+            const int nxt = (a.M + BP - 1) / BP, T = a.fan_chunk, per = T * a.groups;
+            const int c = bx / per, w = bx - c * per, here = min(T, nxt - c * T);
+            gz = w / here; bx = c * T + (w - gz * here);
+        } else { gz = bx % a.groups; bx = bx / a.groups; }
+    }
     if constexpr (ABL == 5) {
         // De-phase the CUs of the fan-out launch.  Every CU holds one workgroup, all tiles take the same time, and a launch starts
         // all CUs together: the epilogues -- ten masked copies of the tile, 1.3 MB per CU -- would all store at the same moment
@@ -3004,6 +3010,12 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         a_local.flags |= CONV_NT_OUT;
     // bits 3 / 4 (f16mx towers): the per-sample tower layers' hx outputs / the first layer's ten-fold hx outputs
     if (a_local.mx && (((nt_stores & 8) && a_local.fan_count <= 1) || ((nt_stores & 16) && a_local.fan_count > 1))) a_local.flags |= CONV_NT_OUT;
+    {   // Work-item order of the fan-out launch (kernels.h ConvArgs.fan_chunk). Measured round 6 (profiles/round6_mx_ablations.txt,
+        // "fan-out work-item order"): chunks of 8..64 tiles are 0.9 % faster than the interleaved order (12.62 against 12.73 ms at
+        // 512 frames), all the same within noise; 16 is the default, BOD_FAN_CHUNK=0 gives the interleaved order back.
+        static const int fan_chunk = getenv("BOD_FAN_CHUNK") ? atoi(getenv("BOD_FAN_CHUNK")) : 16;
+        a_local.fan_chunk = (a_local.fan_count > 1 && a_local.groups > 1 && !a_local.mx && !a_local.split) ? fan_chunk : 0;
+    }
     const ConvArgs& a = a_local;
     if (a.M <= 0) return hipSuccess;
     if (a.cin % 64 != 0 || a.cout_pad % 64 != 0) return hipErrorInvalidValue;

@@ -1328,11 +1328,14 @@ bod_status run_forward(bod_context* h, const float* dev_images, uint64_t seed, u
                 // bf16 inference on rows of <= 256 stem pixels: stem + zero-pad + max-pool in one kernel (the stem plane is never
                 // written; aux_kernels.hip, BOD_STEM_POOL_FUSED=0: the two launches).  Training handles keep the plane (pool backward).
                 const Op* pool = op_i < h->ops.size() && h->ops[op_i].kind == Op::POOL ? &h->ops[op_i] : nullptr;
-                stem_pool_fused = pool && !h->train && h->es == 2 && !h->split && !trace &&
+                // Round 6: the (hi, lo) precisions take the same walk on three bf16 products (their stem was the exact fp32 kernel + a
+                // pooling launch: 5.2 ms per 256 frames against 0.8); BOD_STEM_SPLIT_FUSED=0: as before.
+                static const bool split_fused = [] { const char* e = getenv("BOD_STEM_SPLIT_FUSED"); return !e || atoi(e) != 0; }();
+                stem_pool_fused = pool && !h->train && (h->split ? split_fused : h->es == 2) && !trace &&
                                   stem_pool_fused_applies(dev_images, c.batch, c.image_w, h->sw, is_front ? cus_front : cus_back);
                 if (stem_pool_fused)
-                    HIPCHK(h, launch_stem_pool_fused(dev_images, h->stem_w, h->stem_b, pool->conv.g[0].out, c.batch, c.image_h, c.image_w, h->sh,
-                                                     h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
+                    HIPCHK(h, launch_stem_pool_fused(dev_images, h->stem_w, h->stem_b, pool->conv.g[0].out, h->split ? 1 : 0, c.batch, c.image_h,
+                                                     c.image_w, h->sh, h->sw, h->ph, h->pw, h->pw + 2, (h->ph + 2) * (h->pw + 2), st));
                 else
                 HIPCHK(h, launch_stem_conv(dev_images, h->stem_w, h->stem_b, h->stem_out, h->es == 4, c.batch, c.image_h,
                                            c.image_w, h->sh, h->sw, st));

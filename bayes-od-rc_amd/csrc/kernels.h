@@ -116,6 +116,10 @@ struct ConvArgs {
     // late, so that the ten-fold store bursts of the CUs' epilogues interleave with other CUs' main loops instead of all hitting HBM
     // at once (conv_igemm.hip).  0 = off.
     int32_t stagger_ticks;
+    // Fan-out launch, order of the (pixel tile, head) work items inside an XCD's range (round 6, BOD_FAN_CHUNK=T, A/B): 0 = interleaved
+    // (tile 0 heads 0 1 2, tile 1 ...: the three heads of a tile share its input rows through L2); T > 0 = chunks of T tiles, head-major
+    // inside a chunk (T tiles of head 0, the same T tiles of head 1, ...: one head's weights at a time in L2)
+    int32_t fan_chunk;
     // f16mx precision, head towers on the row-reuse loop (with `split`: same slot counts, same 1 KiB pixel rows): 1 = activations and
     // weights in the hx format, one f16 product + half a block-scaled e2m3 (fp6) product (the two cross terms) per multiplication; 2 = (hi, lo)
     // bf16 pairs in (the bf16x3 loop), epilogue able to write hx rows (first tower layer); 3 = activations and weights in the h4 format
@@ -153,8 +157,9 @@ hipError_t launch_stem_conv(const float* img, const float* w, const float* bias,
 // 2: fp32 -> (hi, lo) bf16 pairs (bf16x3 precision)
 // stem + zero-pad + max-pool in one kernel (bf16 inference, stem rows of <= 256 pixels; aux_kernels.hip)
 bool stem_pool_fused_applies(const float* img, int B, int W, int ow, int n_cu);
-hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int B, int H, int W, int oh, int ow,
-                                  int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s);
+// split = 1: the (hi, lo) precisions -- three bf16 products, fp32 pooling, pooled pixels stored as pairs (aux_kernels.hip)
+hipError_t launch_stem_pool_fused(const float* img, const float* w, const float* bias, void* pooled, int split, int B, int H, int W, int oh,
+                                  int ow, int ph, int pw, int pool_pitch, int pool_plane, hipStream_t s);
 hipError_t launch_stem_pool(const void* in, void* out, int mode, int B, int ih, int iw, int oh, int ow,
                             int out_pitch, int out_plane, hipStream_t s);
 

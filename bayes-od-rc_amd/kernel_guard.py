@@ -310,7 +310,7 @@ def check_asm_lds_reads(body, want, min_reads=60):
 
 
 # kernels of aux_kernels.o that run close to the register file's limit (one block per CU, ~490 VGPRs + AGPRs): no spills either
-AUX_PRODUCTION = ["stem_conv_bf16_row_kernel", "stem_pool_fused_kernel"]
+AUX_PRODUCTION = ["stem_conv_bf16_row_kernel", "stem_pool_fused_kernel", "stem_pool_fused_split_kernel"]
 
 
 def verify_aux(host_obj, wanted=AUX_PRODUCTION):

@@ -787,6 +787,55 @@ def test_fused_stem_pool_is_bit_identical():
         assert np.isfinite(outs[0][k]).all() and np.abs(outs[0][k]).max() > 0, k
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx"])
+def test_fused_stem_pool_of_the_pair_precisions_matches_the_fp32_stem(precision):
+    """Round 6: the (hi, lo) precisions run stem + zero-pad + max-pool as one kernel too (aux_kernels.hip,
+    stem_pool_fused_split_kernel: three bf16 products like every other conv of those modes, fp32 pooling, pooled pixels stored as
+    pairs).  BOD_STEM_SPLIT_FUSED=0 runs the exact fp32 stem + the pooling launch they had before.  The two are not bit-identical
+    (three bf16 products carry 4e-6 of the output RMS per layer): every pyramid level must agree within 2e-5 of its RMS in the RMS
+    and 2e-4 at the worst element (measured: 6.3e-5) -- the class of the backbone's other convs in these modes, a tenth of what the
+    precision-mode tests allow the whole forward -- on even / odd stem heights, widths below and at the 256-pixel limit, a ragged
+    last column, several images.  (A wrong tap, border or slot would show at 1e-2 and above.)"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from bayes_od_rc_amd import synthetic\n"
+            "from bayes_od_rc_amd.engine import Engine, make_config\n"
+            "out = {}\n"
+            "for tag, hw, b in (('a', (128, 128), 3), ('b', (96, 160), 2), ('c', (512, 512), 2), ('d', (192, 512), 1), ('e', (128, 126), 1)):\n"
+            "    eng = Engine(make_config(hw, batch=b, mc_samples=1, precision=%r))\n"
+            "    eng.load_weights(synthetic.make_weights())\n"
+            "    eng.forward(synthetic.make_frames(b, hw[0], hw[1], seed=4), seed=1, first_image_id=0)\n"
+            "    for l in range(5): out['%%s_p%%d' %% (tag, l)] = eng.get_pyramid(l)\n"
+            "    eng.close()\n"
+            "np.savez(sys.argv[1], **out)\n" % (root, precision))
+    outs = []
+    for on in ("1", "0"):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npz")
+            env = dict(os.environ, BOD_STEM_SPLIT_FUSED=on, BOD_STEM_POOL_FUSED_MIN_B="1")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            z = np.load(path)
+            outs.append({k: z[k] for k in z.files})
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) == 25
+    worst = worst_rms = 0.0
+    differs = 0
+    for k in sorted(outs[0]):
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        assert np.isfinite(a).all() and np.abs(a).max() > 0, k
+        rms = np.sqrt(np.mean(b * b))
+        rel, rel_rms = float(np.abs(a - b).max() / rms), float(np.sqrt(np.mean((a - b) ** 2)) / rms)
+        worst, worst_rms = max(worst, rel), max(worst_rms, rel_rms)
+        differs += int(not np.array_equal(a, b))
+        assert rel <= 2e-4 and rel_rms <= 2e-5, (k, rel, rel_rms)
+    assert differs > 0, "the fused kernel did not run (identical bits: both runs took the fp32 stem)"
+    print("fused (hi, lo) stem + pool against the fp32 stem, %s: over 25 pyramid levels max |d| / rms %.2e, rms(d) / rms %.2e" % (precision, worst, worst_rms))
+
+
 @pytest.mark.parametrize("hw,batch", [((512, 512), 128), ((720, 1280), 12), ((512, 1696), 12)])
 def test_streaming_backbone_kernels_are_bit_identical_at_full_size(hw, batch):
     """The round-3 backbone kernels (fused stem + pool, streaming pointwise with stage 2's fused reduction, sliding-window 3x3)

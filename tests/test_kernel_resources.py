@@ -41,14 +41,15 @@ def test_production_conv_kernels_do_not_spill(conv_object, tmp_path):
 def test_row_task_stem_kernel_does_not_spill():
     """The bf16 stem kernels keep their weight fragments in registers (one block per CU): the four-wave forms hold all 44 and sit
     close to the register file's limit; the eight-wave stem + pool kernel (round 4) holds half of them per wave and must stay
-    within the 256 registers two waves per SIMD leave each."""
+    within the 256 registers two waves per SIMD leave each -- and so must its (hi, lo) twin of round 6, which also holds the lo
+    weights of five more k-steps."""
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
     build_mod.build(verbose=False)
     regs = guard.verify_aux(os.path.join(build_mod.LIB_DIR, "obj", "aux_kernels.o"))
-    assert len(regs) == 3, regs
+    assert len(regs) == 4, regs
     for name, v in regs.items():
-        if "stem_pool_fused_kernelILi2E" in name:
+        if "stem_pool_fused_kernelILi2E" in name or "stem_pool_fused_split_kernel" in name:
             assert v <= 256, regs
         else:
             assert 256 < v <= 512, regs
