@@ -25,9 +25,10 @@ tests/tools/op_table.sh "$LABEL; f16mx4 (e2m1 cross terms, opt-in)" --precision 
 cp gpurun_out/op_table.txt gpurun_out/${P}_op_table_f16mx4.txt
 tests/tools/op_table.sh "$LABEL; parity mode of rounds 2-4" --precision bf16x3 --batch 256 > gpurun_out/${P}_op_table_x3.log 2>&1
 cp gpurun_out/op_table.txt gpurun_out/${P}_op_table_bf16x3.txt
-# the f16mx tower kernel: phase clock (with / without the loop's LDS-DMA) and SQ counters on its production launches (256 frames per step)
+# the f16mx tower kernel: phase clock (with / without the loop's LDS-DMA) and SQ counters on its production launches (256 frames per step);
+# the stamped variants exist for the hx instantiation only, hence BOD_MX_CLS_H4=0 (all three heads on hx rows: the three-head launch)
 ( echo "# f16mx tower kernel (conv_igemm_mx_kernel<1>), 256 frames, N = 10, 512x512: phase clock, variant 90; variant 91 = the same without the loop's LDS-DMA -- $LABEL";
-  PRECISION=f16mx B=256 python3 tests/tools/bench_head_conv.py 0:1 90:1 91:1 0:3 90:3 0:0 2>&1 | grep "phase clock\|round 1";
+  BOD_MX_CLS_H4=0 PRECISION=f16mx B=256 python3 tests/tools/bench_head_conv.py 0:1 90:1 91:1 0:3 90:3 0:0 2>&1 | grep "phase clock\|round 1\|Error";
   echo "# f16mx4 tower kernel (conv_igemm_mx_kernel<3>), same shapes: launch times per layer";
   PRECISION=f16mx4 B=256 python3 tests/tools/bench_head_conv.py 0:0 0:1 0:2 0:3 2>&1 | grep "round 1" ) > gpurun_out/${P}_f16mx_phase_clock.txt
 ( echo "# SQ counters of conv_igemm_mx_kernel over bench.py --precision f16mx --batch 256 --steps 2 (per-launch means over both instantiations) -- $LABEL";
