@@ -1662,6 +1662,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
         uint16_t* out16 = reinterpret_cast<uint16_t*>(G.out);
 
         // pass PASS of the tile: bias / residual / ReLU / (hi, lo) split / dropout mask in registers -> LDS tile [PPASS][ROW2]
+        const float clamp_lo = relu ? 0.f : -65504.0f;            // (uniform: hx / h4 epilogues)
         auto write_pass = [&](auto PASS, int n) {
             constexpr int pass = decltype(PASS)::value;
 #pragma unroll
@@ -1702,7 +1703,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
                                 float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
                                               __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
-                                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                                // ReLU and the f16 clamp are ONE v_med3_f32 between clamp_lo (0 with ReLU, -65504 without) and 65504 (round 6: the
+                                // separate maximum + select + median were three of the twelve vector instructions per element; same values: the
+                                // clamp commutes with the dropout's zeroing, and max(x, 0) then min(., 65504) is the median of the three)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], clamp_lo, 65504.0f);
                                 if (drop) {
                                     const DropPair dw = dropout_run_windows(rr, g4);
                                     const uint32_t thr = a.drop_threshold;
@@ -1712,7 +1717,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 uint16_t hb[4];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
                                     const _Float16 hh = (_Float16)v[r];
                                     hb[r] = __builtin_bit_cast(uint16_t, hh);
                                     const float hf = (float)hh;
@@ -1781,7 +1785,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 const float4 bv = *reinterpret_cast<const float4*>(s_bias + col);
                                 float v[4] = {__builtin_fmaf(acc[i][j][g4 * 4 + 0], epi_scale, bv.x), __builtin_fmaf(acc[i][j][g4 * 4 + 1], epi_scale, bv.y),
                                               __builtin_fmaf(acc[i][j][g4 * 4 + 2], epi_scale, bv.z), __builtin_fmaf(acc[i][j][g4 * 4 + 3], epi_scale, bv.w)};
-                                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                                // ReLU and the f16 clamp are ONE v_med3_f32 between clamp_lo (0 with ReLU, -65504 without) and 65504 (round 6: the
+                                // separate maximum + select + median were three of the twelve vector instructions per element; same values: the
+                                // clamp commutes with the dropout's zeroing, and max(x, 0) then min(., 65504) is the median of the three)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], clamp_lo, 65504.0f);
                                 if (drop) {
                                     const DropPair dw = dropout_run_windows(rr, g4);
                                     const uint32_t thr = a.drop_threshold;
@@ -1793,7 +1801,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gz, const
                                 for (int r = 0; r < 4; ++r) {
                                     // (f16 range: a tower activation beyond +-65 504 -- none in a trained RetinaNet, whose tower outputs stay below a
                                     // few hundred -- is clamped instead of becoming an infinity; the bf16x3 mode has no such limit)
-                                    v[r] = __builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
                                     const _Float16 hh = (_Float16)v[r];
                                     hb[r] = __builtin_bit_cast(uint16_t, hh);
                                     const float hf = (float)hh;
